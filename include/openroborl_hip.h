@@ -1,0 +1,235 @@
+/*
+ * openroborl_hip.h -- C-ABI of the MI355X-native vectorised quadruped imitation environment.
+ *
+ * Drop-in boundary.  The reference has no FFI: its boundary is the
+ * duck-typed Gym env consumed by PPOImitation / traj_segment_generator
+ *   (OpenRoboRL/envs/quadruped_robot/wrapper_env.py:58-107  WrapperEnv.step / reset,
+ *    OpenRoboRL/envs/quadruped_robot/quadruped_gym_env.py:63-104,213-239  reset / _step).
+ * Every entry point below names the reference call(s) it replaces.  The Python host side
+ * (openroborl_amd/env.py) binds these with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - plain C, no torch types; all device buffers are CALLER-OWNED (torch tensors' data_ptr()),
+ *     the library allocates only its small model/clip tables inside orr_create();
+ *   - every launch is asynchronous on the hipStream_t passed as void* (NULL = default stream);
+ *   - return value 0 = OK, negative = error (text via orr_last_error()); nothing throws;
+ *   - quaternions are [x, y, z, w] (reference: envs/utilities/pose3d.py:31,132-136);
+ *   - arithmetic type on device: float32.
+ */
+#ifndef OPENROBORL_HIP_H_
+#define OPENROBORL_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORR_ABI_VERSION 1
+
+#define ORR_NUM_MOTORS 12 /* laikago.py:29, mini_cheetah.py:29 */
+#define ORR_NUM_LEGS 4
+#define ORR_POSE_DIM 19     /* root pos 3 + root quat 4 + 12 joints  (motion_data.py:46-49)   */
+#define ORR_VEL_DIM 18      /* root vel 3 + root ang vel 3 + 12 joint rates                   */
+#define ORR_PROPRIO_DIM 84  /* IMU 12 | LastAction 36 | MotorAngle 36 (quadruped_gym_env.py:289-320) */
+#define ORR_NUM_TAR_FRAMES 4
+#define ORR_TARGET_DIM (ORR_NUM_TAR_FRAMES * ORR_POSE_DIM) /* imitation_task.py:254-301 */
+#define ORR_OBS_DIM (ORR_PROPRIO_DIM + ORR_TARGET_DIM)     /* 160, wrapper_env.py:109-125 */
+#define ORR_MAX_ROBOT_TYPES 4
+#define ORR_MAX_CLIPS 16
+#define ORR_MAX_FALL_PROXIES 16
+#define ORR_RING_DEPTH 44   /* latency <= 0.04 s -> int(0.04/0.001)+1 = 41 entries needed      */
+#define ORR_RING_ENTRY 20   /* 12 motor angles + 4 rel. quat + 3 rpy rate (+1 pad)             */
+
+/* ---------------------------------------------------------------------------------------
+ * Per-robot state record: ORR_STATE_STRIDE 32-bit words, one record per robot, records
+ * contiguous ([N, ORR_STATE_STRIDE] tensor).  One wavefront owns one record: lane k loads
+ * word k, k+64, ... (coalesced).  X(name, words, kind) with kind F = float32, I = int32.
+ * Reference provenance of every group: SURVEY.md Appendix A.1.
+ * ------------------------------------------------------------------------------------- */
+#define ORR_STATE_FIELDS(X)                                                                   \
+  /* rigid state, Bullet conventions: base COM frame, world-frame velocities */               \
+  X(POS, 3, F) X(QUAT, 4, F) X(LINVEL, 3, F) X(ANGVEL, 3, F)                                  \
+  X(Q, 12, F)  /* URDF joint coordinates, URDF joint order */                                 \
+  X(QD, 12, F)                                                                                \
+  /* actuator (minitaur.py:160-164,280-293; action_filter.py:99-127), motor order */          \
+  X(ACTION, 12, F) X(FILTER_ACTION, 12, F) X(LAST_ACTION, 12, F)                              \
+  X(XHIST, 24, F) /* x[n-1] (12), x[n-2] (12) */                                              \
+  X(YHIST, 24, F)                                                                             \
+  /* 3-deep sensor histories, newest first (sensor_wrappers.py:122-142) */                    \
+  X(IMU_HIST, 12, F) X(LASTACT_HIST, 36, F) X(MOTORANG_HIST, 36, F)                           \
+  /* task (imitation_task.py:105-139) */                                                      \
+  X(TIME_OFFSET, 1, F) X(ORIGIN_POS, 3, F) X(ORIGIN_ROT, 4, F) X(PREV_PHASE, 1, F)            \
+  X(REF_POSE, 19, F) X(REF_VEL, 18, F)                                                        \
+  /* per-episode randomised parameters (controllable_env_randomizer_from_config.py) */        \
+  X(STRENGTH, 12, F) X(LATENCY, 1, F) X(FOOT_MU, 1, F) X(KNEE_FRICTION, 4, F)                 \
+  X(MASS_RATIO, 2, F) X(INERTIA_RATIO, 2, F) X(BASE_DAMPING, 2, F)                            \
+  /* contact warm start: per leg (normal, t1, t2) impulses */                                 \
+  X(LAMBDA, 12, F)                                                                            \
+  X(EP_RETURN, 1, F) X(LAST_EP_RETURN, 1, F) X(GRID_OFFSET, 2, F)                             \
+  /* integers */                                                                              \
+  X(STATE_ACTION_COUNTER, 1, I) /* minitaur.py:186-189 */                                     \
+  X(STEP_COUNTER, 1, I)                                                                       \
+  X(FILTER_VALID, 1, I)  /* _filter_action is not None (minitaur.py:450-453) */               \
+  X(RING_LEN, 1, I) X(RING_HEAD, 1, I)                                                        \
+  X(EPISODE_IDX, 1, I)   /* RNG stream selector */                                            \
+  X(EP_STEP, 1, I)       /* env_step_counter, per robot (quadruped_gym_env.py:88,237) */      \
+  X(WARMUP, 1, I)        /* _curr_episode_warmup */                                           \
+  X(MAX_EP_STEPS, 1, I)  /* wrapper_env.py:151-159 */                                         \
+  X(ROBOT_TYPE, 1, I) X(CLIP_ID, 1, I)                                                        \
+  X(ROBOT_INDEX, 1, I)   /* global robot index (RNG key, grid slot) */                        \
+  X(LAST_EP_LEN, 1, I) X(DONE_REASON, 1, I) X(RESERVED_I, 2, I)                               \
+  /* latency ring (minitaur.py:127,313-357): ORR_RING_DEPTH entries of ORR_RING_ENTRY */      \
+  X(RING, ORR_RING_DEPTH * ORR_RING_ENTRY, F)
+
+enum orr_state_offset_e {
+#define ORR_X_OFF(name, words, kind) ORR_OFF_##name, ORR_OFFEND_##name = ORR_OFF_##name + (words)-1,
+  ORR_STATE_FIELDS(ORR_X_OFF)
+#undef ORR_X_OFF
+      ORR_STATE_WORDS
+};
+#define ORR_STATE_STRIDE 1216 /* ORR_STATE_WORDS rounded up to a multiple of 64 (19 x 64) */
+
+/* done reasons (bit mask) */
+#define ORR_DONE_CONTACT_FALL 1 /* imitation_task.py:536-546 */
+#define ORR_DONE_ROOT_POS 2     /* imitation_task.py:553-556 */
+#define ORR_DONE_ROOT_ROT 4     /* imitation_task.py:558-565 */
+#define ORR_DONE_TIME_LIMIT 8   /* wrapper_env.py:79 */
+#define ORR_DONE_NAN 16         /* new: non-finite state guard */
+
+/* orr_config.flags */
+#define ORR_FLAG_AUTO_RESET 1        /* per-robot masked auto-reset inside orr_step (native mode) */
+#define ORR_FLAG_RANDOMIZER 2        /* run.py:205-206: enabled when mode == "train" */
+#define ORR_FLAG_CYCLE_SYNC 4        /* run.py:61 enable_cycle_sync=True */
+#define ORR_FLAG_LEGACY_GRID 8       /* minitaur.py:246-248: 2 m grid slots (float32 loses precision at N>>100) */
+#define ORR_FLAG_CURRICULUM 16       /* wrapper_env.py:147-159 */
+
+/* clip flags (motion_data.py:83-97) */
+#define ORR_CLIP_WRAP 1
+#define ORR_CLIP_CYCLE_POS 2
+#define ORR_CLIP_CYCLE_ROT 4
+
+typedef struct orr_config {
+  int32_t abi_version;     /* ORR_ABI_VERSION */
+  int32_t num_robots;      /* robots on THIS device (shard size) */
+  int32_t action_repeat;   /* 33: laikago.py:26 */
+  int32_t solver_iters;    /* int(300/33) = 9: quadruped_gym_env.py:177-178 */
+  float sim_dt;            /* 0.001: pybullet_sim_param.yaml:3 */
+  float gravity_z;         /* -10: quadruped_gym_env.py:200 */
+  float reward_w[5];       /* pose, velocity, end-effector, root pose, root velocity: imitation_task.py:45-49 */
+  float reward_scale[6];   /* pose, vel, end-eff, end-eff height, root pose, root vel: imitation_task.py:50-55 */
+  int32_t tar_frame_steps[ORR_NUM_TAR_FRAMES]; /* run.py:62 [1,2,10,30] */
+  float ref_state_init_prob; /* run.py:63 0.9 */
+  float warmup_time;         /* run.py:64 0.25 */
+  int32_t ep_len_start;      /* run.py:54 20 */
+  int32_t ep_len_end;        /* run.py:55 600 */
+  int64_t curriculum_steps;  /* ceil(3e7 / num_procs): wrapper_env.py:45-46 */
+  uint64_t seed;
+  int32_t flags;
+  /* physics-engine constants (Bullet defaults; parity-unpinned) */
+  float contact_erp;         /* 0.2 */
+  float contact_margin;      /* 0.02 contact breaking threshold */
+  float warmstart_factor;    /* 0.85 */
+  float max_coord_velocity;  /* 100 */
+  float plane_friction;      /* 1.0 plane_implicit.urdf */
+  float limit_activation;    /* 0.1 rad: a joint-limit row exists iff the joint is this close */
+  float max_angle_change;    /* 0.2: laikago.py:71 MAX_MOTOR_ANGLE_CHANGE_PER_STEP */
+  float dist_fail_threshold; /* 1.0: imitation_task.py:518 */
+  float rot_fail_threshold;  /* pi/2 */
+} orr_config;
+
+/* Robot model table (data, swappable without touching kernels).  All geometry is given in the
+ * "kinematic" body frame (x forward, y left, z up) at zero motor angles, where every link frame
+ * is parallel to the base frame.  Base orientation used by the dynamics is
+ * QUAT (x) INIT_QUAT^-1 (the reference's "relative orientation", minitaur.py:325-331), so the
+ * stored QUAT stays in the URDF convention of the motion clips.
+ * Bodies: 0 = base; 1 + 3*leg + k, k = 0 hip(abduction) link, 1 upper leg, 2 lower leg (+ fixed toe
+ * merged for the dynamics).  Joint j = 3*leg + k (URDF joint order) connects body j+1 to its parent. */
+typedef struct orr_model {
+  float init_pos[3];                    /* laikago.py:48 / mini_cheetah.py:49 */
+  float init_quat[4];                   /* laikago.py:49 / mini_cheetah.py:50 */
+  float init_motor_angles[ORR_NUM_MOTORS]; /* motor order; laikago.py:62 */
+  float motor_dir[ORR_NUM_MOTORS];      /* JOINT_DIRECTIONS, motor order */
+  float motor_offset[ORR_NUM_MOTORS];   /* JOINT_OFFSETS, motor order */
+  int32_t joint_of_motor[ORR_NUM_MOTORS]; /* URDF joint index driven by motor m (MOTOR_NAMES order) */
+  float kp[ORR_NUM_MOTORS];             /* motor order; laikago.py:65 */
+  float kd[ORR_NUM_MOTORS];
+  float base_mass;
+  float base_inertia[6];                /* xx yy zz xy xz yz about the base COM */
+  float link_mass[12];
+  float link_com[12][3];                /* in link frame (origin = joint origin) */
+  float link_inertia[12][6];            /* about link COM; scales with the inertia ratio */
+  float link_inertia_pa[12][6];         /* parallel-axis part of a merged (lower leg + toe) link; scales with the mass ratio */
+  int32_t link_group[12];               /* 0 = "base" randomisation group (hip links), 1 = "leg" group (minitaur.py:812-851) */
+  float joint_pos[12][3];               /* joint origin in the parent link frame */
+  float joint_axis[12][3];              /* unit axis; kinematic angle = dir * (q_urdf - offset) */
+  float joint_lo[12];                   /* limits in kinematic (motor-convention) angle */
+  float joint_hi[12];
+  float toe_pos[4][3];                  /* toe sphere centre in the lower-leg link frame (= toe link COM) */
+  float lower_com[4][3];                /* lower leg's own COM (end-effector reward, imitation_task.py:441-446) */
+  float toe_radius;
+  float foot_friction;                  /* default lateral friction of toe / lower leg */
+  int32_t num_fall_proxies;             /* termination-only collision spheres on non-foot links */
+  int32_t fall_body[ORR_MAX_FALL_PROXIES];
+  float fall_pos[ORR_MAX_FALL_PROXIES][3];
+  float fall_radius[ORR_MAX_FALL_PROXIES];
+} orr_model;
+
+/* device-side global counters, caller-owned int64[ORR_NUM_COUNTERS], zero-initialised */
+enum orr_counter_e {
+  ORR_CNT_TOTAL_STEP_COUNT = 0, /* wrapper_env.py:47,82-83 curriculum counter */
+  ORR_CNT_DONE_ACCUM = 1,       /* per-launch scratch */
+  ORR_CNT_TICKET = 2,           /* per-launch scratch */
+  ORR_CNT_TOTAL_TIMESTEPS = 3,  /* robot-steps executed (ppo_imitation.py:421) */
+  ORR_CNT_EPISODES = 4,         /* finished episodes appended to the episode log */
+  ORR_CNT_EPLOG_DROPPED = 5,
+  ORR_NUM_COUNTERS = 8
+};
+
+typedef struct orr_handle orr_handle;
+
+const char* orr_last_error(void);
+int32_t orr_abi_version(void);
+int32_t orr_state_stride(void);                 /* ORR_STATE_STRIDE */
+int32_t orr_layout_count(void);                 /* number of fields in ORR_STATE_FIELDS */
+const char* orr_layout_name(int32_t i);
+int32_t orr_layout_offset(int32_t i);
+int32_t orr_layout_size(int32_t i);
+int32_t orr_layout_is_int(int32_t i);
+int32_t orr_sizeof_config(void);
+int32_t orr_sizeof_model(void);
+
+/* replaces LocomotionGymEnv._init world setup (quadruped_gym_env.py:158-211) */
+int32_t orr_create(const orr_config* cfg, orr_handle** out);
+int32_t orr_destroy(orr_handle* h);
+
+/* replaces loadURDF + _build_urdf_ids + _record_*_from_urdf (minitaur.py:201-230,812-851,897-903) */
+int32_t orr_set_model(orr_handle* h, int32_t robot_type, const orr_model* model_host);
+
+/* replaces MotionData.load results (motion_data.py:72-112): frames [F,19] and frame velocities
+ * [F,18] are DEVICE pointers to post-processed data; cycle_delta = {dx, dy, dz(=0), dheading}. */
+int32_t orr_set_motion(orr_handle* h, int32_t clip_id, const float* frames_dev, const float* frame_vels_dev,
+                       int32_t num_frames, float frame_dt, int32_t clip_flags, const float cycle_delta[4]);
+
+/* bind caller-owned device buffers: state [N, ORR_STATE_STRIDE] words, counters int64[8],
+ * episode log float[ep_log_capacity][2] = (return, length) (may be NULL / 0). */
+int32_t orr_bind(orr_handle* h, void* state_dev, int64_t* counters_dev, float* ep_log_dev, int32_t ep_log_capacity);
+
+/* replaces WrapperEnv.reset (wrapper_env.py:87-107): mask_dev NULL = all robots; obs_dev [N,160]
+ * (rows of robots that are not reset are left untouched). */
+int32_t orr_reset(orr_handle* h, const uint8_t* mask_dev, float* obs_dev, void* stream);
+
+/* replaces WrapperEnv.step (wrapper_env.py:58-85): actions [N,12] policy outputs (already clipped to
+ * +-2pi by the caller, imitation_runners.py:140-143; NOT modified, unlike minitaur.py:281);
+ * obs [N,160], reward [N], done [N] (uint8). */
+int32_t orr_step(orr_handle* h, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev,
+                 void* stream);
+
+/* last launch durations in ms measured with hipEvents on the launch stream (bench only; syncs) */
+int32_t orr_time_steps(orr_handle* h, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev,
+                       void* stream, int32_t num_steps, float* total_ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPENROBORL_HIP_H_ */

@@ -1,0 +1,85 @@
+"""Configuration: the reference's two YAML files -> orr_config.
+
+  training_param.yaml    task sections `imitation_learning_laikago` / `imitation_learning_minicheetah`
+                         (keys read at OpenRoboRL/run.py:194-215)
+  pybullet_sim_param.yaml section `quadruped_robot` (quadruped_gym_env.py:159-178)
+
+Hyper-parameters the reference hard-codes in run.py:54-64 (episode-length curriculum 20 -> 600 over
+3e7 steps, tar_frame_steps [1, 2, 10, 30], ref_state_init_prob 0.9, warmup 0.25 s) and in
+imitation_task.py:45-55 (reward weights / scales) are defaults here.
+"""
+import math
+import os
+
+import yaml
+
+from . import _abi
+
+_PKG_CFG = os.path.join(os.path.dirname(os.path.abspath(__file__)), "config")
+DEFAULT_TRAINING_YAML = os.path.join(_PKG_CFG, "training_param.yaml")
+DEFAULT_SIM_YAML = os.path.join(_PKG_CFG, "pybullet_sim_param.yaml")
+
+TASKS = ("imitation_learning_laikago", "imitation_learning_minicheetah")
+ACTION_REPEAT = 33          # laikago.py:26, mini_cheetah.py:26 NUM_ACTION_REPEAT
+CTRL_LATENCY = 0.002        # laikago.py:27
+
+
+def load_training_params(task_name, path=None):
+    """run.py:194-200: section lookup by --task; ValueError when missing."""
+    path = path or DEFAULT_TRAINING_YAML
+    with open(path) as f:
+        d = yaml.safe_load(f)
+    if task_name not in d:
+        raise ValueError("Hyperparameters not found for %s in %s" % (task_name, path))
+    return d[task_name]
+
+
+def load_sim_params(path=None):
+    """quadruped_gym_env.py:159-165."""
+    path = path or DEFAULT_SIM_YAML
+    with open(path) as f:
+        d = yaml.safe_load(f)
+    if "quadruped_robot" not in d:
+        raise ValueError("Hyperparameters not found for pybullet_sim_config.yaml")
+    return d["quadruped_robot"]
+
+
+def make_config(num_robots, sim_params=None, mode="train", enable_randomizer=None, seed=0, num_procs=1,
+                auto_reset=True, legacy_grid=False, curriculum=None):
+    sim = dict(sim_time_step_s=0.001, num_sim_iter_step=300)
+    sim.update(sim_params or {})
+    c = _abi.OrrConfig()
+    c.abi_version = _abi.ABI_VERSION
+    c.num_robots = int(num_robots)
+    c.action_repeat = ACTION_REPEAT
+    c.solver_iters = int(sim["num_sim_iter_step"] / ACTION_REPEAT)   # quadruped_gym_env.py:177-178
+    if c.action_repeat < 1 or c.solver_iters < 1:
+        raise ValueError("num_sim_iter_step / action_repeat must be >= 1")
+    c.sim_dt = float(sim["sim_time_step_s"])
+    c.gravity_z = -10.0                                               # quadruped_gym_env.py:200
+    c.reward_w[:] = [0.5, 0.05, 0.2, 0.15, 0.1]                       # imitation_task.py:45-49
+    c.reward_scale[:] = [5.0, 0.1, 40.0, 3.0, 20.0, 2.0]              # imitation_task.py:50-55
+    c.tar_frame_steps[:] = [1, 2, 10, 30]                             # run.py:62
+    c.ref_state_init_prob = 0.9                                       # run.py:63
+    c.warmup_time = 0.25                                              # run.py:64
+    c.ep_len_end = 600                                                # run.py:55
+    c.ep_len_start = 600 if mode == "test" else 20                    # run.py:54,66-67
+    c.curriculum_steps = int(math.ceil(30000000 / float(num_procs)))  # run.py:75; wrapper_env.py:45-46
+    c.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    if enable_randomizer is None:
+        enable_randomizer = mode == "train"                           # run.py:205-206
+    if curriculum is None:
+        curriculum = True                                             # wrapper_env.py:147-149 (steps > 0)
+    c.flags = ((_abi.FLAG_AUTO_RESET if auto_reset else 0) | (_abi.FLAG_RANDOMIZER if enable_randomizer else 0) |
+               _abi.FLAG_CYCLE_SYNC | (_abi.FLAG_LEGACY_GRID if legacy_grid else 0) |
+               (_abi.FLAG_CURRICULUM if curriculum else 0))
+    c.contact_erp = 0.2
+    c.contact_margin = 0.02
+    c.warmstart_factor = 0.85
+    c.max_coord_velocity = 100.0
+    c.plane_friction = 1.0
+    c.limit_activation = 0.1
+    c.max_angle_change = 0.2                                          # laikago.py:71
+    c.dist_fail_threshold = 1.0                                       # imitation_task.py:518
+    c.rot_fail_threshold = 0.5 * math.pi
+    return c

@@ -1,0 +1,118 @@
+"""Motion-clip loading (host side, load time only).
+
+Reads the reference's clip format -- JSON with LoopMode / FrameDuration / EnableCycleOffsetPosition /
+EnableCycleOffsetRotation / Frames, 19 floats per frame = root pos 3 + root quat xyzw 4 + 12 joint
+angles (task/motions/*.txt) -- and derives what the device kernels consume:
+
+  frames      [F,19]  first-frame xy removed, quaternions normalised and standardised (w >= 0)
+                      (motion_data.py:527-556 _postprocess_frames)
+  frame_vels  [F,18]  finite differences: root vel, root angular velocity = angle/dt * axis of
+                      q[f+1] (x) q[f]^*, joint rates; last row replicated (motion_data.py:635-680)
+  cycle_delta [4]     (dx, dy, 0, dheading) over one cycle (motion_data.py:558-589)
+
+Time -> frame sampling (calc_blend_idx / calc_frame / calc_frame_vel) happens on the device.
+"""
+import json
+import os
+
+import numpy as np
+
+from . import _abi
+
+DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "motions")
+
+
+def _qmul(a, b):
+    x1, y1, z1, w1 = a
+    x0, y0, z0, w0 = b
+    return np.array([x1 * w0 + y1 * z0 - z1 * y0 + w1 * x0,
+                     -x1 * z0 + y1 * w0 + z1 * x0 + w1 * y0,
+                     x1 * y0 - y1 * x0 + z1 * w0 + w1 * z0,
+                     -x1 * x0 - y1 * y0 - z1 * z0 + w1 * w0])
+
+
+def _qconj(q):
+    return np.array([-q[0], -q[1], -q[2], q[3]])
+
+
+def _rotate_x_axis_heading(q):
+    """atan2 of the rotated x axis (pose3d.py:325-341), valid for unit q."""
+    x, y, z, w = q
+    return np.arctan2(2.0 * (x * y + z * w), 1.0 - 2.0 * (y * y + z * z))
+
+
+def resolve_path(path):
+    """Accept a reference-style path (e.g. 'OpenRoboRL/envs/.../motions/laikago_pace.txt'), an
+    absolute path, or a bare clip name; fall back to the clips shipped with this package."""
+    if os.path.isfile(path):
+        return path
+    base = os.path.basename(path)
+    for cand in (base, base + ".txt"):
+        p = os.path.join(DATA_DIR, cand)
+        if os.path.isfile(p):
+            return p
+    raise FileNotFoundError("motion clip not found: %r (looked in %s too)" % (path, DATA_DIR))
+
+
+class MotionClip(object):
+    """Post-processed clip; mirrors the constructor work of MotionData (motion_data.py:56-112)."""
+
+    def __init__(self, path):
+        self.path = resolve_path(path)
+        with open(self.path, "r") as f:
+            js = json.load(f)
+        self.loop_wrap = js["LoopMode"] == "Wrap"
+        self.frame_duration = float(js["FrameDuration"])
+        self.cycle_pos = bool(js.get("EnableCycleOffsetPosition", False))
+        self.cycle_rot = bool(js.get("EnableCycleOffsetRotation", False))
+        frames = np.array(js["Frames"], dtype=np.float64)
+        if frames.ndim != 2 or frames.shape[0] < 1:
+            raise ValueError("Must have at least 1 frame.")
+        if frames.shape[1] != _abi.POSE_DIM:
+            raise ValueError("Frames must have %d values (got %d)." % (_abi.POSE_DIM, frames.shape[1]))
+        if not self.frame_duration > 0:
+            raise ValueError("Frame duration must be positive.")
+        self.frames = self._postprocess(frames)
+        self.frame_vels = self._frame_vels(self.frames, self.frame_duration)
+        self.num_frames = self.frames.shape[0]
+        self.duration = self.frame_duration * (self.num_frames - 1)
+        d = self.frames[-1, 0:3] - self.frames[0, 0:3]
+        d[2] = 0.0
+        dq = _qmul(self.frames[-1, 3:7], _qconj(self.frames[0, 3:7]))
+        self.cycle_delta = np.array([d[0], d[1], 0.0, _rotate_x_axis_heading(dq / np.linalg.norm(dq))])
+
+    @staticmethod
+    def _postprocess(frames):
+        out = frames.copy()
+        out[:, 0] -= frames[0, 0]
+        out[:, 1] -= frames[0, 1]
+        q = out[:, 3:7]
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+        q[q[:, 3] < 0] *= -1.0
+        return out
+
+    @staticmethod
+    def _frame_vels(frames, dt):
+        nf = frames.shape[0]
+        vels = np.zeros((nf, _abi.VEL_DIM))
+        for f in range(nf - 1):
+            a, b = frames[f], frames[f + 1]
+            vels[f, 0:3] = (b[0:3] - a[0:3]) / dt
+            dq = _qmul(b[3:7], _qconj(a[3:7]))
+            n = np.linalg.norm(dq[:3])
+            axis = np.array([0.0, 0.0, 1.0]) if n < 1e-8 else dq[:3] / n
+            angle = 2.0 * np.arctan2(n, dq[3])
+            vels[f, 3:6] = (angle / dt) * axis
+            vels[f, 6:] = (b[7:] - a[7:]) / dt
+        if nf > 1:
+            vels[-1] = vels[-2]
+        return vels
+
+    @property
+    def flags(self):
+        return ((_abi.CLIP_WRAP if self.loop_wrap else 0) | (_abi.CLIP_CYCLE_POS if self.cycle_pos else 0) |
+                (_abi.CLIP_CYCLE_ROT if self.cycle_rot else 0))
+
+    def joint_bounds(self):
+        """Per-dimension min / max over frames (imitation_task.py:303-335, before root overrides)."""
+        return self.frames.min(axis=0), self.frames.max(axis=0)

@@ -1,0 +1,198 @@
+"""Robot model tables (data) for the Laikago and mini-cheetah quadrupeds.
+
+The reference loads `laikago/laikago_toes_limits.urdf` and `mini_cheetah/mini_cheetah.urdf` from
+the third-party `pybullet_data` package (robots/laikago.py:23, robots/mini_cheetah.py:23); those
+files are neither under /root/reference nor in this image.  What IS in the reference tree and is
+reproduced exactly here:
+
+  * control constants: INIT_POSITION / INIT_QUAT / INIT_MOTOR_ANGLES / JOINT_DIRECTIONS /
+    JOINT_OFFSETS / motor_kp / motor_kd / MOTOR_NAMES order (robots/laikago.py:29-66,
+    robots/mini_cheetah.py:29-67);
+  * leg kinematics (link lengths and the motor-angle sign conventions) used by the authors' own
+    retargeting scripts: coxa/femur/tibia = 0.032875/0.25223/0.251 (Laikago) and 0.062/0.209/0.18
+    (mini-cheetah), FK p = [t*s23 + f*s2, c*side*c1 + (t*c23 + f*c2)*s1, c*side*s1 - (t*c23 + f*c2)*c1]
+    (task/motions/trans2minicheetah.m:3-5,28-30; trans_data.py:55-69), and the URDF<->kinematic
+    angle maps (trans2minicheetah.m:8-9,32);
+  * hip positions +-0.21 / +-0.1157 (robots/laikago.py:54-59);
+  * URDF joint order = motion-frame joint order: FR, FL, RR, RL (Laikago; laikago.py:31-44) and
+    fr, fl, hr, hl (mini-cheetah; sign pattern of the abduction columns of minicheetah_trot.txt),
+    while the mini-cheetah MOTOR order is fl, hl, fr, hr (mini_cheetah.py:31-44).
+
+Inertial parameters, collision proxies, joint limits and the toe radius are HAND-AUTHORED
+(Unitree / MIT-published figures from memory) and are **parity-unpinned**; they live only in this
+file so they can be swapped without touching a kernel.
+
+Frames: "kinematic" body frame x forward, y left, z up; all link frames are parallel to it at zero
+motor angles; the kinematic joint angle equals the motor angle `dir * (q_urdf - offset)`.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+
+LEG_SX = np.array([1.0, 1.0, -1.0, -1.0])   # front / rear
+LEG_SY = np.array([-1.0, 1.0, -1.0, 1.0])   # right / left  (URDF leg order R, L, R, L)
+
+
+def _sphere_inertia(m, r):
+    return np.array([0.4 * m * r * r] * 3 + [0.0] * 3)
+
+
+def _pa(m, d):
+    """Parallel-axis inertia (xx yy zz xy xz yz) of a point mass m at offset d."""
+    x, y, z = d
+    return m * np.array([y * y + z * z, x * x + z * z, x * x + y * y, -x * y, -x * z, -y * z])
+
+
+def _build(name, init_pos, init_quat, init_motor_angles, motor_dir, motor_offset, joint_of_motor, kp, kd,
+           base_mass, base_inertia, hip_xy, coxa, femur, tibia, pitch_axis,
+           hip_m, hip_com, hip_I, up_m, up_com, up_I, lo_m, lo_com, lo_I, toe_m, toe_r,
+           limits, chassis_half, hip_r, knee_r, foot_friction):
+    m = {
+        "name": name,
+        "init_pos": np.array(init_pos, dtype=np.float64),
+        "init_quat": np.array(init_quat, dtype=np.float64),
+        "init_motor_angles": np.array(init_motor_angles, dtype=np.float64),
+        "motor_dir": np.array(motor_dir, dtype=np.float64),
+        "motor_offset": np.array(motor_offset, dtype=np.float64),
+        "joint_of_motor": np.array(joint_of_motor, dtype=np.int32),
+        "kp": np.array(kp, dtype=np.float64),
+        "kd": np.array(kd, dtype=np.float64),
+        "base_mass": float(base_mass),
+        "base_inertia": np.array(list(base_inertia) + [0.0, 0.0, 0.0]),
+        "toe_radius": float(toe_r),
+        "foot_friction": float(foot_friction),
+    }
+    link_mass = np.zeros(12)
+    link_com = np.zeros((12, 3))
+    link_I = np.zeros((12, 6))
+    link_Ipa = np.zeros((12, 6))
+    link_group = np.zeros(12, dtype=np.int32)
+    jpos = np.zeros((12, 3))
+    jaxis = np.zeros((12, 3))
+    jlo = np.zeros(12)
+    jhi = np.zeros(12)
+    toe_pos = np.zeros((4, 3))
+    lower_com = np.zeros((4, 3))
+    fall_body, fall_pos, fall_radius = [], [], []
+    for sx in (1, -1):
+        for sy in (1, -1):
+            for sz in (1, -1):
+                fall_body.append(0)
+                fall_pos.append([sx * chassis_half[0], sy * chassis_half[1], sz * chassis_half[2]])
+                fall_radius.append(0.0)
+    for leg in range(4):
+        sx, sy = LEG_SX[leg], LEG_SY[leg]
+        j0 = 3 * leg
+        # hip (abduction) link: "base" randomisation group (minitaur.py:828-829 chassis_link_ids)
+        jpos[j0] = [sx * hip_xy[0], sy * hip_xy[1], 0.0]
+        jaxis[j0] = [1.0, 0.0, 0.0]
+        link_mass[j0] = hip_m
+        link_com[j0] = [hip_com[0] * sx, hip_com[1] * sy, hip_com[2]]
+        link_I[j0] = list(hip_I) + [0, 0, 0]
+        link_group[j0] = 0
+        # upper leg: "leg" group (motor_link_ids)
+        jpos[j0 + 1] = [0.0, sy * coxa, 0.0]
+        jaxis[j0 + 1] = pitch_axis
+        link_mass[j0 + 1] = up_m
+        link_com[j0 + 1] = [up_com[0], up_com[1] * sy, up_com[2]]
+        link_I[j0 + 1] = list(up_I) + [0, 0, 0]
+        link_group[j0 + 1] = 1
+        # lower leg + fixed toe merged for the dynamics: "leg" group (knee + foot link ids)
+        jpos[j0 + 2] = [0.0, 0.0, -femur]
+        jaxis[j0 + 2] = pitch_axis
+        c_l = np.array(lo_com, dtype=np.float64)
+        c_t = np.array([0.0, 0.0, -tibia])
+        mm = lo_m + toe_m
+        c = (lo_m * c_l + toe_m * c_t) / mm
+        link_mass[j0 + 2] = mm
+        link_com[j0 + 2] = c
+        link_I[j0 + 2] = np.array(list(lo_I) + [0, 0, 0]) + _sphere_inertia(toe_m, toe_r)
+        link_Ipa[j0 + 2] = _pa(lo_m, c_l - c) + _pa(toe_m, c_t - c)
+        link_group[j0 + 2] = 1
+        toe_pos[leg] = c_t
+        lower_com[leg] = c_l
+        for k in range(3):
+            jlo[j0 + k], jhi[j0 + k] = limits[k]
+        fall_body.append(1 + j0)
+        fall_pos.append([0.0, 0.0, 0.0])
+        fall_radius.append(hip_r)
+    for leg in range(4):
+        fall_body.append(1 + 3 * leg + 1)
+        fall_pos.append([0.0, 0.0, -femur])
+        fall_radius.append(knee_r)
+    m.update(link_mass=link_mass, link_com=link_com, link_inertia=link_I, link_inertia_pa=link_Ipa,
+             link_group=link_group, joint_pos=jpos, joint_axis=jaxis, joint_lo=jlo, joint_hi=jhi,
+             toe_pos=toe_pos, lower_com=lower_com, num_fall_proxies=len(fall_body),
+             fall_body=np.array(fall_body, dtype=np.int32), fall_pos=np.array(fall_pos),
+             fall_radius=np.array(fall_radius))
+    assert m["num_fall_proxies"] <= _abi.MAX_FALL_PROXIES
+    return m
+
+
+def laikago():
+    """robots/laikago.py constants + authored inertial / collision data."""
+    return _build(
+        "laikago",
+        init_pos=[0, 0, 0.48], init_quat=[0.5, 0.5, 0.5, 0.5],               # laikago.py:48-49
+        init_motor_angles=[0, 0.67, -1.25] * 4,                              # laikago.py:62
+        motor_dir=[-1, 1, 1, 1, 1, 1, -1, 1, 1, 1, 1, 1],                    # laikago.py:50
+        motor_offset=[0.0, -0.6, 0.66] * 4,                                  # laikago.py:52
+        joint_of_motor=list(range(12)),                                      # laikago.py:31-44 = URDF order
+        kp=[220.0] * 12, kd=[0.3, 2.0, 2.0] * 4,                             # laikago.py:65-66
+        base_mass=13.715, base_inertia=[0.073348887, 0.250684593, 0.254469458],
+        hip_xy=[0.21, 0.1157 - 0.032875],                                    # laikago.py:54-59 minus coxa
+        coxa=0.032875, femur=0.25223, tibia=0.251,                           # trans2minicheetah.m:3-5
+        pitch_axis=[0.0, -1.0, 0.0],                                         # FK sign: trans_data.py:55-69
+        hip_m=1.095, hip_com=[0.0, 0.0, 0.0], hip_I=[0.00100, 0.00120, 0.00100],
+        up_m=1.527, up_com=[0.0, 0.0, -0.04], up_I=[0.0078, 0.0081, 0.0012],
+        lo_m=0.241, lo_com=[0.0, 0.0, -0.11], lo_I=[0.0013, 0.0013, 0.00005],
+        toe_m=0.06, toe_r=0.0265,
+        # Unitree Laikago spec in motor convention: hip +-60 deg, thigh -30..225 deg, calf -159..-35 deg
+        limits=[(-1.0471975512, 1.0471975512), (-0.5235987756, 3.9269908170), (-2.7750735107, -0.6108652382)],
+        chassis_half=[0.27, 0.09, 0.055], hip_r=0.045, knee_r=0.035, foot_friction=1.0)
+
+
+def mini_cheetah():
+    """robots/mini_cheetah.py constants + MIT mini-cheetah published inertial figures."""
+    return _build(
+        "mini_cheetah",
+        init_pos=[0, 0, 0.28], init_quat=[0.0, 0.0, 0.0, 1.0],               # mini_cheetah.py:49-50
+        init_motor_angles=[0, -0.78, 1.74] * 4,                              # mini_cheetah.py:63
+        motor_dir=[1] * 12, motor_offset=[0.0] * 12,                         # mini_cheetah.py:51,53
+        # MOTOR_NAMES order fl, hl, fr, hr (mini_cheetah.py:31-44) -> URDF legs fr, fl, hr, hl
+        joint_of_motor=[3, 4, 5, 9, 10, 11, 0, 1, 2, 6, 7, 8],
+        kp=[80.0] * 12, kd=[0.1, 1.0, 1.0] * 4,                              # mini_cheetah.py:66-67
+        base_mass=3.3, base_inertia=[0.011253, 0.036203, 0.042673],
+        hip_xy=[0.19, 0.049], coxa=0.062, femur=0.209, tibia=0.18,           # trans2minicheetah.m:28-30
+        pitch_axis=[0.0, 1.0, 0.0],                                          # trans2minicheetah.m:32 (q_urdf = -kin)
+        hip_m=0.54, hip_com=[0.0, 0.036, 0.0], hip_I=[0.000381, 0.000560, 0.000444],
+        up_m=0.634, up_com=[0.0, 0.016, -0.02], up_I=[0.001983, 0.002103, 0.000408],
+        lo_m=0.064, lo_com=[0.0, 0.0, -0.061], lo_I=[0.000245, 0.000248, 0.000006],
+        toe_m=0.03, toe_r=0.0175,
+        limits=[(-1e9, 1e9)] * 3,                                            # continuous joints
+        chassis_half=[0.19, 0.049, 0.05], hip_r=0.04, knee_r=0.02, foot_friction=1.0)
+
+
+ROBOTS = {"laikago": laikago, "mini_cheetah": mini_cheetah}
+ROBOT_TYPE_ID = {"laikago": 0, "mini_cheetah": 1}
+
+
+def to_struct(model):
+    """dict of arrays -> ctypes OrrModel (float32 table handed to orr_set_model)."""
+    s = _abi.OrrModel()
+    for fname, _ in _abi.OrrModel._fields_:
+        val = model[fname]
+        field = getattr(s, fname)
+        if isinstance(field, C.Array):
+            arr = np.ctypeslib.as_array(field)
+            v = np.asarray(val)
+            if v.shape != arr.shape:  # padded tables (fall proxies)
+                pad = np.zeros(arr.shape, dtype=arr.dtype)
+                pad[tuple(slice(0, n) for n in v.shape)] = v
+                v = pad
+            arr[...] = v.astype(arr.dtype)
+        else:
+            setattr(s, fname, val)
+    return s
