@@ -46,7 +46,7 @@ def _pa(m, d):
 
 
 def _build(name, init_pos, init_quat, init_motor_angles, motor_dir, motor_offset, joint_of_motor, kp, kd,
-           base_mass, base_inertia, hip_xy, coxa, femur, tibia, pitch_axis,
+           base_mass, base_inertia, hip_xy, hip_z, coxa, femur, tibia, pitch_axis,
            hip_m, hip_com, hip_I, up_m, up_com, up_I, lo_m, lo_com, lo_I, toe_m, toe_r,
            limits, chassis_half, hip_r, knee_r, foot_friction):
     m = {
@@ -86,7 +86,7 @@ def _build(name, init_pos, init_quat, init_motor_angles, motor_dir, motor_offset
         sx, sy = LEG_SX[leg], LEG_SY[leg]
         j0 = 3 * leg
         # hip (abduction) link: "base" randomisation group (minitaur.py:828-829 chassis_link_ids)
-        jpos[j0] = [sx * hip_xy[0], sy * hip_xy[1], 0.0]
+        jpos[j0] = [sx * hip_xy[0], sy * hip_xy[1], hip_z]
         jaxis[j0] = [1.0, 0.0, 0.0]
         link_mass[j0] = hip_m
         link_com[j0] = [hip_com[0] * sx, hip_com[1] * sy, hip_com[2]]
@@ -143,8 +143,12 @@ def laikago():
         kp=[220.0] * 12, kd=[0.3, 2.0, 2.0] * 4,                             # laikago.py:65-66
         base_mass=13.715, base_inertia=[0.073348887, 0.250684593, 0.254469458],
         hip_xy=[0.21, 0.1157 - 0.032875],                                    # laikago.py:54-59 minus coxa
+        # hip axis plane below the base COM frame: calibrated on in-tree data -- with it the stance toes of
+        # every Laikago clip touch the ground (min toe-centre height = toe radius) and the default pose
+        # stands at z = 0.478 ~ INIT_POSITION z = 0.48 (laikago.py:48)
+        hip_z=-0.044,
         coxa=0.032875, femur=0.25223, tibia=0.251,                           # trans2minicheetah.m:3-5
-        pitch_axis=[0.0, -1.0, 0.0],                                         # FK sign: trans_data.py:55-69
+        pitch_axis=[0.0, 1.0, 0.0],                                          # FK sign: trans_data.py:55-69
         hip_m=1.095, hip_com=[0.0, 0.0, 0.0], hip_I=[0.00100, 0.00120, 0.00100],
         up_m=1.527, up_com=[0.0, 0.0, -0.04], up_I=[0.0078, 0.0081, 0.0012],
         lo_m=0.241, lo_com=[0.0, 0.0, -0.11], lo_I=[0.0013, 0.0013, 0.00005],
@@ -165,8 +169,8 @@ def mini_cheetah():
         joint_of_motor=[3, 4, 5, 9, 10, 11, 0, 1, 2, 6, 7, 8],
         kp=[80.0] * 12, kd=[0.1, 1.0, 1.0] * 4,                              # mini_cheetah.py:66-67
         base_mass=3.3, base_inertia=[0.011253, 0.036203, 0.042673],
-        hip_xy=[0.19, 0.049], coxa=0.062, femur=0.209, tibia=0.18,           # trans2minicheetah.m:28-30
-        pitch_axis=[0.0, 1.0, 0.0],                                          # trans2minicheetah.m:32 (q_urdf = -kin)
+        hip_xy=[0.19, 0.049], hip_z=0.0, coxa=0.062, femur=0.209, tibia=0.18,           # trans2minicheetah.m:28-30
+        pitch_axis=[0.0, -1.0, 0.0],                                         # trans2minicheetah.m:32 (q_urdf = -kin)
         hip_m=0.54, hip_com=[0.0, 0.036, 0.0], hip_I=[0.000381, 0.000560, 0.000444],
         up_m=0.634, up_com=[0.0, 0.016, -0.02], up_I=[0.001983, 0.002103, 0.000408],
         lo_m=0.064, lo_com=[0.0, 0.0, -0.061], lo_I=[0.000245, 0.000248, 0.000006],
