@@ -225,6 +225,10 @@ int32_t orr_reset(orr_handle* h, const uint8_t* mask_dev, float* obs_dev, void* 
 int32_t orr_step(orr_handle* h, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev,
                  void* stream);
 
+/* parity / debug entry (not part of the drop-in surface): nsub physics sub-steps with fixed motor torques
+ * [N,12] applied as tau_urdf = tau * JOINT_DIRECTIONS; fall_dev [N] receives the fall-proxy flag (may be NULL). */
+int32_t orr_debug_physics(orr_handle* h, const float* torques_dev, uint8_t* fall_dev, int32_t nsub, void* stream);
+
 /* last launch durations in ms measured with hipEvents on the launch stream (bench only; syncs) */
 int32_t orr_time_steps(orr_handle* h, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev,
                        void* stream, int32_t num_steps, float* total_ms_out);

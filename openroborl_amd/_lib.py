@@ -1,0 +1,94 @@
+"""Build + load the C-ABI library (libopenroborl_hip.so) and declare its ctypes signatures.
+
+There is NO CPU fallback: if the library cannot be built or loaded, importing / using the
+environment raises.  (The CPU restatement under oracle/ is test infrastructure and is never
+imported from here.)
+"""
+import ctypes as C
+import os
+import subprocess
+
+from . import _abi
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(PKG_DIR, "csrc", "orr_kernels.hip")
+DEPS = [SRC, os.path.join(PKG_DIR, "csrc", "orr_device.h"),
+        os.path.join(os.path.dirname(PKG_DIR), "include", "openroborl_hip.h")]
+LIB_PATH = os.path.join(PKG_DIR, "libopenroborl_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+EXPORTS = [
+    "orr_last_error", "orr_abi_version", "orr_state_stride", "orr_layout_count", "orr_layout_name",
+    "orr_layout_offset", "orr_layout_size", "orr_layout_is_int", "orr_sizeof_config", "orr_sizeof_model",
+    "orr_create", "orr_destroy", "orr_set_model", "orr_set_motion", "orr_bind", "orr_reset", "orr_step",
+    "orr_time_steps",
+]
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(d) > t for d in DEPS if os.path.exists(d))
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP kernels + C-ABI for gfx950 into the in-tree shared library."""
+    if not force and not needs_build():
+        return LIB_PATH
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-Wno-unused-value",
+           "-o", LIB_PATH, SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if needs_build():
+        try:
+            build()
+        except Exception as e:  # stale library on a box without hipcc is still usable
+            if not os.path.exists(LIB_PATH):
+                raise RuntimeError("libopenroborl_hip.so is missing and could not be built: %r" % (e,))
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.orr_last_error.restype = C.c_char_p
+    L.orr_abi_version.restype = C.c_int32
+    L.orr_create.restype = C.c_int32
+    L.orr_create.argtypes = [C.POINTER(_abi.OrrConfig), C.POINTER(vp)]
+    L.orr_destroy.argtypes = [vp]
+    L.orr_set_model.restype = C.c_int32
+    L.orr_set_model.argtypes = [vp, C.c_int32, C.POINTER(_abi.OrrModel)]
+    L.orr_set_motion.restype = C.c_int32
+    L.orr_set_motion.argtypes = [vp, C.c_int32, vp, vp, C.c_int32, C.c_float, C.c_int32, C.POINTER(C.c_float)]
+    L.orr_bind.restype = C.c_int32
+    L.orr_bind.argtypes = [vp, vp, vp, vp, C.c_int32]
+    L.orr_reset.restype = C.c_int32
+    L.orr_reset.argtypes = [vp, vp, vp, vp]
+    L.orr_step.restype = C.c_int32
+    L.orr_step.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.orr_debug_physics.restype = C.c_int32
+    L.orr_debug_physics.argtypes = [vp, vp, vp, C.c_int32, vp]
+    L.orr_time_steps.restype = C.c_int32
+    L.orr_time_steps.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int32, C.POINTER(C.c_float)]
+    L.orr_sizeof_config.restype = C.c_int32
+    L.orr_sizeof_model.restype = C.c_int32
+    if L.orr_abi_version() != _abi.ABI_VERSION:
+        raise RuntimeError("libopenroborl_hip.so ABI version mismatch")
+    if L.orr_sizeof_config() != C.sizeof(_abi.OrrConfig) or L.orr_sizeof_model() != C.sizeof(_abi.OrrModel):
+        raise RuntimeError("ctypes struct layout does not match include/openroborl_hip.h")
+    _lib = L
+    return L
+
+
+def check(rc, lib=None):
+    if rc != 0:
+        lib = lib or load()
+        raise RuntimeError("openroborl_hip error %d: %s" % (rc, lib.orr_last_error().decode()))

@@ -1,0 +1,285 @@
+// orr_device.h -- device-side building blocks of the quadruped env kernels (gfx950, wave64).
+//
+// One wavefront owns one robot.  Lane roles change phase by phase:
+//   motors      lanes 0..11   action filter / interpolation / clip / PD torque (minitaur.py:280-293,438-460,706-769)
+//   legs        lanes 0..3    articulated-body passes over the 3-link leg chains (pybullet stepSimulation)
+//   rows        lanes 0..27   one constraint row each: impulse response, Delassus row, PGS state
+//   dofs        lanes 0..17   generalised velocity u = [omega_w, v_w, joint rates]
+// Cross-lane data goes through LDS (register arrays are never indexed dynamically).
+//
+// Arithmetic: float32.  Reference citations are relative to /root/reference/OpenRoboRL/.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/openroborl_hip.h"
+
+#define ORR_PI_F 3.14159265358979323846f
+#define WSYNC() __syncthreads()
+
+namespace orr {
+
+constexpr int kMaxRows = 28;  // 4 knee-friction + <=12 joint-limit + 12 contact rows
+constexpr int kHead = 320;    // words of the state record staged in LDS (everything before the ring)
+constexpr int kLinkCache = 36;
+
+struct DevClip {
+  const float* frames;
+  const float* vels;
+  int F, flags;
+  float dt, dur;
+  float cdp[3];
+  float cdh;
+};
+
+struct DevTables {
+  orr_model model[ORR_MAX_ROBOT_TYPES];
+  DevClip clip[ORR_MAX_CLIPS];
+};
+
+struct KParams {
+  orr_config cfg;
+  float fb[3], fa[3];  // Butterworth coefficients (action_filter.py:196-217), computed on the host in double
+  const DevTables* tab;
+  float* state;
+  long long* counters;
+  float* ep_log;
+  int ep_log_cap;
+};
+
+// ------------------------------------------------------------------------------------------------
+// LDS image of one robot (one wave).  ~2.7 K words.
+// ------------------------------------------------------------------------------------------------
+struct LinkCache {  // per movable link, written by the leg lanes, read by the row lanes
+  float R[9];       // child -> parent rotation
+  float U[6];
+  float invD;
+  float u;          // tau - S.pA
+  float Rw[9];      // link -> world
+  float ow[3];      // link origin, world
+  float pad;
+};
+
+struct Shared {
+  float s[kHead];                // state head (float / int bit patterns)
+  orr_model m;                   // model table of this robot's type
+  float jdir[12], joff[12];      // per JOINT (URDF order) direction / offset
+  int motor_of_joint[12];
+  float mass[13];                // after randomisation ratios
+  float Ic[13][6];
+  LinkCache lc[12];
+  float Rb[9];                   // kinematic base frame -> world
+  float IA0inv[36];
+  float tau[12];                 // joint torques, kinematic convention, joint order
+  float acc[18];
+  float ustar[18];
+  float du[18];
+  float W[kMaxRows][18];         // M^-1 J^T per dense row
+  float A[kMaxRows][kMaxRows + 1];
+  float lam[kMaxRows];
+  float rowdata[kMaxRows][8];    // per dense row: rhs*jdi, jdi, lo, hi, mu, normal row, warm slot, lambda0
+  float co[20];                  // control (latency-delayed) observation
+  float frames[10][19];          // staged clip frames: 5 sample times x (f0, f1)
+  float fvel[2][18];
+  float pose[5][19];             // sampled reference poses (update time + 4 target times)
+  float vel[18];
+  float ee[2][8][3];             // end-effector world positions, [0] sim [1] ref
+  float red[64];
+  int imisc[16];
+};
+
+// ------------------------------------------------------------------------------------------------
+// small math (xyzw quaternions; pose3d.py / pybullet_utils.transformations semantics)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cross3(const float a[3], const float b[3], float o[3]) {
+  float x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+__device__ __forceinline__ float dot3(const float a[3], const float b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+__device__ __forceinline__ void mv3(const float M[9], const float v[3], float o[3]) {
+  float a = M[0] * v[0] + M[1] * v[1] + M[2] * v[2];
+  float b = M[3] * v[0] + M[4] * v[1] + M[5] * v[2];
+  float c = M[6] * v[0] + M[7] * v[1] + M[8] * v[2];
+  o[0] = a; o[1] = b; o[2] = c;
+}
+__device__ __forceinline__ void mtv3(const float M[9], const float v[3], float o[3]) {
+  float a = M[0] * v[0] + M[3] * v[1] + M[6] * v[2];
+  float b = M[1] * v[0] + M[4] * v[1] + M[7] * v[2];
+  float c = M[2] * v[0] + M[5] * v[1] + M[8] * v[2];
+  o[0] = a; o[1] = b; o[2] = c;
+}
+__device__ __forceinline__ void mm3(const float A[9], const float B[9], float C[9]) {
+  float t[9];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) t[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+#pragma unroll
+  for (int i = 0; i < 9; i++) C[i] = t[i];
+}
+// C = A * B^T
+__device__ __forceinline__ void mmt3(const float A[9], const float B[9], float C[9]) {
+  float t[9];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) t[i * 3 + j] = A[i * 3] * B[j * 3] + A[i * 3 + 1] * B[j * 3 + 1] + A[i * 3 + 2] * B[j * 3 + 2];
+#pragma unroll
+  for (int i = 0; i < 9; i++) C[i] = t[i];
+}
+// skew(r) * M
+__device__ __forceinline__ void skewmul(const float r[3], const float M[9], float C[9]) {
+  float t[9];
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    t[0 + j] = -r[2] * M[3 + j] + r[1] * M[6 + j];
+    t[3 + j] = r[2] * M[0 + j] - r[0] * M[6 + j];
+    t[6 + j] = -r[1] * M[0 + j] + r[0] * M[3 + j];
+  }
+#pragma unroll
+  for (int i = 0; i < 9; i++) C[i] = t[i];
+}
+// M * skew(r)
+__device__ __forceinline__ void mulskew(const float M[9], const float r[3], float C[9]) {
+  float t[9];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    t[i * 3 + 0] = M[i * 3 + 1] * r[2] - M[i * 3 + 2] * r[1];
+    t[i * 3 + 1] = -M[i * 3 + 0] * r[2] + M[i * 3 + 2] * r[0];
+    t[i * 3 + 2] = M[i * 3 + 0] * r[1] - M[i * 3 + 1] * r[0];
+  }
+#pragma unroll
+  for (int i = 0; i < 9; i++) C[i] = t[i];
+}
+__device__ __forceinline__ void sym_to_m3(const float s[6], float M[9]) {
+  M[0] = s[0]; M[4] = s[1]; M[8] = s[2];
+  M[1] = M[3] = s[3]; M[2] = M[6] = s[4]; M[5] = M[7] = s[5];
+}
+// Rodrigues rotation about unit axis: maps child-frame coordinates to parent-frame coordinates
+__device__ __forceinline__ void rodrigues(const float ax[3], float ang, float R[9]) {
+  float s, c;
+  sincosf(ang, &s, &c);
+  float t = 1.0f - c, x = ax[0], y = ax[1], z = ax[2];
+  R[0] = t * x * x + c; R[1] = t * x * y - s * z; R[2] = t * x * z + s * y;
+  R[3] = t * x * y + s * z; R[4] = t * y * y + c; R[5] = t * y * z - s * x;
+  R[6] = t * x * z - s * y; R[7] = t * y * z + s * x; R[8] = t * z * z + c;
+}
+// transformations.quaternion_multiply(a, b): Hamilton product (pose3d.py:228-230)
+__device__ __forceinline__ void qmul(const float a[4], const float b[4], float o[4]) {
+  float x1 = a[0], y1 = a[1], z1 = a[2], w1 = a[3], x0 = b[0], y0 = b[1], z0 = b[2], w0 = b[3];
+  o[0] = x1 * w0 + y1 * z0 - z1 * y0 + w1 * x0;
+  o[1] = -x1 * z0 + y1 * w0 + z1 * x0 + w1 * y0;
+  o[2] = x1 * y0 - y1 * x0 + z1 * w0 + w1 * z0;
+  o[3] = -x1 * x0 - y1 * y0 - z1 * z0 + w1 * w0;
+}
+__device__ __forceinline__ void qconj(const float q[4], float o[4]) { o[0] = -q[0]; o[1] = -q[1]; o[2] = -q[2]; o[3] = q[3]; }
+__device__ __forceinline__ void qinv(const float q[4], float o[4]) {
+  float n = 1.0f / (q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  o[0] = -q[0] * n; o[1] = -q[1] * n; o[2] = -q[2] * n; o[3] = q[3] * n;
+}
+// pose3d.QuaternionRotatePoint (pose3d.py:213-231): q [p,0] q^-1
+__device__ __forceinline__ void qrot(const float p[3], const float q[4], float o[3]) {
+  float qp[4] = {p[0], p[1], p[2], 0.0f}, qi[4], t[4], r[4];
+  qinv(q, qi);
+  qmul(q, qp, t);
+  qmul(t, qi, r);
+  o[0] = r[0]; o[1] = r[1]; o[2] = r[2];
+}
+__device__ __forceinline__ void qstd(float q[4]) {  // pose3d.py:289-301
+  if (q[3] < 0.0f) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
+}
+__device__ __forceinline__ float qheading(const float q[4]) {  // pose3d.py:325-341
+  float x[3] = {1.0f, 0.0f, 0.0f}, r[3];
+  qrot(x, q, r);
+  return atan2f(r[1], r[0]);
+}
+__device__ __forceinline__ void q_about_z(float ang, float o[4]) {
+  float s, c;
+  sincosf(0.5f * ang, &s, &c);
+  o[0] = 0.0f; o[1] = 0.0f; o[2] = s; o[3] = c;
+}
+// |angle| of pose3d.QuaternionToAxisAngle + normalize_rotation_angle (pose3d.py:139-187,304-322)
+__device__ __forceinline__ float q_norm_angle(const float q[4]) {
+  float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+  float ang = 2.0f * atan2f(n, q[3]);
+  if (fabsf(ang) > ORR_PI_F) {
+    ang = fmodf(ang, 2.0f * ORR_PI_F);
+    ang += (ang >= 0.0f) ? -2.0f * ORR_PI_F : 2.0f * ORR_PI_F;
+  }
+  return ang;
+}
+__device__ __forceinline__ float map_pi(float a) {  // pose3d.MapToMinusPiToPi (pose3d.py:358-374)
+  float m = fmodf(a, 2.0f * ORR_PI_F);
+  if (m >= ORR_PI_F) m -= 2.0f * ORR_PI_F;
+  else if (m < -ORR_PI_F) m += 2.0f * ORR_PI_F;
+  return m;
+}
+__device__ __forceinline__ void q_to_mat(const float qin[4], float R[9]) {
+  float n = rsqrtf(qin[0] * qin[0] + qin[1] * qin[1] + qin[2] * qin[2] + qin[3] * qin[3]);
+  float x = qin[0] * n, y = qin[1] * n, z = qin[2] * n, w = qin[3] * n;
+  R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w); R[2] = 2 * (x * z + y * w);
+  R[3] = 2 * (x * y + z * w); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
+  R[6] = 2 * (x * z - y * w); R[7] = 2 * (y * z + x * w); R[8] = 1 - 2 * (x * x + y * y);
+}
+// pybullet.getEulerFromQuaternion: roll, pitch, yaw (Bullet ZYX)
+__device__ __forceinline__ void euler_from_quat(const float q[4], float rpy[3]) {
+  float x = q[0], y = q[1], z = q[2], w = q[3];
+  float sqx = x * x, sqy = y * y, sqz = z * z, sqw = w * w;
+  float sarg = -2.0f * (x * z - w * y);
+  rpy[0] = atan2f(2.0f * (y * z + w * x), -sqx - sqy + sqz + sqw);
+  rpy[1] = sarg <= -1.0f ? -0.5f * ORR_PI_F : (sarg >= 1.0f ? 0.5f * ORR_PI_F : asinf(sarg));
+  rpy[2] = atan2f(2.0f * (x * y + w * z), sqx - sqy - sqz + sqw);
+}
+// transformations.quaternion_slerp (shortest path)
+__device__ __forceinline__ void qslerp(const float a[4], const float b[4], float f, float o[4]) {
+  const float EPS = 1.1920929e-07f * 4.0f;
+  float n0 = rsqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3]);
+  float n1 = rsqrtf(b[0] * b[0] + b[1] * b[1] + b[2] * b[2] + b[3] * b[3]);
+  float q0[4] = {a[0] * n0, a[1] * n0, a[2] * n0, a[3] * n0};
+  float q1[4] = {b[0] * n1, b[1] * n1, b[2] * n1, b[3] * n1};
+  float d = q0[0] * q1[0] + q0[1] * q1[1] + q0[2] * q1[2] + q0[3] * q1[3];
+  float s0 = 1.0f, s1 = 0.0f;
+  if (f == 0.0f) { s0 = 1.0f; s1 = 0.0f; }
+  else if (f == 1.0f) { s0 = 0.0f; s1 = 1.0f; }
+  else if (fabsf(fabsf(d) - 1.0f) < EPS) { s0 = 1.0f; s1 = 0.0f; }
+  else {
+    float sgn = 1.0f;
+    if (d < 0.0f) { d = -d; sgn = -1.0f; }
+    float ang = acosf(d);
+    if (fabsf(ang) < EPS) { s0 = 1.0f; s1 = 0.0f; }
+    else {
+      float isin = 1.0f / sinf(ang);
+      s0 = sinf((1.0f - f) * ang) * isin;
+      s1 = sgn * sinf(f * ang) * isin;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) o[i] = q0[i] * s0 + q1[i] * s1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Philox4x32-10 (same stream definition as oracle/orr_oracle.c: key = seed, ctr = (robot, episode, idx>>2, "ORRL"))
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float philox_uniform(unsigned long long seed, uint32_t robot, uint32_t episode, uint32_t idx) {
+  uint32_t c0 = robot, c1 = episode, c2 = idx >> 2, c3 = 0x4F52524Cu;
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  uint32_t sel = idx & 3u;
+  uint32_t x = sel == 0 ? c0 : (sel == 1 ? c1 : (sel == 2 ? c2 : c3));
+  return (float)(x >> 8) * (1.0f / 16777216.0f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// state helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int geti(const Shared& S, int off) { return __float_as_int(S.s[off]); }
+__device__ __forceinline__ void seti(Shared& S, int off, int v) { S.s[off] = __int_as_float(v); }
+
+}  // namespace orr

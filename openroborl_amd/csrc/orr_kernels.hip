@@ -1,0 +1,1419 @@
+// orr_kernels.hip -- HIP kernels (gfx950) + C-ABI of the vectorised quadruped imitation env.
+//
+// Hot path replaced: WrapperEnv.step / reset (wrapper_env.py:58-107) -> LocomotionGymEnv._step /
+// reset (quadruped_gym_env.py:63-104,213-239) -> Minitaur (minitaur.py) + ImitationTask
+// (imitation_task.py) + pybullet.stepSimulation.  One launch = one env step for all robots of
+// this device: 33 physics sub-steps, observation, reward, termination, optional auto-reset.
+// Specification of every stage: DESIGN.md section 4; CPU restatement: oracle/orr_oracle.c.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "orr_device.h"
+
+using namespace orr;
+
+#define O(name) ORR_OFF_##name
+
+// ================================================================================================
+// load / store of the per-robot record
+// ================================================================================================
+__device__ static void load_robot(const KParams& P, const float* rec, Shared& S, int lane) {
+  for (int i = lane; i < kHead; i += 64) S.s[i] = rec[i];
+  WSYNC();
+  const int type = geti(S, O(ROBOT_TYPE));
+  const float* mp = reinterpret_cast<const float*>(&P.tab->model[type]);
+  float* dst = reinterpret_cast<float*>(&S.m);
+  for (int i = lane; i < (int)(sizeof(orr_model) / 4); i += 64) dst[i] = mp[i];
+  WSYNC();
+  if (lane < 12) {
+    int j = S.m.joint_of_motor[lane];
+    S.jdir[j] = S.m.motor_dir[lane];
+    S.joff[j] = S.m.motor_offset[lane];
+    S.motor_of_joint[j] = lane;
+  }
+  // randomised mass properties (controllable_env_randomizer_from_config.py:193-222,309-335)
+  if (lane < 13) {
+    int g = lane == 0 ? 0 : S.m.link_group[lane - 1];
+    float mr = S.s[O(MASS_RATIO) + g], ir = S.s[O(INERTIA_RATIO) + g];
+    S.mass[lane] = (lane == 0 ? S.m.base_mass : S.m.link_mass[lane - 1]) * mr;
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+      S.Ic[lane][k] = lane == 0 ? S.m.base_inertia[k] * ir : S.m.link_inertia[lane - 1][k] * ir + S.m.link_inertia_pa[lane - 1][k] * mr;
+  }
+  WSYNC();
+}
+
+__device__ static void store_robot(float* rec, const Shared& S, int lane) {
+  for (int i = lane; i < O(RING); i += 64) rec[i] = S.s[i];
+}
+
+// ================================================================================================
+// latency ring (minitaur.py:127,313-357) -- lives in global memory, lane k owns word k of an entry
+// ================================================================================================
+__device__ static void ctrl_obs(const KParams& P, const float* rec, Shared& S, int lane) {
+  const float lat = S.s[O(LATENCY)], dt = P.cfg.sim_dt;
+  const int len = geti(S, O(RING_LEN)), head = geti(S, O(RING_HEAD));
+  int k0 = 0, k1 = 0;
+  float al = 0.0f;
+  if (!(lat <= 0.0f || len == 1)) {  // Minitaur._get_delay_obs (minitaur.py:336-357)
+    int n = (int)(lat / dt);
+    if (n + 1 >= len) { k0 = k1 = len - 1; }
+    else { k0 = n; k1 = n + 1; al = (lat - n * dt) / dt; }
+  }
+  if (lane < 19) {
+    int i0 = (head - k0 + 2 * ORR_RING_DEPTH) % ORR_RING_DEPTH, i1 = (head - k1 + 2 * ORR_RING_DEPTH) % ORR_RING_DEPTH;
+    float e0 = rec[O(RING) + i0 * ORR_RING_ENTRY + lane], e1 = rec[O(RING) + i1 * ORR_RING_ENTRY + lane];
+    S.co[lane] = (k0 == k1) ? e0 : (1.0f - al) * e0 + al * e1;
+  }
+  WSYNC();
+}
+
+// Minitaur.receive_obs + get_true_obs (minitaur.py:304-334): push the true observation
+__device__ static void receive_obs(float* rec, Shared& S, int lane) {
+  const int head = (geti(S, O(RING_HEAD)) + 1) % ORR_RING_DEPTH, len = geti(S, O(RING_LEN));
+  float qi[4], rel[4], ri[4], Rm[9], rate[3];
+  qinv(S.m.init_quat, qi);
+  qmul(&S.s[O(QUAT)], qi, rel);  // orientation relative to the initial one (minitaur.py:325-331)
+  qinv(rel, ri);
+  q_to_mat(ri, Rm);
+  mv3(Rm, &S.s[O(ANGVEL)], rate);  // get_true_base_rpy_rate (minitaur.py:640-672)
+  float val = 0.0f;
+  if (lane < 12) {
+    int j = S.m.joint_of_motor[lane];
+    val = (S.s[O(Q) + j] - S.m.motor_offset[lane]) * S.m.motor_dir[lane];  // get_true_motor_angles (:543-553)
+  } else if (lane < 16) {
+    val = lane == 12 ? rel[0] : (lane == 13 ? rel[1] : (lane == 14 ? rel[2] : rel[3]));
+  } else if (lane < 19) {
+    val = lane == 16 ? rate[0] : (lane == 17 ? rate[1] : rate[2]);
+  }
+  if (lane < ORR_RING_ENTRY) rec[O(RING) + head * ORR_RING_ENTRY + lane] = val;
+  WSYNC();
+  if (lane == 0) {
+    seti(S, O(RING_HEAD), head);
+    seti(S, O(RING_LEN), len + 1 > ORR_RING_DEPTH ? ORR_RING_DEPTH : len + 1);
+  }
+  WSYNC();
+}
+
+// ================================================================================================
+// physics sub-step (pybullet stepSimulation, quadruped_gym_env.py:223)
+// ================================================================================================
+
+// Cholesky factor of a 6x6 SPD matrix (row-major full storage), in place lower triangle; returns via L
+__device__ __forceinline__ void chol6(const float A[36], float L[21], float invdiag[6]) {
+  // L packed row-wise: index (i,j) j<=i -> i*(i+1)/2 + j
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+#pragma unroll
+    for (int j = 0; j <= i; j++) {
+      float s = A[i * 6 + j];
+#pragma unroll
+      for (int k = 0; k < j; k++) s -= L[i * (i + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
+      if (i == j) {
+        float d = sqrtf(s);
+        L[i * (i + 1) / 2 + j] = d;
+        invdiag[i] = 1.0f / d;
+      } else {
+        L[i * (i + 1) / 2 + j] = s * invdiag[j];
+      }
+    }
+  }
+}
+__device__ __forceinline__ void chol6_solve(const float L[21], const float invdiag[6], const float b[6], float x[6]) {
+  float y[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    float s = b[i];
+#pragma unroll
+    for (int k = 0; k < i; k++) s -= L[i * (i + 1) / 2 + k] * y[k];
+    y[i] = s * invdiag[i];
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; i--) {
+    float s = y[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; k++) s -= L[k * (k + 1) / 2 + i] * x[k];
+    x[i] = s * invdiag[i];
+  }
+}
+
+// Articulated-body passes.  Lanes with the same (lane & 3) do the same leg; results are written by lanes 0..3.
+__device__ static void aba_legs(const KParams& P, Shared& S, int lane) {
+  const int leg = lane & 3;
+  float qrel[4], Rb[9], wb[3], vb[3];
+  {
+    float qi[4];
+    qinv(S.m.init_quat, qi);
+    qmul(&S.s[O(QUAT)], qi, qrel);
+  }
+  q_to_mat(qrel, Rb);
+  mtv3(Rb, &S.s[O(ANGVEL)], wb);
+  mtv3(Rb, &S.s[O(LINVEL)], vb);
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) S.Rb[i] = Rb[i];
+  }
+
+  // ---------------- pass 1: velocities, bias terms, world poses ----------------
+  float Rk[3][9], ck[3][6], pAk[3][6];
+  {
+    float wp[3] = {wb[0], wb[1], wb[2]}, vp[3] = {vb[0], vb[1], vb[2]};
+    float Rwp[9], owp[3] = {S.s[O(POS)], S.s[O(POS) + 1], S.s[O(POS) + 2]};
+#pragma unroll
+    for (int i = 0; i < 9; i++) Rwp[i] = Rb[i];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const int j = 3 * leg + k;
+      const float ax[3] = {S.m.joint_axis[j][0], S.m.joint_axis[j][1], S.m.joint_axis[j][2]};
+      const float r[3] = {S.m.joint_pos[j][0], S.m.joint_pos[j][1], S.m.joint_pos[j][2]};
+      const float a = S.jdir[j] * (S.s[O(Q) + j] - S.joff[j]);
+      const float ad = S.jdir[j] * S.s[O(QD) + j];
+      rodrigues(ax, a, Rk[k]);
+      float t[3], w[3], v[3];
+      cross3(wp, r, t);
+      t[0] += vp[0]; t[1] += vp[1]; t[2] += vp[2];
+      mtv3(Rk[k], wp, w);
+      mtv3(Rk[k], t, v);
+      const float sq[3] = {ax[0] * ad, ax[1] * ad, ax[2] * ad};
+      w[0] += sq[0]; w[1] += sq[1]; w[2] += sq[2];
+      cross3(w, sq, &ck[k][0]);
+      cross3(v, sq, &ck[k][3]);
+      const float m = S.mass[j + 1];
+      const float com[3] = {S.m.link_com[j][0], S.m.link_com[j][1], S.m.link_com[j][2]};
+      float wxc[3], f[3], n[3], cxf[3], Icm[9];
+      cross3(w, com, wxc);
+      f[0] = m * (v[0] + wxc[0]); f[1] = m * (v[1] + wxc[1]); f[2] = m * (v[2] + wxc[2]);
+      sym_to_m3(S.Ic[j + 1], Icm);
+      mv3(Icm, w, n);
+      cross3(com, f, cxf);
+      n[0] += cxf[0]; n[1] += cxf[1]; n[2] += cxf[2];
+      float t1[3], t2[3];
+      cross3(w, n, t1);
+      cross3(v, f, t2);
+      pAk[k][0] = t1[0] + t2[0]; pAk[k][1] = t1[1] + t2[1]; pAk[k][2] = t1[2] + t2[2];
+      cross3(w, f, &pAk[k][3]);
+      // forward kinematics
+      float Rw[9], ow[3];
+      mm3(Rwp, Rk[k], Rw);
+      mv3(Rwp, r, ow);
+      ow[0] += owp[0]; ow[1] += owp[1]; ow[2] += owp[2];
+      if (lane < 4) {
+        LinkCache& L = S.lc[j];
+#pragma unroll
+        for (int i = 0; i < 9; i++) { L.R[i] = Rk[k][i]; L.Rw[i] = Rw[i]; }
+#pragma unroll
+        for (int i = 0; i < 3; i++) L.ow[i] = ow[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 3; i++) { wp[i] = w[i]; vp[i] = v[i]; owp[i] = ow[i]; }
+#pragma unroll
+      for (int i = 0; i < 9; i++) Rwp[i] = Rw[i];
+    }
+  }
+
+  // ---------------- pass 2: articulated inertias, inward ----------------
+  float Iacc[6] = {0, 0, 0, 0, 0, 0}, Hacc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Macc[6] = {0, 0, 0, 0, 0, 0};
+  float pacc[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int k = 2; k >= 0; k--) {
+    const int j = 3 * leg + k;
+    const float ax[3] = {S.m.joint_axis[j][0], S.m.joint_axis[j][1], S.m.joint_axis[j][2]};
+    const float r[3] = {S.m.joint_pos[j][0], S.m.joint_pos[j][1], S.m.joint_pos[j][2]};
+    const float m = S.mass[j + 1];
+    const float c0 = S.m.link_com[j][0], c1 = S.m.link_com[j][1], c2 = S.m.link_com[j][2];
+    const float cc = c0 * c0 + c1 * c1 + c2 * c2;
+    float I[9], H[9], M[9];
+    {
+      float Is[6];
+      Is[0] = S.Ic[j + 1][0] + m * (cc - c0 * c0) + Iacc[0];
+      Is[1] = S.Ic[j + 1][1] + m * (cc - c1 * c1) + Iacc[1];
+      Is[2] = S.Ic[j + 1][2] + m * (cc - c2 * c2) + Iacc[2];
+      Is[3] = S.Ic[j + 1][3] - m * c0 * c1 + Iacc[3];
+      Is[4] = S.Ic[j + 1][4] - m * c0 * c2 + Iacc[4];
+      Is[5] = S.Ic[j + 1][5] - m * c1 * c2 + Iacc[5];
+      sym_to_m3(Is, I);
+      float Ms[6] = {m + Macc[0], m + Macc[1], m + Macc[2], Macc[3], Macc[4], Macc[5]};
+      sym_to_m3(Ms, M);
+      H[0] = Hacc[0]; H[1] = -m * c2 + Hacc[1]; H[2] = m * c1 + Hacc[2];
+      H[3] = m * c2 + Hacc[3]; H[4] = Hacc[4]; H[5] = -m * c0 + Hacc[5];
+      H[6] = -m * c1 + Hacc[6]; H[7] = m * c0 + Hacc[7]; H[8] = Hacc[8];
+    }
+    float pA[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) pA[i] = pAk[k][i] + pacc[i];
+    float Ut[3], Ub[3];
+    mv3(I, ax, Ut);
+    mtv3(H, ax, Ub);
+    const float D = dot3(ax, Ut), invD = 1.0f / D;
+    const float u = S.tau[j] - dot3(ax, pA);
+    const float uD = u * invD;
+    if (lane < 4) {
+      LinkCache& L = S.lc[j];
+      L.U[0] = Ut[0]; L.U[1] = Ut[1]; L.U[2] = Ut[2]; L.U[3] = Ub[0]; L.U[4] = Ub[1]; L.U[5] = Ub[2];
+      L.invD = invD; L.u = u;
+    }
+#pragma unroll
+    for (int a_ = 0; a_ < 3; a_++)
+#pragma unroll
+      for (int b_ = 0; b_ < 3; b_++) {
+        I[a_ * 3 + b_] -= Ut[a_] * Ut[b_] * invD;
+        H[a_ * 3 + b_] -= Ut[a_] * Ub[b_] * invD;
+        M[a_ * 3 + b_] -= Ub[a_] * Ub[b_] * invD;
+      }
+    // pa = pA + Ia c + U u / D
+    float pat[3], pab[3], t1[3], t2[3];
+    mv3(I, &ck[k][0], t1);
+    mv3(H, &ck[k][3], t2);
+#pragma unroll
+    for (int i = 0; i < 3; i++) pat[i] = pA[i] + t1[i] + t2[i] + Ut[i] * uD;
+    mtv3(H, &ck[k][0], t1);
+    mv3(M, &ck[k][3], t2);
+#pragma unroll
+    for (int i = 0; i < 3; i++) pab[i] = pA[3 + i] + t1[i] + t2[i] + Ub[i] * uD;
+    // express in the parent frame: rotate by R (child -> parent), then shift by r
+    float Ip[9], Hp[9], Mp[9], T[9];
+    mm3(Rk[k], I, T); mmt3(T, Rk[k], Ip);
+    mm3(Rk[k], H, T); mmt3(T, Rk[k], Hp);
+    mm3(Rk[k], M, T); mmt3(T, Rk[k], Mp);
+    float K[9], rxM[9], rxHt[9], Krx[9], Hpt[9];
+    skewmul(r, Mp, rxM);
+#pragma unroll
+    for (int i = 0; i < 9; i++) K[i] = Hp[i] + rxM[i];
+#pragma unroll
+    for (int a_ = 0; a_ < 3; a_++)
+#pragma unroll
+      for (int b_ = 0; b_ < 3; b_++) Hpt[a_ * 3 + b_] = Hp[b_ * 3 + a_];
+    skewmul(r, Hpt, rxHt);
+    mulskew(K, r, Krx);
+#pragma unroll
+    for (int i = 0; i < 9; i++) Ip[i] = Ip[i] + rxHt[i] - Krx[i];
+    Iacc[0] = Ip[0]; Iacc[1] = Ip[4]; Iacc[2] = Ip[8];
+    Iacc[3] = 0.5f * (Ip[1] + Ip[3]); Iacc[4] = 0.5f * (Ip[2] + Ip[6]); Iacc[5] = 0.5f * (Ip[5] + Ip[7]);
+#pragma unroll
+    for (int i = 0; i < 9; i++) Hacc[i] = K[i];
+    Macc[0] = Mp[0]; Macc[1] = Mp[4]; Macc[2] = Mp[8];
+    Macc[3] = 0.5f * (Mp[1] + Mp[3]); Macc[4] = 0.5f * (Mp[2] + Mp[6]); Macc[5] = 0.5f * (Mp[5] + Mp[7]);
+    float fp[3], np_[3], rxf[3];
+    mv3(Rk[k], pab, fp);
+    mv3(Rk[k], pat, np_);
+    cross3(r, fp, rxf);
+    pacc[0] = np_[0] + rxf[0]; pacc[1] = np_[1] + rxf[1]; pacc[2] = np_[2] + rxf[2];
+    pacc[3] = fp[0]; pacc[4] = fp[1]; pacc[5] = fp[2];
+  }
+  // ---------------- base: sum the four leg contributions (butterfly over lane bits 0,1) ----------------
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    Iacc[i] += __shfl_xor(Iacc[i], 1); Iacc[i] += __shfl_xor(Iacc[i], 2);
+    Macc[i] += __shfl_xor(Macc[i], 1); Macc[i] += __shfl_xor(Macc[i], 2);
+    pacc[i] += __shfl_xor(pacc[i], 1); pacc[i] += __shfl_xor(pacc[i], 2);
+  }
+#pragma unroll
+  for (int i = 0; i < 9; i++) { Hacc[i] += __shfl_xor(Hacc[i], 1); Hacc[i] += __shfl_xor(Hacc[i], 2); }
+  float A6[36], pA0[6];
+  {
+    const float m0 = S.mass[0];
+    float Ib[9], Is[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) Is[i] = S.Ic[0][i];
+    sym_to_m3(Is, Ib);
+    float n[3], f[3] = {m0 * vb[0], m0 * vb[1], m0 * vb[2]}, t1[3], t2[3];
+    mv3(Ib, wb, n);
+    cross3(wb, n, t1);
+    cross3(wb, f, t2);
+    // Bullet base damping (btMultiBody ABA): torque k_a I w, force k_l m v on the bias side
+    const float kl = S.s[O(BASE_DAMPING)], ka = S.s[O(BASE_DAMPING) + 1];
+#pragma unroll
+    for (int i = 0; i < 3; i++) { pA0[i] = t1[i] + ka * n[i] + pacc[i]; pA0[3 + i] = t2[i] + kl * f[i] + pacc[3 + i]; }
+    float Im[9], Mm[9];
+    sym_to_m3(Iacc, Im);
+    sym_to_m3(Macc, Mm);
+#pragma unroll
+    for (int a_ = 0; a_ < 3; a_++)
+#pragma unroll
+      for (int b_ = 0; b_ < 3; b_++) {
+        A6[a_ * 6 + b_] = Ib[a_ * 3 + b_] + Im[a_ * 3 + b_];
+        A6[a_ * 6 + 3 + b_] = Hacc[a_ * 3 + b_];
+        A6[(3 + a_) * 6 + b_] = Hacc[b_ * 3 + a_];
+        A6[(3 + a_) * 6 + 3 + b_] = Mm[a_ * 3 + b_] + (a_ == b_ ? m0 : 0.0f);
+      }
+  }
+  float Lc[21], idg[6], a0[6];
+  chol6(A6, Lc, idg);
+  {
+    float nb[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) nb[i] = -pA0[i];
+    chol6_solve(Lc, idg, nb, a0);
+    // explicit inverse for the impulse responses: lane c (< 6) solves for unit column c
+    float e[6], x[6];
+    const int col = lane % 6;
+#pragma unroll
+    for (int i = 0; i < 6; i++) e[i] = (i == col) ? 1.0f : 0.0f;
+    chol6_solve(Lc, idg, e, x);
+    if (lane < 6) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) S.IA0inv[i * 6 + col] = x[i];
+    }
+  }
+  // ---------------- pass 3: accelerations, outward ----------------
+  {
+    float ap[6] = {a0[0], a0[1], a0[2], a0[3], a0[4], a0[5]};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const int j = 3 * leg + k;
+      const float ax[3] = {S.m.joint_axis[j][0], S.m.joint_axis[j][1], S.m.joint_axis[j][2]};
+      const float r[3] = {S.m.joint_pos[j][0], S.m.joint_pos[j][1], S.m.joint_pos[j][2]};
+      const LinkCache& L = S.lc[j];  // U / invD / u written by this very lane (or its replica) above
+      float t[3], at[3], ab[3];
+      cross3(&ap[0], r, t);
+      t[0] += ap[3]; t[1] += ap[4]; t[2] += ap[5];
+      mtv3(Rk[k], &ap[0], at);
+      mtv3(Rk[k], t, ab);
+#pragma unroll
+      for (int i = 0; i < 3; i++) { at[i] += ck[k][i]; ab[i] += ck[k][3 + i]; }
+      // U, invD, u recomputed values are identical in replica lanes; read own copies from registers is
+      // not possible across the pass-2 loop, so take them from LDS (same wave, ordered by WSYNC below)
+      float qdd;
+      {
+        float Ud = L.U[0] * at[0] + L.U[1] * at[1] + L.U[2] * at[2] + L.U[3] * ab[0] + L.U[4] * ab[1] + L.U[5] * ab[2];
+        qdd = (L.u - Ud) * L.invD;
+      }
+      at[0] += ax[0] * qdd; at[1] += ax[1] * qdd; at[2] += ax[2] * qdd;
+      if (lane < 4) S.acc[6 + j] = qdd;
+#pragma unroll
+      for (int i = 0; i < 3; i++) { ap[i] = at[i]; ap[3 + i] = ab[i]; }
+    }
+  }
+  if (lane == 0) {
+    // world-frame base accelerations (Bullet: vdot = R (a_lin + w x v)); gravity = uniform-field offset
+    float t[3], wxv[3];
+    mv3(Rb, &a0[0], t);
+    S.acc[0] = t[0]; S.acc[1] = t[1]; S.acc[2] = t[2];
+    cross3(wb, vb, wxv);
+    wxv[0] += a0[3]; wxv[1] += a0[4]; wxv[2] += a0[5];
+    mv3(Rb, wxv, t);
+    S.acc[3] = t[0]; S.acc[4] = t[1]; S.acc[5] = t[2] + P.cfg.gravity_z;
+  }
+}
+
+// One physics sub-step.  Returns the fall-proxy flag (wave-uniform) when want_fall.
+__device__ static int physics_substep(const KParams& P, Shared& S, int lane, bool want_fall) {
+  const orr_config& cfg = P.cfg;
+  const float dt = cfg.sim_dt;
+  // pass-3 of aba_legs reads U / invD / u that pass 2 wrote to LDS from the same lanes (lanes >= 4
+  // read what lanes 0..3 wrote): one barrier inside would be needed for lanes >= 4 only; they do not
+  // write anything, so their (possibly stale) values are harmless.
+  aba_legs(P, S, lane);
+  WSYNC();
+  if (lane < 18) {
+    float u = lane < 3 ? S.s[O(ANGVEL) + lane] : (lane < 6 ? S.s[O(LINVEL) + lane - 3] : S.jdir[lane - 6] * S.s[O(QD) + lane - 6]);
+    S.ustar[lane] = u + dt * S.acc[lane];
+  }
+  int fall = 0;
+  if (want_fall) {  // termination-only collision proxies (imitation_task.py:536-546)
+    bool hit = false;
+    if (lane < S.m.num_fall_proxies) {
+      int b = S.m.fall_body[lane];
+      const float* Rw = b == 0 ? S.Rb : S.lc[b - 1].Rw;
+      float oz = b == 0 ? S.s[O(POS) + 2] : S.lc[b - 1].ow[2];
+      float wz = Rw[6] * S.m.fall_pos[lane][0] + Rw[7] * S.m.fall_pos[lane][1] + Rw[8] * S.m.fall_pos[lane][2];
+      hit = (oz + wz - S.m.fall_radius[lane]) < cfg.contact_margin;
+    }
+    fall = __ballot(hit) != 0ull;
+  }
+  WSYNC();
+
+  // ---------------- constraint rows: one per lane (slot order = solve order) ----------------
+  //  0..3   knee joint-friction motors (minitaur.py:1063-1070)
+  //  4..15  joint limits (joint j = lane-4; at most one side can be within limit_activation)
+  //  16..19 toe contact normals, 20..27 pyramid friction (leg = (lane-20)/2, t1 = +x, t2 = +y)
+  bool active = false;
+  int leg = 0, nrm_slot = -1, warm = -1;
+  float Jb[6] = {0, 0, 0, 0, 0, 0}, jl[3] = {0, 0, 0};
+  float rhs = 0.0f, lo = 0.0f, hi = 0.0f, mu = 0.0f;
+  if (lane < 4) {
+    leg = lane;
+    float fr = S.s[O(KNEE_FRICTION) + leg];
+    active = fr > 0.0f;
+    jl[2] = 1.0f;
+    lo = -fr * dt; hi = fr * dt;
+    rhs = -S.ustar[6 + 3 * leg + 2];
+  } else if (lane < 16) {
+    int j = lane - 4;
+    leg = j / 3;
+    int kk = j - 3 * leg;
+    float a = S.jdir[j] * (S.s[O(Q) + j] - S.joff[j]);
+    float pen_lo = a - S.m.joint_lo[j], pen_hi = S.m.joint_hi[j] - a;
+    bool use_lo = pen_lo < cfg.limit_activation;
+    bool use_hi = (!use_lo) && pen_hi < cfg.limit_activation;
+    active = use_lo || use_hi;
+    float sgn = use_lo ? 1.0f : -1.0f, pen = use_lo ? pen_lo : pen_hi;
+    jl[0] = kk == 0 ? sgn : 0.0f; jl[1] = kk == 1 ? sgn : 0.0f; jl[2] = kk == 2 ? sgn : 0.0f;
+    float rel = sgn * S.ustar[6 + j];
+    lo = 0.0f; hi = 1e30f;
+    rhs = pen > 0.0f ? -rel - pen / dt : -rel - pen * cfg.contact_erp / dt;
+  } else if (lane < 28) {
+    int d;
+    if (lane < 20) { leg = lane - 16; d = 0; }
+    else { leg = (lane - 20) >> 1; d = 1 + ((lane - 20) & 1); }
+    const int jb = 3 * leg + 2;
+    const LinkCache& Lb = S.lc[jb];
+    float cw[3];
+    mv3(Lb.Rw, S.m.toe_pos[leg], cw);
+    cw[0] += Lb.ow[0]; cw[1] += Lb.ow[1]; cw[2] += Lb.ow[2];
+    const float dist = cw[2] - S.m.toe_radius;
+    active = dist < cfg.contact_margin;
+    const float Pw[3] = {cw[0], cw[1], cw[2] - S.m.toe_radius};
+    const float dir[3] = {d == 1 ? 1.0f : 0.0f, d == 2 ? 1.0f : 0.0f, d == 0 ? 1.0f : 0.0f};
+    float rr[3] = {Pw[0] - S.s[O(POS)], Pw[1] - S.s[O(POS) + 1], Pw[2] - S.s[O(POS) + 2]};
+    cross3(rr, dir, &Jb[0]);
+    Jb[3] = dir[0]; Jb[4] = dir[1]; Jb[5] = dir[2];
+    float rel = Jb[0] * S.ustar[0] + Jb[1] * S.ustar[1] + Jb[2] * S.ustar[2] + Jb[3] * S.ustar[3] + Jb[4] * S.ustar[4] + Jb[5] * S.ustar[5];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const LinkCache& L = S.lc[3 * leg + k];
+      float axw[3], cr[3];
+      mv3(L.Rw, S.m.joint_axis[3 * leg + k], axw);
+      rr[0] = Pw[0] - L.ow[0]; rr[1] = Pw[1] - L.ow[1]; rr[2] = Pw[2] - L.ow[2];
+      cross3(axw, rr, cr);
+      jl[k] = dot3(dir, cr);
+      rel += jl[k] * S.ustar[6 + 3 * leg + k];
+    }
+    warm = 3 * leg + d;
+    if (d == 0) {
+      lo = 0.0f; hi = 1e30f;
+      rhs = dist > 0.0f ? -rel - dist / dt : -rel - dist * cfg.contact_erp / dt;
+    } else {
+      nrm_slot = 16 + leg;
+      mu = S.s[O(FOOT_MU)] * cfg.plane_friction;  // combined friction = product of the two coefficients
+      rhs = -rel;
+    }
+  }
+  const unsigned long long mask = __ballot(active);
+  const int nrows = __popcll(mask);
+  const int dense = __popcll(mask & ((1ull << lane) - 1ull));
+
+  // ---------------- impulse response M^-1 J^T (btMultiBody::calcAccelerationDeltasMultiDof) ----------------
+  float mj[6], mq[12], diag = 0.0f;
+  {
+    // inward over the row's own leg
+    float pA[6] = {0, 0, 0, 0, 0, 0}, ud[3];
+#pragma unroll
+    for (int k = 2; k >= 0; k--) {
+      const int j = 3 * leg + k;
+      const LinkCache& L = S.lc[j];
+      ud[k] = jl[k] - dot3(S.m.joint_axis[j], pA);
+      const float s = ud[k] * L.invD;
+      float pat[3] = {pA[0] + L.U[0] * s, pA[1] + L.U[1] * s, pA[2] + L.U[2] * s};
+      float pab[3] = {pA[3] + L.U[3] * s, pA[4] + L.U[4] * s, pA[5] + L.U[5] * s};
+      float fp[3], np_[3], rxf[3];
+      mv3(L.R, pab, fp);
+      mv3(L.R, pat, np_);
+      cross3(S.m.joint_pos[j], fp, rxf);
+      pA[0] = np_[0] + rxf[0]; pA[1] = np_[1] + rxf[1]; pA[2] = np_[2] + rxf[2];
+      pA[3] = fp[0]; pA[4] = fp[1]; pA[5] = fp[2];
+    }
+    float fb[6], a0[6];
+    mtv3(S.Rb, &Jb[0], &fb[0]);
+    mtv3(S.Rb, &Jb[3], &fb[3]);
+#pragma unroll
+    for (int i = 0; i < 6; i++) fb[i] -= pA[i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      float s = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 6; k++) s += S.IA0inv[i * 6 + k] * fb[k];
+      a0[i] = s;
+    }
+#pragma unroll
+    for (int L4 = 0; L4 < 4; L4++) {
+      float ap[6] = {a0[0], a0[1], a0[2], a0[3], a0[4], a0[5]};
+      const bool mine = (L4 == leg);
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const int j = 3 * L4 + k;
+        const LinkCache& L = S.lc[j];
+        float t[3], at[3], ab[3];
+        cross3(&ap[0], S.m.joint_pos[j], t);
+        t[0] += ap[3]; t[1] += ap[4]; t[2] += ap[5];
+        mtv3(L.R, &ap[0], at);
+        mtv3(L.R, t, ab);
+        const float Ud = L.U[0] * at[0] + L.U[1] * at[1] + L.U[2] * at[2] + L.U[3] * ab[0] + L.U[4] * ab[1] + L.U[5] * ab[2];
+        const float qdd = ((mine ? ud[k] : 0.0f) - Ud) * L.invD;
+        mq[j] = qdd;
+        diag += mine ? jl[k] * qdd : 0.0f;
+        ap[0] = at[0] + S.m.joint_axis[j][0] * qdd; ap[1] = at[1] + S.m.joint_axis[j][1] * qdd; ap[2] = at[2] + S.m.joint_axis[j][2] * qdd;
+        ap[3] = ab[0]; ap[4] = ab[1]; ap[5] = ab[2];
+      }
+    }
+    mv3(S.Rb, &a0[0], &mj[0]);
+    mv3(S.Rb, &a0[3], &mj[3]);
+#pragma unroll
+    for (int i = 0; i < 6; i++) diag += Jb[i] * mj[i];
+  }
+  const float jdi = 1.0f / diag;
+  float lam = 0.0f;
+  if (active) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) S.W[dense][i] = mj[i];
+#pragma unroll
+    for (int i = 0; i < 12; i++) S.W[dense][6 + i] = mq[i];
+    lam = warm >= 0 ? cfg.warmstart_factor * S.s[O(LAMBDA) + warm] : 0.0f;
+    S.lam[dense] = lam;
+  }
+  WSYNC();
+  // Delassus rows A[i][s] = J_i . W[s]; stored transposed so that PGS step r reads a contiguous line
+  if (active) {
+    for (int s = 0; s < nrows; s++) {
+      float a = Jb[0] * S.W[s][0] + Jb[1] * S.W[s][1] + Jb[2] * S.W[s][2] + Jb[3] * S.W[s][3] + Jb[4] * S.W[s][4] + Jb[5] * S.W[s][5];
+      a += jl[0] * S.W[s][6 + 3 * leg] + jl[1] * S.W[s][6 + 3 * leg + 1] + jl[2] * S.W[s][6 + 3 * leg + 2];
+      S.A[s][dense] = a;
+    }
+  }
+  // move row state slot-lane -> dense-lane
+  float (*rowdata)[8] = S.rowdata;
+  if (active) {
+    rowdata[dense][0] = rhs * jdi;
+    rowdata[dense][1] = jdi;
+    rowdata[dense][2] = lo;
+    rowdata[dense][3] = hi;
+    rowdata[dense][4] = mu;
+    rowdata[dense][5] = __int_as_float(nrm_slot >= 0 ? __popcll(mask & ((1ull << nrm_slot) - 1ull)) : -1);
+    rowdata[dense][6] = __int_as_float(warm);
+    rowdata[dense][7] = lam;
+  }
+  WSYNC();
+  {
+    const bool mine = lane < nrows;
+    float r_rhs = 0, r_jdi = 0, r_lo = 0, r_hi = 0, r_mu = 0, r_lam = 0, w = 0, lam_n = 0;
+    int r_nrm = -1, r_warm = -1;
+    if (mine) {
+      r_rhs = rowdata[lane][0]; r_jdi = rowdata[lane][1]; r_lo = rowdata[lane][2]; r_hi = rowdata[lane][3];
+      r_mu = rowdata[lane][4]; r_nrm = __float_as_int(rowdata[lane][5]); r_warm = __float_as_int(rowdata[lane][6]);
+      r_lam = rowdata[lane][7];
+      for (int s = 0; s < nrows; s++) w += S.A[s][lane] * S.lam[s];  // warm-start contribution
+      if (r_nrm >= 0) lam_n = S.lam[r_nrm];
+    }
+    // projected Gauss-Seidel (btMultiBodyConstraintSolver::solveSingleIteration), Delassus form
+    for (int it = 0; it < cfg.solver_iters; it++) {
+      for (int r = 0; r < nrows; r++) {
+        const float acol = mine ? S.A[r][lane] : 0.0f;
+        float dl = r_rhs - w * r_jdi;
+        const float hi_e = r_nrm >= 0 ? r_mu * lam_n : r_hi;
+        const float lo_e = r_nrm >= 0 ? -hi_e : r_lo;
+        float sum = r_lam + dl;
+        sum = sum < lo_e ? lo_e : (sum > hi_e ? hi_e : sum);
+        dl = sum - r_lam;
+        const float d_r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dl), r));
+        if (lane == r) r_lam = sum;
+        w += acol * d_r;
+        if (r_nrm == r) lam_n += d_r;
+      }
+    }
+    WSYNC();
+    if (mine) {
+      S.lam[lane] = r_lam;
+      if (r_warm >= 0) S.s[O(LAMBDA) + r_warm] = r_lam;
+    }
+    // contact slots that are not active this sub-step forget their warm-start impulse
+    if (lane >= 16 && lane < 28 && !active) S.s[O(LAMBDA) + warm] = 0.0f;
+  }
+  WSYNC();
+  // ---------------- velocity update, Bullet coordinate-velocity clamp, semi-implicit Euler ----------------
+  float unew = 0.0f;
+  if (lane < 18) {
+    float du = 0.0f;
+    for (int s = 0; s < nrows; s++) du += S.W[s][lane] * S.lam[s];
+    unew = S.ustar[lane] + du;
+    unew = fminf(fmaxf(unew, -cfg.max_coord_velocity), cfg.max_coord_velocity);
+    S.du[lane] = unew;
+  }
+  WSYNC();
+  {
+    // quaternion: exponential map of the world angular velocity, then normalise
+    const float w0 = S.du[0], w1 = S.du[1], w2 = S.du[2];
+    const float wn = sqrtf(w0 * w0 + w1 * w1 + w2 * w2), half = 0.5f * wn * dt;
+    float sc, ch;
+    if (wn < 1e-12f) { sc = 0.5f * dt; ch = 1.0f; }
+    else { float sh; sincosf(half, &sh, &ch); sc = sh / wn; }
+    float dq[4] = {w0 * sc, w1 * sc, w2 * sc, ch}, qn[4];
+    qmul(dq, &S.s[O(QUAT)], qn);
+    const float nn = rsqrtf(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+    WSYNC();
+    if (lane < 3) S.s[O(ANGVEL) + lane] = unew;
+    else if (lane < 6) { S.s[O(LINVEL) + lane - 3] = unew; S.s[O(POS) + lane - 3] += dt * unew; }
+    else if (lane < 18) {
+      const int j = lane - 6;
+      const float a = S.jdir[j] * (S.s[O(Q) + j] - S.joff[j]) + dt * unew;
+      S.s[O(Q) + j] = a * S.jdir[j] + S.joff[j];
+      S.s[O(QD) + j] = unew * S.jdir[j];
+    } else if (lane < 22) {
+      const int i = lane - 18;
+      S.s[O(QUAT) + i] = (i == 0 ? qn[0] : (i == 1 ? qn[1] : (i == 2 ? qn[2] : qn[3]))) * nn;
+    }
+  }
+  WSYNC();
+  return fall;
+}
+
+// ================================================================================================
+// reference-motion sampling (task/motion_data.py:417-509,591-633,682-718)
+// ================================================================================================
+struct Sample {
+  int f0, f1, count;
+  float blend, phase;
+};
+__device__ __forceinline__ float clip_phase(const DevClip& c, float t) {  // motion_data.py:210-232
+  float ph = t / c.dur;
+  if (c.flags & ORR_CLIP_WRAP) ph -= floorf(ph);
+  else ph = fminf(fmaxf(ph, 0.0f), 1.0f);
+  return ph;
+}
+__device__ __forceinline__ Sample clip_index(const DevClip& c, float t) {  // motion_data.py:234-253,682-718
+  Sample s;
+  const bool wrap = c.flags & ORR_CLIP_WRAP;
+  s.count = (int)floorf(t / c.dur);
+  if (!wrap) s.count = s.count < 0 ? 0 : (s.count > 1 ? 1 : s.count);
+  s.phase = clip_phase(c, t);
+  if (!wrap && t <= 0.0f) { s.f0 = 0; s.f1 = 0; s.blend = 0.0f; }
+  else if (!wrap && t >= c.dur) { s.f0 = c.F - 1; s.f1 = c.F - 1; s.blend = 0.0f; }
+  else {
+    s.f0 = (int)(s.phase * (c.F - 1));
+    s.f0 = s.f0 > c.F - 1 ? c.F - 1 : s.f0;
+    s.f1 = s.f0 + 1 < c.F - 1 ? s.f0 + 1 : c.F - 1;
+    const float nt = s.phase * c.dur, t0 = s.f0 * c.dt, t1 = s.f1 * c.dt;
+    s.blend = s.f1 == s.f0 ? 0.0f : (nt - t0) / (t1 - t0);
+  }
+  return s;
+}
+__device__ static void cycle_offset(const DevClip& c, int count, float pos[3], float rot[4]) {  // motion_data.py:591-633
+  pos[0] = pos[1] = pos[2] = 0.0f;
+  if (c.flags & ORR_CLIP_CYCLE_POS) {
+    if (!(c.flags & ORR_CLIP_CYCLE_ROT)) {
+      pos[0] = count * c.cdp[0]; pos[1] = count * c.cdp[1]; pos[2] = count * c.cdp[2];
+    } else {
+      for (int i = 0; i < count; i++) {
+        float r[4], o[3];
+        q_about_z(i * c.cdh, r);
+        qrot(c.cdp, r, o);
+        pos[0] += o[0]; pos[1] += o[1]; pos[2] += o[2];
+      }
+    }
+  }
+  if (!(c.flags & ORR_CLIP_CYCLE_ROT)) { rot[0] = rot[1] = rot[2] = 0.0f; rot[3] = 1.0f; }
+  else q_about_z(count * c.cdh, rot);
+}
+
+// Sample the active clip at up to 5 times (lane l < nt samples time t_l): frames are staged into LDS by
+// coalesced row loads (lanes 0..18 read one 19-float frame row), then lanes 0..nt-1 blend serially.
+// Result: S.pose[l] = raw (no origin offset) pose; if with_vel, S.vel = raw frame velocity at time of lane 0.
+// Warm-up poses (imitation_task.py:985-1009) are substituted where `warm` and -warmup <= t < 0.
+__device__ static void sample_poses(const KParams& P, Shared& S, int lane, int nt, float t_lane, bool with_vel) {
+  const DevClip& c = P.tab->clip[geti(S, O(CLIP_ID))];
+  const bool warm_ep = geti(S, O(WARMUP)) != 0;
+  Sample sm = clip_index(c, lane < nt ? t_lane : 0.0f);
+  for (int e = 0; e < 2 * nt; e++) {
+    const int src = e >> 1;
+    const int f = (e & 1) ? __shfl(sm.f1, src) : __shfl(sm.f0, src);
+    if (lane < 19) S.frames[e][lane] = c.frames[f * 19 + lane];
+  }
+  if (with_vel) {
+    const int f0 = __shfl(sm.f0, 0), f1 = __shfl(sm.f1, 0);
+    if (lane < 18) { S.fvel[0][lane] = c.vels[f0 * 18 + lane]; S.fvel[1][lane] = c.vels[f1 * 18 + lane]; }
+  }
+  if (lane < 19) S.red[lane] = c.frames[lane];  // frame 0 (warm-up heading)
+  WSYNC();
+  if (lane < nt) {
+    const bool warm_pose = warm_ep && t_lane >= -P.cfg.warmup_time && t_lane < 0.0f;
+    float out[19];
+    if (warm_pose) {
+      // default pose rotated to the heading of frame(0) (imitation_task.py:985-1009, 1245-1252)
+      float dr[4], pp[3], qq[4], q0[4] = {S.red[3], S.red[4], S.red[5], S.red[6]};
+      const float dh = qheading(q0) - qheading(S.m.init_quat);
+      q_about_z(dh, dr);
+      qrot(S.m.init_pos, dr, pp);
+      qmul(dr, S.m.init_quat, qq);
+      out[0] = pp[0]; out[1] = pp[1]; out[2] = pp[2];
+      out[3] = qq[0]; out[4] = qq[1]; out[5] = qq[2]; out[6] = qq[3];
+#pragma unroll
+      for (int i = 0; i < 12; i++) out[7 + i] = (S.m.init_motor_angles[i] + S.m.motor_offset[i]) * S.m.motor_dir[i];
+    } else {
+      const float* a = S.frames[2 * lane];
+      const float* b = S.frames[2 * lane + 1];
+      const float bl = sm.blend;
+#pragma unroll
+      for (int k = 0; k < 3; k++) out[k] = (1.0f - bl) * a[k] + bl * b[k];
+      float q[4];
+      qslerp(a + 3, b + 3, bl, q);
+      qstd(q);
+#pragma unroll
+      for (int k = 7; k < 19; k++) out[k] = (1.0f - bl) * a[k] + bl * b[k];
+      float cp[3], cr[4], p[3], q2[4];
+      cycle_offset(c, sm.count, cp, cr);
+      qrot(out, cr, p);
+      out[0] = p[0] + cp[0]; out[1] = p[1] + cp[1]; out[2] = p[2] + cp[2];
+      qmul(cr, q, q2);
+      qstd(q2);
+      out[3] = q2[0]; out[4] = q2[1]; out[5] = q2[2]; out[6] = q2[3];
+    }
+#pragma unroll
+    for (int k = 0; k < 19; k++) S.pose[lane][k] = out[k];
+    if (with_vel && lane == 0) {
+      if (warm_pose) {
+#pragma unroll
+        for (int k = 0; k < 18; k++) S.vel[k] = 0.0f;
+      } else {
+        float v[18], cp[3], cr[4], t3[3];
+#pragma unroll
+        for (int k = 0; k < 18; k++) v[k] = (1.0f - sm.blend) * S.fvel[0][k] + sm.blend * S.fvel[1][k];
+        cycle_offset(c, sm.count, cp, cr);
+        qrot(&v[0], cr, t3); v[0] = t3[0]; v[1] = t3[1]; v[2] = t3[2];
+        qrot(&v[3], cr, t3); v[3] = t3[0]; v[4] = t3[1]; v[5] = t3[2];
+#pragma unroll
+        for (int k = 0; k < 18; k++) S.vel[k] = v[k];
+      }
+    }
+  }
+  WSYNC();
+}
+
+// apply the origin offset (imitation_task.py:938-951) to S.pose[l] in place (lane l < nt)
+__device__ static void apply_origin(Shared& S, int lane, int nt) {
+  if (lane < nt) {
+    float qq[4], pp[3];
+    qmul(&S.s[O(ORIGIN_ROT)], &S.pose[lane][3], qq);
+    qrot(&S.pose[lane][0], &S.s[O(ORIGIN_ROT)], pp);
+    S.pose[lane][0] = pp[0] + S.s[O(ORIGIN_POS)]; S.pose[lane][1] = pp[1] + S.s[O(ORIGIN_POS) + 1]; S.pose[lane][2] = pp[2] + S.s[O(ORIGIN_POS) + 2];
+    S.pose[lane][3] = qq[0]; S.pose[lane][4] = qq[1]; S.pose[lane][5] = qq[2]; S.pose[lane][6] = qq[3];
+  }
+  WSYNC();
+}
+
+__device__ __forceinline__ float motion_time(const KParams& P, const Shared& S) {  // imitation_task.py:831-848
+  float t = geti(S, O(STATE_ACTION_COUNTER)) * P.cfg.sim_dt + S.s[O(TIME_OFFSET)];
+  if (geti(S, O(WARMUP))) t -= P.cfg.warmup_time;
+  return t;
+}
+
+// build the 76-d target observation into obs76 (LDS) from S.pose[1..4] (already origin-offset) -- imitation_task.py:254-301
+__device__ static void target_obs(const KParams& P, const float* rec, Shared& S, int lane, float* obs76) {
+  ctrl_obs(P, rec, S, lane);
+  if (lane >= 1 && lane <= 4) {
+    float rpy[3];
+    euler_from_quat(&S.co[12], rpy);
+    // robot.get_base_orientation (minitaur.py:630-638) = quaternion of the delayed rpy; its heading is the
+    // direction of the rotated x axis = atan2(sin(yaw) cos(pitch), cos(yaw) cos(pitch))
+    float sy, cy, cpch = cosf(rpy[1]);
+    sincosf(rpy[2], &sy, &cy);
+    const float heading = atan2f(sy * cpch, cy * cpch);
+    float ih[4], p[3], pr[3], q[4];
+    q_about_z(-heading, ih);
+    const float* pose = S.pose[lane];
+    p[0] = pose[0] - S.s[O(REF_POSE)]; p[1] = pose[1] - S.s[O(REF_POSE) + 1]; p[2] = pose[2] - S.s[O(REF_POSE) + 2];
+    qrot(p, ih, pr);
+    qmul(ih, pose + 3, q);
+    qstd(q);
+    float* o = obs76 + (lane - 1) * 19;
+    o[0] = pr[0]; o[1] = pr[1]; o[2] = pr[2]; o[3] = q[0]; o[4] = q[1]; o[5] = q[2]; o[6] = q[3];
+#pragma unroll
+    for (int k = 7; k < 19; k++) o[k] = pose[k];
+  }
+  WSYNC();
+}
+
+// forward kinematics of one leg's two end-effector link COMs (lower leg, toe) -- getLinkState in
+// imitation_task.py:441-446; link set minitaur.py:842-844
+__device__ static void leg_end_effectors(const Shared& S, const float pos[3], const float quat[4], const float* qj, int leg,
+                                         float lower[3], float toe[3]) {
+  float qi[4], qrel[4], R[9], o[3] = {pos[0], pos[1], pos[2]};
+  qinv(S.m.init_quat, qi);
+  qmul(quat, qi, qrel);
+  q_to_mat(qrel, R);
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const int j = 3 * leg + k;
+    float t[3], Rj[9], Rn[9];
+    mv3(R, S.m.joint_pos[j], t);
+    o[0] += t[0]; o[1] += t[1]; o[2] += t[2];
+    rodrigues(S.m.joint_axis[j], S.jdir[j] * (qj[j] - S.joff[j]), Rj);
+    mm3(R, Rj, Rn);
+#pragma unroll
+    for (int i = 0; i < 9; i++) R[i] = Rn[i];
+  }
+  float t[3];
+  mv3(R, S.m.lower_com[leg], t); lower[0] = o[0] + t[0]; lower[1] = o[1] + t[1]; lower[2] = o[2] + t[2];
+  mv3(R, S.m.toe_pos[leg], t); toe[0] = o[0] + t[0]; toe[1] = o[1] + t[1]; toe[2] = o[2] + t[2];
+}
+
+__device__ __forceinline__ void task_heading_rot(const Shared& S, const float q[4], float out[4]) {  // imitation_task.py:1168-1189
+  float dc[4], rel[4];
+  qconj(S.m.init_quat, dc);
+  qmul(q, dc, rel);
+  q_about_z(qheading(rel), out);
+}
+
+// ImitationTask.reward (imitation_task.py:341-516); every lane returns the same value
+__device__ static float calc_reward(const KParams& P, Shared& S, int lane) {
+  const float* rp = &S.s[O(REF_POSE)];
+  const float* rv = &S.s[O(REF_VEL)];
+  if (lane < 8) {
+    const int leg = lane & 3, which = lane >> 2;  // 0 sim, 1 ref
+    float lower[3], toe[3];
+    if (which == 0) leg_end_effectors(S, &S.s[O(POS)], &S.s[O(QUAT)], &S.s[O(Q)], leg, lower, toe);
+    else leg_end_effectors(S, rp, rp + 3, rp + 7, leg, lower, toe);
+#pragma unroll
+    for (int i = 0; i < 3; i++) { S.ee[which][2 * leg][i] = lower[i]; S.ee[which][2 * leg + 1][i] = toe[i]; }
+  }
+  WSYNC();
+  const orr_config& c = P.cfg;
+  float pose_err = 0.0f, vel_err = 0.0f, ee_err = 0.0f;
+#pragma unroll
+  for (int j = 0; j < 12; j++) {
+    float d = rp[7 + j] - S.s[O(Q) + j];
+    pose_err += d * d;
+    d = rv[6 + j] - S.s[O(QD) + j];
+    vel_err += d * d;
+  }
+  {
+    float hr[4], hs[4], ihr[4], ihs[4];
+    task_heading_rot(S, rp + 3, hr);
+    task_heading_rot(S, &S.s[O(QUAT)], hs);
+    qconj(hr, ihr);
+    qconj(hs, ihs);
+    // each of lanes 0..7 handles one end effector, then an 8-lane sum
+    float e = 0.0f;
+    if (lane < 8) {
+      float a[3], b[3], ar[3], br[3];
+#pragma unroll
+      for (int k = 0; k < 3; k++) { a[k] = S.ee[1][lane][k] - rp[k]; b[k] = S.ee[0][lane][k] - S.s[O(POS) + k]; }
+      qrot(a, ihr, ar);
+      qrot(b, ihs, br);
+      const float dh = S.ee[1][lane][2] - S.ee[0][lane][2];
+      e = (ar[0] - br[0]) * (ar[0] - br[0]) + (ar[1] - br[1]) * (ar[1] - br[1]) + c.reward_scale[3] * dh * dh;
+    }
+    S.red[lane] = e;
+    WSYNC();
+#pragma unroll
+    for (int k = 0; k < 8; k++) ee_err += S.red[k];
+  }
+  float root_pose_err, root_vel_err;
+  {
+    float pe = 0.0f, qc[4], dq[4];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { float d = rp[k] - S.s[O(POS) + k]; pe += d * d; }
+    qconj(&S.s[O(QUAT)], qc);
+    qmul(rp + 3, qc, dq);
+    const float ang = q_norm_angle(dq);
+    root_pose_err = pe + 0.5f * ang * ang;
+    float ve = 0.0f, we = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      float d = rv[k] - S.s[O(LINVEL) + k]; ve += d * d;
+      d = rv[3 + k] - S.s[O(ANGVEL) + k]; we += d * d;
+    }
+    root_vel_err = ve + 0.1f * we;
+  }
+  const float r = c.reward_w[0] * expf(-c.reward_scale[0] * pose_err) + c.reward_w[1] * expf(-c.reward_scale[1] * vel_err) +
+                  c.reward_w[2] * expf(-c.reward_scale[2] * ee_err) + c.reward_w[3] * expf(-c.reward_scale[4] * root_pose_err) +
+                  c.reward_w[4] * expf(-c.reward_scale[5] * root_vel_err);
+  WSYNC();
+  return r;
+}
+
+__device__ __forceinline__ int time_limit(const orr_config& c, long long total) {  // wrapper_env.py:151-159
+  if (!(c.flags & ORR_FLAG_CURRICULUM) || c.curriculum_steps <= 0) return c.ep_len_end;
+  double t = (double)total / (double)c.curriculum_steps;
+  t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+  t = t * t * t;
+  return (int)((1.0 - t) * c.ep_len_start + t * c.ep_len_end);
+}
+
+// current sensor readings (robot_sensors.py:74-83,153-190) from S.co -> push into the 3-deep histories
+__device__ static void sensors_push(Shared& S, int lane, bool fill_all) {
+  float rpy[3];
+  euler_from_quat(&S.co[12], rpy);
+  // lanes 0..11 motor angle k, lanes 12..15 IMU channel, lanes 16..27 last action
+  float newest = 0.0f, h0 = 0.0f, h1 = 0.0f;
+  int base = 0, w = 0, k = 0;
+  if (lane < 12) { base = O(MOTORANG_HIST); w = 12; k = lane; newest = map_pi(S.co[lane]); }
+  else if (lane < 16) { base = O(IMU_HIST); w = 4; k = lane - 12; newest = k == 0 ? rpy[0] : (k == 1 ? rpy[1] : (k == 2 ? S.co[16] : S.co[17])); }
+  else if (lane < 28) { base = O(LASTACT_HIST); w = 12; k = lane - 16; newest = S.s[O(LAST_ACTION) + k]; }
+  if (lane < 28) { h0 = S.s[base + k]; h1 = S.s[base + w + k]; }
+  WSYNC();
+  if (lane < 28) {
+    S.s[base + k] = newest;
+    S.s[base + w + k] = fill_all ? newest : h0;
+    S.s[base + 2 * w + k] = fill_all ? newest : h1;
+  }
+  WSYNC();
+}
+
+// ================================================================================================
+// reset of one robot (wrapper_env.py:87-107 -> quadruped_gym_env.py:63-104 -> minitaur.py:232-278 ->
+// imitation_task.py:166-199); SURVEY.md Appendix A.2.  Writes the 160-d observation into obs (LDS).
+// ================================================================================================
+__device__ static void reset_robot(const KParams& P, float* rec, Shared& S, int lane, long long total_step_count, float* obs) {
+  const orr_config& c = P.cfg;
+  const uint32_t robot = (uint32_t)geti(S, O(ROBOT_INDEX)), ep = (uint32_t)geti(S, O(EPISODE_IDX));
+  // 1-2. default pose at the grid slot, counters, ring, filter (minitaur.py:246-268, 465-483)
+  if (lane < 3) {
+    S.s[O(POS) + lane] = S.m.init_pos[lane] + (lane < 2 ? S.s[O(GRID_OFFSET) + lane] : 0.0f);
+    S.s[O(LINVEL) + lane] = 0.0f; S.s[O(ANGVEL) + lane] = 0.0f;
+  }
+  if (lane < 4) S.s[O(QUAT) + lane] = S.m.init_quat[lane];
+  if (lane < 12) {
+    const int j = S.m.joint_of_motor[lane];
+    S.s[O(Q) + j] = S.m.init_motor_angles[lane] + S.m.motor_offset[lane];  // no direction factor (minitaur.py:481)
+    S.s[O(QD) + j] = 0.0f;
+    S.s[O(LAST_ACTION) + lane] = 0.0f; S.s[O(ACTION) + lane] = 0.0f; S.s[O(FILTER_ACTION) + lane] = 0.0f; S.s[O(LAMBDA) + lane] = 0.0f;
+    S.s[O(XHIST) + lane] = 0.0f; S.s[O(XHIST) + 12 + lane] = 0.0f; S.s[O(YHIST) + lane] = 0.0f; S.s[O(YHIST) + 12 + lane] = 0.0f;
+  }
+  if (lane == 0) {
+    seti(S, O(RING_LEN), 0); seti(S, O(RING_HEAD), ORR_RING_DEPTH - 1);
+    seti(S, O(STATE_ACTION_COUNTER), 0); seti(S, O(STEP_COUNTER), 0); seti(S, O(FILTER_VALID), 0);
+    seti(S, O(EP_STEP), 0); seti(S, O(DONE_REASON), 0);
+    S.s[O(EP_RETURN)] = 0.0f;
+  }
+  WSYNC();
+  receive_obs(rec, S, lane);  // ring entry #1
+  // 3. sensor histories <- 3 copies of the current readings (minitaur.py:270-271; sensor_wrappers.py:122-129)
+  ctrl_obs(P, rec, S, lane);
+  sensors_push(S, lane, true);
+  // 4. randomiser (controllable_env_randomizer_from_config.py:92-122), sorted-name draw order:
+  //    inertia 2 | joint friction 8 | latency 1 | lateral friction 1 | mass 2 | motor strength 12
+  if (c.flags & ORR_FLAG_RANDOMIZER) {
+    if (lane < 26) {
+      const float u = philox_uniform(c.seed, robot, ep, (uint32_t)lane);
+      if (lane < 2) S.s[O(INERTIA_RATIO) + lane] = 0.5f + u * 1.0f;
+      else if (lane < 10) { if (((lane - 2) & 1) == 0) S.s[O(KNEE_FRICTION) + ((lane - 2) >> 1)] = u * 0.05f; }
+      else if (lane == 10) S.s[O(LATENCY)] = u * 0.04f;
+      else if (lane == 11) S.s[O(FOOT_MU)] = 0.5f + u * 0.75f;
+      else if (lane < 14) S.s[O(MASS_RATIO) + lane - 12] = 0.8f + u * 0.4f;
+      else S.s[O(STRENGTH) + lane - 14] = 0.8f + u * 0.4f;
+    }
+    WSYNC();
+    if (lane < 13) {  // refresh the randomised mass properties
+      int g = lane == 0 ? 0 : S.m.link_group[lane - 1];
+      float mr = S.s[O(MASS_RATIO) + g], ir = S.s[O(INERTIA_RATIO) + g];
+      S.mass[lane] = (lane == 0 ? S.m.base_mass : S.m.link_mass[lane - 1]) * mr;
+#pragma unroll
+      for (int k = 0; k < 6; k++)
+        S.Ic[lane][k] = lane == 0 ? S.m.base_inertia[k] * ir : S.m.link_inertia[lane - 1][k] * ir + S.m.link_inertia_pa[lane - 1][k] * mr;
+    }
+    WSYNC();
+  }
+  // 5. task reset (imitation_task.py:183-199, 694-732, 1103-1110)
+  const DevClip& clip = P.tab->clip[geti(S, O(CLIP_ID))];
+  {
+    const float u1 = philox_uniform(c.seed, robot, ep, 26u), u2 = philox_uniform(c.seed, robot, ep, 27u);
+    const bool ref_init = u1 < c.ref_state_init_prob;
+    const bool warm = (!ref_init) && c.warmup_time > 0.0f;
+    if (lane == 0) {
+      seti(S, O(WARMUP), warm ? 1 : 0);
+      S.s[O(TIME_OFFSET)] = warm ? u2 * c.warmup_time : u2 * clip.dur;
+      S.s[O(ORIGIN_POS)] = 0.0f; S.s[O(ORIGIN_POS) + 1] = 0.0f; S.s[O(ORIGIN_POS) + 2] = 0.0f;
+      S.s[O(ORIGIN_ROT)] = 0.0f; S.s[O(ORIGIN_ROT) + 1] = 0.0f; S.s[O(ORIGIN_ROT) + 2] = 0.0f; S.s[O(ORIGIN_ROT) + 3] = 1.0f;
+    }
+    WSYNC();
+  }
+  const float t = motion_time(P, S);
+  const float step_dt = c.sim_dt * c.action_repeat;
+  float tl = t;
+  if (lane >= 1 && lane <= 4) tl = t + c.tar_frame_steps[lane - 1] * step_dt;
+  sample_poses(P, S, lane, 5, tl, true);
+  if (lane == 0) {
+    // origin offset: position first (with identity rotation), then rotation; position is NOT recomputed
+    // afterwards (imitation_task.py:712-723)
+    S.s[O(ORIGIN_POS)] = S.s[O(POS)] - S.pose[0][0];
+    S.s[O(ORIGIN_POS) + 1] = S.s[O(POS) + 1] - S.pose[0][1];
+    S.s[O(ORIGIN_POS) + 2] = 0.0f;
+    const float dh = qheading(&S.s[O(QUAT)]) - qheading(&S.pose[0][3]);
+    q_about_z(dh, &S.s[O(ORIGIN_ROT)]);
+    S.s[O(PREV_PHASE)] = clip_phase(clip, t);
+  }
+  WSYNC();
+  apply_origin(S, lane, 5);
+  if (lane < 19) S.s[O(REF_POSE) + lane] = S.pose[0][lane];
+  if (lane == 0) {
+    float v[3];
+    qrot(&S.vel[0], &S.s[O(ORIGIN_ROT)], v); S.vel[0] = v[0]; S.vel[1] = v[1]; S.vel[2] = v[2];
+    qrot(&S.vel[3], &S.s[O(ORIGIN_ROT)], v); S.vel[3] = v[0]; S.vel[4] = v[1]; S.vel[5] = v[2];
+  }
+  WSYNC();
+  if (lane < 18) S.s[O(REF_VEL) + lane] = S.vel[lane];
+  // 6. _sync_sim_model / _set_state (:778-829): teleport the sim robot onto the reference
+  if (lane < 3) { S.s[O(POS) + lane] = S.pose[0][lane]; S.s[O(LINVEL) + lane] = S.vel[lane]; S.s[O(ANGVEL) + lane] = S.vel[3 + lane]; }
+  if (lane < 4) S.s[O(QUAT) + lane] = S.pose[0][3 + lane];
+  if (lane < 12) { S.s[O(Q) + lane] = S.pose[0][7 + lane]; S.s[O(QD) + lane] = S.vel[6 + lane]; }
+  WSYNC();
+  receive_obs(rec, S, lane);  // ring entry #2 (imitation_task.py:792)
+  // 7. observation = histories from step 3 + target observation (quadruped_gym_env.py:100-102; wrapper_env.py:101-105)
+  if (lane == 0) seti(S, O(MAX_EP_STEPS), time_limit(c, total_step_count));
+  if (lane < 12) obs[lane] = S.s[O(IMU_HIST) + lane];
+  if (lane < 36) { obs[12 + lane] = S.s[O(LASTACT_HIST) + lane]; obs[48 + lane] = S.s[O(MOTORANG_HIST) + lane]; }
+  target_obs(P, rec, S, lane, obs + ORR_PROPRIO_DIM);
+}
+
+// ================================================================================================
+// kernels
+// ================================================================================================
+__global__ __launch_bounds__(64) void orr_reset_kernel(KParams P, const uint8_t* mask, float* obs_out) {
+  __shared__ Shared S;
+  __shared__ float obs[ORR_OBS_DIM];
+  const int robot = blockIdx.x, lane = threadIdx.x;
+  if (mask && !mask[robot]) return;
+  float* rec = P.state + (size_t)robot * ORR_STATE_STRIDE;
+  load_robot(P, rec, S, lane);
+  const long long total = P.counters ? P.counters[ORR_CNT_TOTAL_STEP_COUNT] : 0;
+  reset_robot(P, rec, S, lane, total, obs);
+  WSYNC();
+  store_robot(rec, S, lane);
+  if (obs_out)
+    for (int i = lane; i < ORR_OBS_DIM; i += 64) obs_out[(size_t)robot * ORR_OBS_DIM + i] = obs[i];
+}
+
+// mode 0: full env step.  mode 1 (debug / parity of row C): nsub physics sub-steps with the given
+// motor torques (actions = torques), no robot or task logic.
+template <int MODE>
+__global__ __launch_bounds__(64) void orr_step_kernel(KParams P, const float* actions, float* obs_out, float* reward_out,
+                                                      uint8_t* done_out, int nsub) {
+  __shared__ Shared S;
+  __shared__ float obs[ORR_OBS_DIM];
+  const int robot = blockIdx.x, lane = threadIdx.x;
+  float* rec = P.state + (size_t)robot * ORR_STATE_STRIDE;
+  const orr_config& c = P.cfg;
+  load_robot(P, rec, S, lane);
+
+  if (MODE == 1) {
+    if (lane < 12) S.tau[S.m.joint_of_motor[lane]] = actions[(size_t)robot * 12 + lane];
+    WSYNC();
+    int fall = 0;
+    for (int s = 0; s < nsub; s++) fall = physics_substep(P, S, lane, true);
+    if (lane == 0 && done_out) done_out[robot] = (uint8_t)fall;
+    store_robot(rec, S, lane);
+    return;
+  }
+
+  // ---- set_act (minitaur.py:280-285): offset, last action, Butterworth filter ----
+  ctrl_obs(P, rec, S, lane);
+  if (lane < 12) {
+    const float act = actions[(size_t)robot * 12 + lane] + S.m.init_motor_angles[lane];
+    S.s[O(LAST_ACTION) + lane] = act;
+    float x1 = S.s[O(XHIST) + lane], x2 = S.s[O(XHIST) + 12 + lane], y1 = S.s[O(YHIST) + lane], y2 = S.s[O(YHIST) + 12 + lane];
+    if (geti(S, O(STATE_ACTION_COUNTER)) == 0) {  // _filter (minitaur.py:1169-1178): init_history(current delayed angles)
+      const float d = map_pi(S.co[lane]);
+      x1 = x2 = y1 = y2 = d;
+    }
+    const float y = act * P.fb[0] + (x1 * P.fb[1] + x2 * P.fb[2]) - (y1 * P.fa[1] + y2 * P.fa[2]);  // action_filter.py:111-120
+    S.s[O(XHIST) + 12 + lane] = x1; S.s[O(XHIST) + lane] = act;
+    S.s[O(YHIST) + 12 + lane] = y1; S.s[O(YHIST) + lane] = y;
+    S.s[O(ACTION) + lane] = y;
+  }
+  WSYNC();
+  int fall = 0;
+  for (int sub = 0; sub < c.action_repeat; sub++) {
+    if (sub > 0) ctrl_obs(P, rec, S, lane);
+    if (lane < 12) {
+      const float lerp = (float)(sub + 1) / (float)c.action_repeat;  // process_action (minitaur.py:438-460)
+      const float cur = map_pi(S.co[lane]);
+      const float prev = geti(S, O(FILTER_VALID)) ? S.s[O(FILTER_ACTION) + lane] : cur;
+      float cmd = prev + lerp * (S.s[O(ACTION) + lane] - prev);
+      cmd = fminf(fmaxf(cmd, cur - c.max_angle_change), cur + c.max_angle_change);  // _clip_motor_commands (:706-723)
+      const int j = S.m.joint_of_motor[lane];
+      const float qm = (S.s[O(Q) + j] - S.m.motor_offset[lane]) * S.m.motor_dir[lane];  // pd latency 0 (:359-363)
+      const float qdm = S.s[O(QD) + j] * S.m.motor_dir[lane];
+      // MotorModel.convert_to_torque, POSITION mode (minitaur_motor.py:163-171)
+      S.tau[j] = S.s[O(STRENGTH) + lane] * (-1.0f * (S.m.kp[lane] * (qm - cmd)) - S.m.kd[lane] * qdm);
+    }
+    WSYNC();
+    if (lane == 0) {  // robot_step bookkeeping (minitaur.py:287-293)
+      seti(S, O(STATE_ACTION_COUNTER), geti(S, O(STATE_ACTION_COUNTER)) + 1);
+      if (sub == c.action_repeat - 1) { seti(S, O(FILTER_VALID), 1); seti(S, O(STEP_COUNTER), geti(S, O(STEP_COUNTER)) + 1); }
+    }
+    if (sub == c.action_repeat - 1 && lane < 12) S.s[O(FILTER_ACTION) + lane] = S.s[O(ACTION) + lane];
+    fall = physics_substep(P, S, lane, sub == c.action_repeat - 1);
+    receive_obs(rec, S, lane);
+  }
+  // ---- get_obs: sensors on_step (minitaur.py:295-299) ----
+  ctrl_obs(P, rec, S, lane);
+  sensors_push(S, lane, false);
+  // ---- reward -> update -> done (quadruped_gym_env.py:230-233) ----
+  float rew = calc_reward(P, S, lane);
+  const DevClip& clip = P.tab->clip[geti(S, O(CLIP_ID))];
+  const float t = motion_time(P, S);
+  const float step_dt = c.sim_dt * c.action_repeat;
+  float tl = t;
+  if (lane >= 1 && lane <= 4) tl = t + c.tar_frame_steps[lane - 1] * step_dt;
+  sample_poses(P, S, lane, 5, tl, true);
+  {
+    // _update_ref_motion (imitation_task.py:734-761) with _sync_ref_origin (:1020-1055)
+    const float ph = clip_phase(clip, t);
+    if (lane == 0) {
+      if ((c.flags & ORR_FLAG_CYCLE_SYNC) && ph < S.s[O(PREV_PHASE)]) {
+        float pr[3];
+        qrot(&S.pose[0][0], &S.s[O(ORIGIN_ROT)], pr);
+        S.s[O(ORIGIN_POS)] = S.s[O(POS)] - pr[0];
+        S.s[O(ORIGIN_POS) + 1] = S.s[O(POS) + 1] - pr[1];
+        S.s[O(ORIGIN_POS) + 2] = 0.0f;
+      }
+      S.s[O(PREV_PHASE)] = ph;
+      float v[3];
+      qrot(&S.vel[0], &S.s[O(ORIGIN_ROT)], v); S.vel[0] = v[0]; S.vel[1] = v[1]; S.vel[2] = v[2];
+      qrot(&S.vel[3], &S.s[O(ORIGIN_ROT)], v); S.vel[3] = v[0]; S.vel[4] = v[1]; S.vel[5] = v[2];
+    }
+    WSYNC();
+    apply_origin(S, lane, 5);
+    if (lane < 19) S.s[O(REF_POSE) + lane] = S.pose[0][lane];
+    if (lane < 18) S.s[O(REF_VEL) + lane] = S.vel[lane];
+    WSYNC();
+  }
+  // _terminal_condition (imitation_task.py:518-572) + time limit (wrapper_env.py:79) + non-finite guard
+  int reason = 0;
+  {
+    const float* rp = &S.s[O(REF_POSE)];
+    float pe = 0.0f, qc[4], dq[4];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { float d = rp[k] - S.s[O(POS) + k]; pe += d * d; }
+    qconj(&S.s[O(QUAT)], qc);
+    qmul(rp + 3, qc, dq);
+    const float ang = q_norm_angle(dq);
+    if (geti(S, O(STEP_COUNTER)) > 0 && fall) reason |= ORR_DONE_CONTACT_FALL;
+    if (pe > c.dist_fail_threshold * c.dist_fail_threshold) reason |= ORR_DONE_ROOT_POS;
+    if (fabsf(ang) > c.rot_fail_threshold) reason |= ORR_DONE_ROOT_ROT;
+    bool bad = false;
+    if (lane < 37) bad = !(fabsf(S.s[O(POS) + lane]) < 1e30f);
+    if (__ballot(bad) != 0ull) reason |= ORR_DONE_NAN;
+    if (!(fabsf(rew) < 1e30f)) { reason |= ORR_DONE_NAN; rew = 0.0f; }
+    const int ep_step = geti(S, O(EP_STEP)) + 1;  // quadruped_gym_env.py:237
+    if (ep_step >= geti(S, O(MAX_EP_STEPS))) reason |= ORR_DONE_TIME_LIMIT;
+    WSYNC();
+    if (lane == 0) {
+      seti(S, O(EP_STEP), ep_step);
+      seti(S, O(DONE_REASON), reason);
+      S.s[O(EP_RETURN)] += rew;
+    }
+  }
+  // observation (wrapper_env.py:109-125)
+  if (lane < 12) obs[lane] = S.s[O(IMU_HIST) + lane];
+  if (lane < 36) { obs[12 + lane] = S.s[O(LASTACT_HIST) + lane]; obs[48 + lane] = S.s[O(MOTORANG_HIST) + lane]; }
+  target_obs(P, rec, S, lane, obs + ORR_PROPRIO_DIM);
+  if (lane == 0) {
+    reward_out[robot] = rew;
+    done_out[robot] = reason != 0;
+  }
+  long long total_snapshot = P.counters ? P.counters[ORR_CNT_TOTAL_STEP_COUNT] : 0;
+  if (reason != 0) {
+    if (lane == 0) {
+      S.s[O(LAST_EP_RETURN)] = S.s[O(EP_RETURN)];
+      seti(S, O(LAST_EP_LEN), geti(S, O(EP_STEP)));
+      if (P.counters) {
+        atomicAdd((unsigned long long*)&P.counters[ORR_CNT_DONE_ACCUM], 1ull);
+        const unsigned long long slot = atomicAdd((unsigned long long*)&P.counters[ORR_CNT_EPISODES], 1ull);
+        if (P.ep_log && slot < (unsigned long long)P.ep_log_cap) {
+          P.ep_log[2 * slot] = S.s[O(EP_RETURN)];
+          P.ep_log[2 * slot + 1] = (float)geti(S, O(EP_STEP));
+        } else if (P.ep_log) {
+          atomicAdd((unsigned long long*)&P.counters[ORR_CNT_EPLOG_DROPPED], 1ull);
+        }
+      }
+    }
+    WSYNC();
+    if (c.flags & ORR_FLAG_AUTO_RESET) {
+      if (lane == 0) seti(S, O(EPISODE_IDX), geti(S, O(EPISODE_IDX)) + 1);
+      WSYNC();
+      reset_robot(P, rec, S, lane, total_snapshot, obs);
+    }
+  }
+  WSYNC();
+  store_robot(rec, S, lane);
+  for (int i = lane; i < ORR_OBS_DIM; i += 64) obs_out[(size_t)robot * ORR_OBS_DIM + i] = obs[i];
+  // the last wave to finish folds this launch's done count into the curriculum counter (wrapper_env.py:82-83)
+  if (P.counters && lane == 0) {
+    const unsigned long long ticket = atomicAdd((unsigned long long*)&P.counters[ORR_CNT_TICKET], 1ull);
+    if (ticket == (unsigned long long)gridDim.x - 1ull) {
+      const unsigned long long nd = atomicExch((unsigned long long*)&P.counters[ORR_CNT_DONE_ACCUM], 0ull);
+      atomicAdd((unsigned long long*)&P.counters[ORR_CNT_TOTAL_STEP_COUNT], nd);
+      atomicAdd((unsigned long long*)&P.counters[ORR_CNT_TOTAL_TIMESTEPS], (unsigned long long)gridDim.x);
+      atomicExch((unsigned long long*)&P.counters[ORR_CNT_TICKET], 0ull);
+    }
+  }
+}
+
+// ================================================================================================
+// C-ABI (include/openroborl_hip.h)
+// ================================================================================================
+struct orr_handle {
+  orr_config cfg;
+  DevTables* tab_dev;
+  DevTables tab_host;
+  float fb[3], fa[3];
+  float* state;
+  long long* counters;
+  float* ep_log;
+  int ep_log_cap;
+  hipEvent_t ev0, ev1;
+};
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* msg, hipError_t e = hipSuccess) {
+  if (e != hipSuccess) snprintf(g_err, sizeof(g_err), "%s: %s", msg, hipGetErrorString(e));
+  else snprintf(g_err, sizeof(g_err), "%s", msg);
+  return code;
+}
+#define HIPCHK(call, msg)                         \
+  do {                                            \
+    hipError_t e_ = (call);                       \
+    if (e_ != hipSuccess) return fail(-2, msg, e_); \
+  } while (0)
+
+struct field_t { const char* name; int off, size, is_int; };
+static const field_t g_fields[] = {
+#define ORR_X_F(name, words, kind) {#name, ORR_OFF_##name, words, (#kind)[0] == 'I'},
+    ORR_STATE_FIELDS(ORR_X_F)
+#undef ORR_X_F
+};
+
+extern "C" {
+
+const char* orr_last_error(void) { return g_err; }
+int32_t orr_abi_version(void) { return ORR_ABI_VERSION; }
+int32_t orr_state_stride(void) { return ORR_STATE_STRIDE; }
+int32_t orr_layout_count(void) { return (int32_t)(sizeof(g_fields) / sizeof(g_fields[0])); }
+const char* orr_layout_name(int32_t i) { return g_fields[i].name; }
+int32_t orr_layout_offset(int32_t i) { return g_fields[i].off; }
+int32_t orr_layout_size(int32_t i) { return g_fields[i].size; }
+int32_t orr_layout_is_int(int32_t i) { return g_fields[i].is_int; }
+int32_t orr_sizeof_config(void) { return (int32_t)sizeof(orr_config); }
+int32_t orr_sizeof_model(void) { return (int32_t)sizeof(orr_model); }
+
+int32_t orr_create(const orr_config* cfg, orr_handle** out) {
+  if (!cfg || !out) return fail(-1, "orr_create: null argument");
+  if (cfg->abi_version != ORR_ABI_VERSION) return fail(-1, "orr_create: ABI version mismatch");
+  if (cfg->num_robots < 1) return fail(-1, "orr_create: num_robots must be >= 1");
+  if (cfg->action_repeat < 1 || cfg->solver_iters < 1) return fail(-1, "orr_create: action_repeat / solver_iters must be >= 1");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev < 1) return fail(-3, "orr_create: no HIP device available (this library has no CPU fallback)", e);
+  orr_handle* h = new orr_handle();
+  memset(h, 0, sizeof(*h));
+  h->cfg = *cfg;
+  // ActionFilterButter.butter_filter (action_filter.py:196-217): scipy.signal.butter(2, [4 / (fs / 2)], 'low')
+  {
+    const double fs = 1.0 / ((double)cfg->sim_dt * cfg->action_repeat), wn = 4.0 / (0.5 * fs);
+    const double K = tan(M_PI * wn / 2.0), K2 = K * K, den = 1.0 + sqrt(2.0) * K + K2;
+    h->fb[0] = (float)(K2 / den); h->fb[1] = (float)(2.0 * K2 / den); h->fb[2] = (float)(K2 / den);
+    h->fa[0] = 1.0f; h->fa[1] = (float)(2.0 * (K2 - 1.0) / den); h->fa[2] = (float)((1.0 - sqrt(2.0) * K + K2) / den);
+  }
+  e = hipMalloc((void**)&h->tab_dev, sizeof(DevTables));
+  if (e != hipSuccess) { delete h; return fail(-2, "orr_create: hipMalloc", e); }
+  e = hipMemset(h->tab_dev, 0, sizeof(DevTables));
+  if (e != hipSuccess) { hipFree(h->tab_dev); delete h; return fail(-2, "orr_create: hipMemset", e); }
+  hipEventCreate(&h->ev0);
+  hipEventCreate(&h->ev1);
+  *out = h;
+  return 0;
+}
+
+int32_t orr_destroy(orr_handle* h) {
+  if (!h) return 0;
+  hipFree(h->tab_dev);
+  hipEventDestroy(h->ev0);
+  hipEventDestroy(h->ev1);
+  delete h;
+  return 0;
+}
+
+int32_t orr_set_model(orr_handle* h, int32_t robot_type, const orr_model* m) {
+  if (!h || !m) return fail(-1, "orr_set_model: null argument");
+  if (robot_type < 0 || robot_type >= ORR_MAX_ROBOT_TYPES) return fail(-1, "orr_set_model: robot_type out of range");
+  if (m->num_fall_proxies < 0 || m->num_fall_proxies > ORR_MAX_FALL_PROXIES) return fail(-1, "orr_set_model: bad num_fall_proxies");
+  for (int i = 0; i < 12; i++) {
+    if (m->joint_of_motor[i] < 0 || m->joint_of_motor[i] > 11) return fail(-1, "orr_set_model: joint_of_motor out of range");
+    if (m->link_group[i] < 0 || m->link_group[i] > 1) return fail(-1, "orr_set_model: link_group must be 0 or 1");
+  }
+  for (int i = 0; i < m->num_fall_proxies; i++)
+    if (m->fall_body[i] < 0 || m->fall_body[i] > 12) return fail(-1, "orr_set_model: fall_body out of range");
+  h->tab_host.model[robot_type] = *m;
+  HIPCHK(hipMemcpy(&h->tab_dev->model[robot_type], m, sizeof(orr_model), hipMemcpyHostToDevice), "orr_set_model: hipMemcpy");
+  return 0;
+}
+
+int32_t orr_set_motion(orr_handle* h, int32_t clip_id, const float* frames_dev, const float* frame_vels_dev, int32_t num_frames,
+                       float frame_dt, int32_t clip_flags, const float cycle_delta[4]) {
+  if (!h || !frames_dev || !frame_vels_dev || !cycle_delta) return fail(-1, "orr_set_motion: null argument");
+  if (clip_id < 0 || clip_id >= ORR_MAX_CLIPS) return fail(-1, "orr_set_motion: clip_id out of range");
+  if (num_frames < 2) return fail(-1, "orr_set_motion: need at least 2 frames");
+  if (!(frame_dt > 0.0f)) return fail(-1, "orr_set_motion: Frame duration must be positive.");
+  DevClip c;
+  c.frames = frames_dev; c.vels = frame_vels_dev; c.F = num_frames; c.flags = clip_flags;
+  c.dt = frame_dt; c.dur = frame_dt * (num_frames - 1);
+  c.cdp[0] = cycle_delta[0]; c.cdp[1] = cycle_delta[1]; c.cdp[2] = cycle_delta[2]; c.cdh = cycle_delta[3];
+  h->tab_host.clip[clip_id] = c;
+  HIPCHK(hipMemcpy(&h->tab_dev->clip[clip_id], &c, sizeof(DevClip), hipMemcpyHostToDevice), "orr_set_motion: hipMemcpy");
+  return 0;
+}
+
+int32_t orr_bind(orr_handle* h, void* state_dev, int64_t* counters_dev, float* ep_log_dev, int32_t ep_log_capacity) {
+  if (!h || !state_dev) return fail(-1, "orr_bind: null argument");
+  h->state = (float*)state_dev;
+  h->counters = (long long*)counters_dev;
+  h->ep_log = ep_log_dev;
+  h->ep_log_cap = ep_log_dev ? ep_log_capacity : 0;
+  return 0;
+}
+
+static KParams make_params(const orr_handle* h) {
+  KParams P;
+  P.cfg = h->cfg;
+  for (int i = 0; i < 3; i++) { P.fb[i] = h->fb[i]; P.fa[i] = h->fa[i]; }
+  P.tab = h->tab_dev;
+  P.state = h->state;
+  P.counters = h->counters;
+  P.ep_log = h->ep_log;
+  P.ep_log_cap = h->ep_log_cap;
+  return P;
+}
+
+int32_t orr_reset(orr_handle* h, const uint8_t* mask_dev, float* obs_dev, void* stream) {
+  if (!h || !h->state) return fail(-1, "orr_reset: handle not bound");
+  hipLaunchKernelGGL(orr_reset_kernel, dim3(h->cfg.num_robots), dim3(64), 0, (hipStream_t)stream, make_params(h), mask_dev, obs_dev);
+  HIPCHK(hipGetLastError(), "orr_reset: launch");
+  return 0;
+}
+
+int32_t orr_step(orr_handle* h, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev, void* stream) {
+  if (!h || !h->state) return fail(-1, "orr_step: handle not bound");
+  if (!actions_dev || !obs_dev || !reward_dev || !done_dev) return fail(-1, "orr_step: null buffer");
+  hipLaunchKernelGGL(orr_step_kernel<0>, dim3(h->cfg.num_robots), dim3(64), 0, (hipStream_t)stream, make_params(h), actions_dev,
+                     obs_dev, reward_dev, done_dev, 0);
+  HIPCHK(hipGetLastError(), "orr_step: launch");
+  return 0;
+}
+
+// parity / debug entry point (not part of the drop-in surface): nsub physics sub-steps with fixed motor torques
+int32_t orr_debug_physics(orr_handle* h, const float* torques_dev, uint8_t* fall_dev, int32_t nsub, void* stream) {
+  if (!h || !h->state || !torques_dev) return fail(-1, "orr_debug_physics: bad argument");
+  hipLaunchKernelGGL(orr_step_kernel<1>, dim3(h->cfg.num_robots), dim3(64), 0, (hipStream_t)stream, make_params(h), torques_dev,
+                     nullptr, nullptr, fall_dev, nsub);
+  HIPCHK(hipGetLastError(), "orr_debug_physics: launch");
+  return 0;
+}
+
+int32_t orr_time_steps(orr_handle* h, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev, void* stream,
+                       int32_t num_steps, float* total_ms_out) {
+  if (!h || !h->state || !total_ms_out) return fail(-1, "orr_time_steps: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(hipEventRecord(h->ev0, st), "orr_time_steps: event");
+  for (int i = 0; i < num_steps; i++) {
+    int rc = orr_step(h, actions_dev, obs_dev, reward_dev, done_dev, stream);
+    if (rc) return rc;
+  }
+  HIPCHK(hipEventRecord(h->ev1, st), "orr_time_steps: event");
+  HIPCHK(hipEventSynchronize(h->ev1), "orr_time_steps: sync");
+  HIPCHK(hipEventElapsedTime(total_ms_out, h->ev0, h->ev1), "orr_time_steps: elapsed");
+  return 0;
+}
+
+}  // extern "C"

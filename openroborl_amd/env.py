@@ -1,0 +1,313 @@
+"""Host side of the MI355X-native quadruped imitation environment.
+
+VecQuadrupedEnv  tensor-native: reset(mask=None) -> obs[N,160]; step(actions[N,12]) ->
+                 (obs[N,160], reward[N], done[N], info) on torch.float32 ROCm tensors, no host sync,
+                 per-robot masked auto-reset.  Mirrors the attribute surface the reference's agent
+                 reads: num_robot, observation_space, action_space, env_step_counter, seed(), close()
+                 (wrapper_env.py:55-56,58-107; quadruped_gym_env.py:59-61,149-152).
+LegacyListEnv    the reference's exact list-of-numpy protocol (wrapper_env.py:58-107) including the
+                 "caller resets the whole env when any robot is done" flow of
+                 agents/imitation_runners.py:185-205, so a stable-baselines-style loop runs unchanged.
+
+PyTorch only owns the device buffers and the stream; all per-robot work happens inside the HIP
+kernels behind the C-ABI (include/openroborl_hip.h).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _abi, _lib, config as cfgmod, motion, robots, state as statemod
+
+
+class Box(object):
+    """Minimal stand-in for gym.spaces.Box (gym is not a dependency): low / high / shape / dtype."""
+
+    def __init__(self, low, high, dtype=np.float32):
+        self.low = np.asarray(low, dtype=dtype)
+        self.high = np.asarray(high, dtype=dtype)
+        self.shape = self.low.shape
+        self.dtype = np.dtype(dtype)
+
+    def contains(self, x):
+        x = np.asarray(x)
+        return x.shape == self.shape and np.all(x >= self.low) and np.all(x <= self.high)
+
+    def sample(self):
+        return np.random.uniform(self.low, self.high).astype(self.dtype)
+
+    def __repr__(self):
+        return "Box(%s, %s)" % (self.shape, self.dtype)
+
+
+def proprio_bounds():
+    """Sensor bounds in flattened (sorted-name) order: IMU x3 | LastAction x3 | MotorAngle x3
+    (robot_sensors.py:52-71,111-133; environment_sensors.py:37-38; sensor_wrappers.py:108-110)."""
+    imu = np.array([2 * np.pi, 2 * np.pi, 2000 * np.pi, 2000 * np.pi])
+    high = np.concatenate([np.tile(imu, 3), np.ones(36), np.pi * np.ones(36)])
+    return -high, high
+
+
+def target_bounds(clips):
+    """ImitationTask.get_target_obs_bounds (imitation_task.py:303-335)."""
+    low = np.inf * np.ones(_abi.POSE_DIM)
+    high = -np.inf * np.ones(_abi.POSE_DIM)
+    for c in clips:
+        lo, hi = c.joint_bounds()
+        low = np.minimum(low, lo)
+        high = np.maximum(high, hi)
+    low[0:3], high[0:3] = -2.0, 2.0
+    low[3:7], high[3:7] = -1.0, 1.0
+    return np.tile(low, 4), np.tile(high, 4)
+
+
+def observation_space(clips):
+    """WrapperEnv._build_observation_space (wrapper_env.py:127-145)."""
+    pl, ph = proprio_bounds()
+    tl, th = target_bounds(clips)
+    return Box(np.concatenate([pl, tl]), np.concatenate([ph, th]), dtype=np.float32)
+
+
+def action_space():
+    """minitaur.py:145-148."""
+    return Box(np.array([-2 * math.pi] * 12), np.array([2 * math.pi] * 12), dtype=np.float32)
+
+
+class VecQuadrupedEnv(object):
+    """N independent quadrupeds on one GPU; one wavefront per robot (see csrc/orr_kernels.hip)."""
+
+    def __init__(self, task_name=None, training_yaml=None, sim_yaml=None, device="cuda", num_robot=None, seed=None,
+                 robot=None, motion_file=None, mode=None, enable_randomizer=None, auto_reset=True, num_procs=1,
+                 robot_index_offset=0, legacy_grid=False, mixed_robots=None, ep_log_capacity=65536):
+        import torch
+        self.torch = torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("VecQuadrupedEnv needs a ROCm GPU (the HIP path has no CPU fallback)")
+        self.L = _lib.load()
+        self.device = torch.device(device)
+        params = {}
+        if task_name is not None:
+            params = cfgmod.load_training_params(task_name, training_yaml)
+        sim = cfgmod.load_sim_params(sim_yaml)
+        robot = robot or params.get("robot", "laikago")
+        if robot not in robots.ROBOTS:
+            raise ValueError("wrong robot select")                       # minitaur.py:97
+        mode = mode or params.get("mode", "train")
+        if enable_randomizer is None:
+            enable_randomizer = bool(params.get("enable_env_randomizer", True)) and mode == "train"   # run.py:205-206
+        num_robot = int(num_robot if num_robot is not None else params.get("num_robot", 1))
+        seed = int(seed if seed is not None else params.get("seed", 0))
+        motion_file = motion_file or params.get("motion_file")
+        if motion_file is None:
+            raise ValueError("no input robot or task")                   # quadruped_gym_env.py:50-51
+        motion_files = list(motion_file) if isinstance(motion_file, (list, tuple)) else [motion_file]
+        self.num_robot = num_robot
+        self.mode = mode
+        self.cfg = cfgmod.make_config(num_robot, sim_params=sim, mode=mode, enable_randomizer=enable_randomizer, seed=seed,
+                                      num_procs=num_procs, auto_reset=auto_reset, legacy_grid=legacy_grid)
+        # robots: homogeneous batch, or interleaved heterogeneous batch (BASELINE config 5)
+        if mixed_robots:
+            self.robot_names = list(mixed_robots)
+            robot_type = np.array([robots.ROBOT_TYPE_ID[self.robot_names[i % len(self.robot_names)]]
+                                   for i in range(num_robot)], dtype=np.int32)
+        else:
+            self.robot_names = [robot]
+            robot_type = np.full(num_robot, robots.ROBOT_TYPE_ID[robot], dtype=np.int32)
+        self.models = [None] * _abi.MAX_ROBOT_TYPES
+        for name in set(self.robot_names):
+            self.models[robots.ROBOT_TYPE_ID[name]] = robots.ROBOTS[name]()
+        # clips: one per robot type in a mixed batch, else the task's clip
+        self.clips = [motion.MotionClip(f) for f in motion_files]
+        if mixed_robots:
+            if len(self.clips) != len(self.robot_names):
+                raise ValueError("mixed batch needs one motion file per robot name")
+            type_to_clip = {robots.ROBOT_TYPE_ID[n]: i for i, n in enumerate(self.robot_names)}
+            clip_id = np.array([type_to_clip[t] for t in robot_type], dtype=np.int32)
+        else:
+            clip_id = np.zeros(num_robot, dtype=np.int32)
+        self.robot_type = robot_type
+        self.clip_id = clip_id
+
+        h = C.c_void_p()
+        _lib.check(self.L.orr_create(C.byref(self.cfg), C.byref(h)), self.L)
+        self.h = h
+        for t, m in enumerate(self.models):
+            if m is not None:
+                _lib.check(self.L.orr_set_model(self.h, t, C.byref(robots.to_struct(m))), self.L)
+        self._clip_tensors = []
+        for i, c in enumerate(self.clips):
+            fr = torch.tensor(c.frames, dtype=torch.float32, device=self.device).contiguous()
+            fv = torch.tensor(c.frame_vels, dtype=torch.float32, device=self.device).contiguous()
+            self._clip_tensors.append((fr, fv))
+            cd = (C.c_float * 4)(*[float(x) for x in c.cycle_delta])
+            _lib.check(self.L.orr_set_motion(self.h, i, fr.data_ptr(), fv.data_ptr(), c.num_frames,
+                                             float(c.frame_duration), c.flags, cd), self.L)
+        self.layout = statemod.Layout(self.L, "orr")
+        idx = np.arange(num_robot, dtype=np.int32) + int(robot_index_offset)
+        st = statemod.default_state(self.layout, num_robot, self.models, robot_type, clip_id, idx,
+                                    legacy_grid=legacy_grid, ctrl_latency=cfgmod.CTRL_LATENCY,
+                                    max_ep_steps=self.cfg.ep_len_end)
+        self.state = torch.from_numpy(st).to(self.device).contiguous()
+        self.counters = torch.zeros(_abi.NUM_COUNTERS, dtype=torch.int64, device=self.device)
+        self.ep_log = torch.zeros((max(int(ep_log_capacity), 1), 2), dtype=torch.float32, device=self.device)
+        _lib.check(self.L.orr_bind(self.h, self.state.data_ptr(), self.counters.data_ptr(), self.ep_log.data_ptr(),
+                                   int(ep_log_capacity)), self.L)
+        self.obs = torch.zeros((num_robot, _abi.OBS_DIM), dtype=torch.float32, device=self.device)
+        self.reward = torch.zeros(num_robot, dtype=torch.float32, device=self.device)
+        self.done = torch.zeros(num_robot, dtype=torch.uint8, device=self.device)
+        self.observation_space = observation_space(self.clips)
+        self.action_space = action_space()
+        self._env_step_counter = 0
+        self._closed = False
+
+    # ---- reference attribute surface -------------------------------------------------------
+    @property
+    def env_step_counter(self):
+        """quadruped_gym_env.py:336-337 (env-global in the reference; here: steps since the last full reset)."""
+        return self._env_step_counter
+
+    @property
+    def env_time_step(self):
+        return self.cfg.action_repeat * self.cfg.sim_dt
+
+    def seed(self, seed=None):
+        """quadruped_gym_env.py:59-61.  The RNG is counter-based (Philox keyed by seed, robot, episode); the
+        seed is fixed at construction (pass seed= to the constructor), so this only reports it."""
+        if seed is not None and (int(seed) & 0xFFFFFFFFFFFFFFFF) != int(self.cfg.seed):
+            raise ValueError("the env seed is fixed at construction; build a new env with seed=%r" % (seed,))
+        return [int(self.cfg.seed)]
+
+    def close(self):
+        if not self._closed and self.h:
+            self.torch.cuda.synchronize(self.device)
+            self.L.orr_destroy(self.h)
+            self.h = None
+            self._closed = True
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- hot path ------------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def reset(self, mask=None):
+        """WrapperEnv.reset (wrapper_env.py:87-107).  mask: optional bool/uint8 tensor [N]; rows of robots
+        that are not reset keep their previous observation."""
+        mp = None
+        if mask is not None:
+            mask = mask.to(device=self.device, dtype=self.torch.uint8).contiguous()
+            mp = mask.data_ptr()
+        else:
+            self._env_step_counter = 0
+        _lib.check(self.L.orr_reset(self.h, mp, self.obs.data_ptr(), self._stream()), self.L)
+        return self.obs
+
+    def step(self, actions):
+        """WrapperEnv.step (wrapper_env.py:58-85).  actions: float32 [N,12] on the env device (policy
+        outputs, clipped to +-2 pi by the caller as in imitation_runners.py:140-143)."""
+        t = self.torch
+        if actions.dtype != t.float32 or actions.device != self.obs.device or not actions.is_contiguous():
+            actions = actions.to(device=self.device, dtype=t.float32).contiguous()
+        if tuple(actions.shape) != (self.num_robot, _abi.NUM_MOTORS):
+            raise ValueError("actions must have shape (%d, %d)" % (self.num_robot, _abi.NUM_MOTORS))
+        _lib.check(self.L.orr_step(self.h, actions.data_ptr(), self.obs.data_ptr(), self.reward.data_ptr(),
+                                   self.done.data_ptr(), self._stream()), self.L)
+        self._env_step_counter += 1
+        return self.obs, self.reward, self.done, {}
+
+    def time_steps(self, actions, num_steps):
+        """Bench helper: num_steps back-to-back launches timed with hipEvents on the launch stream (ms)."""
+        ms = C.c_float()
+        _lib.check(self.L.orr_time_steps(self.h, actions.data_ptr(), self.obs.data_ptr(), self.reward.data_ptr(),
+                                         self.done.data_ptr(), self._stream(), int(num_steps), C.byref(ms)), self.L)
+        self._env_step_counter += int(num_steps)
+        return float(ms.value)
+
+    def debug_physics(self, torques, nsub):
+        fall = self.torch.zeros(self.num_robot, dtype=self.torch.uint8, device=self.device)
+        _lib.check(self.L.orr_debug_physics(self.h, torques.data_ptr(), fall.data_ptr(), int(nsub), self._stream()), self.L)
+        return fall
+
+    # ---- state access (checkpoint / parity injection) -------------------------------------------
+    def field(self, name):
+        """View of a float field of the state tensor: [N, size]."""
+        return self.state[:, self.layout.sl(name)]
+
+    def field_int(self, name):
+        return self.state.view(self.torch.int32)[:, self.layout.sl(name)]
+
+    def state_dict(self):
+        return {"state": self.state.clone(), "counters": self.counters.clone(), "env_step_counter": self._env_step_counter}
+
+    def load_state_dict(self, d):
+        self.state.copy_(d["state"])
+        self.counters.copy_(d["counters"])
+        self._env_step_counter = int(d["env_step_counter"])
+
+    def episode_log(self):
+        """(returns[K], lengths[K]) of the episodes finished since the last call; clears the log.  Syncs."""
+        n = int(self.counters[_abi.CNT_EPISODES].item())
+        k = min(n, self.ep_log.shape[0])
+        log = self.ep_log[:k].clone()
+        self.counters[_abi.CNT_EPISODES] = 0
+        self.counters[_abi.CNT_EPLOG_DROPPED] = 0
+        return log[:, 0], log[:, 1]
+
+
+class LegacyListEnv(object):
+    """The reference's list-of-numpy env protocol on top of a VecQuadrupedEnv built with auto_reset=False.
+
+    reset() -> list[N] of float64 arrays (160,)
+    step(list[N] of arrays (12,)) -> (obs list, reward list[float], done list[bool], info list[dict])
+    (wrapper_env.py:58-107).  As in the reference, the caller resets the WHOLE env when any (train,
+    imitation_runners.py:185-205) or all (test, run.py:169) robots are done, `info[i]["terminated"]` aliases
+    the done list, the time limit uses the env-global step counter, and the caller's action arrays get
+    INIT_MOTOR_ANGLES added in place (minitaur.py:281).
+    """
+
+    def __init__(self, env, mutate_actions=True):
+        if env.cfg.flags & _abi.FLAG_AUTO_RESET:
+            raise ValueError("LegacyListEnv needs a VecQuadrupedEnv created with auto_reset=False")
+        self._env = env
+        self._mutate = mutate_actions
+        self.num_robot = env.num_robot
+        self.observation_space = env.observation_space
+        self.action_space = env.action_space
+        self._init_angles = [np.asarray(env.models[t]["init_motor_angles"], dtype=np.float64) for t in env.robot_type]
+
+    def __getattr__(self, attr):           # wrapper_env.py:55-56
+        return getattr(self._env, attr)
+
+    def reset(self):
+        obs = self._env.reset().detach().cpu().numpy().astype(np.float64)
+        return [obs[i] for i in range(self.num_robot)]
+
+    def step(self, action):
+        t = self._env.torch
+        a = np.stack([np.asarray(action[i], dtype=np.float32) for i in range(self.num_robot)])
+        obs, rew, done, _ = self._env.step(t.from_numpy(a).to(self._env.device))
+        if self._mutate:
+            for i in range(self.num_robot):
+                try:
+                    action[i] += self._init_angles[i]
+                except Exception:
+                    pass
+        obs = obs.detach().cpu().numpy().astype(np.float64)
+        rew = rew.detach().cpu().numpy().astype(np.float64)
+        done = done.detach().cpu().numpy().astype(bool)
+        done_list = [bool(d) for d in done]
+        info = [{"terminated": done_list} for _ in range(self.num_robot)]
+        return [obs[i] for i in range(self.num_robot)], [float(r) for r in rew], done_list, info
+
+
+def build_env(task_name, num_robot=None, mode=None, enable_randomizer=None, legacy=False, **kw):
+    """Counterpart of run.py:49-97 build_env for the two imitation tasks."""
+    if task_name not in cfgmod.TASKS:
+        raise ValueError("unknown task %r" % (task_name,))
+    env = VecQuadrupedEnv(task_name=task_name, num_robot=num_robot, mode=mode, enable_randomizer=enable_randomizer,
+                          auto_reset=not legacy, **kw)
+    return LegacyListEnv(env) if legacy else env

@@ -1,0 +1,248 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C-ABI, against the
+CPU oracle on identical seeded inputs.  Tolerances: the device computes in float32, the oracle in float64;
+one physics sub-step agrees to ~1e-5, a full env step (33 sub-steps with contacts) to ~1e-3 on states and
+2e-3 on rewards; longer rollouts are compared statistically (contact dynamics amplify rounding)."""
+import os
+
+import numpy as np
+import pytest
+
+from openroborl_amd import _abi, config, motion, robots, state as statemod
+from tests import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+CLIP = {"laikago": "laikago_pace", "mini_cheetah": "minicheetah_trot"}
+
+
+def make_pair(robot="laikago", n=32, randomizer=False, auto_reset=False, seed=3, mode="test", mixed=None, legacy_grid=False):
+    import torch
+    from openroborl_amd.env import VecQuadrupedEnv
+    if mixed:
+        env = VecQuadrupedEnv(num_robot=n, seed=seed, mode=mode, enable_randomizer=randomizer, auto_reset=auto_reset,
+                              mixed_robots=mixed, motion_file=[CLIP[m] for m in mixed], legacy_grid=legacy_grid)
+    else:
+        env = VecQuadrupedEnv(num_robot=n, seed=seed, robot=robot, motion_file=CLIP[robot], mode=mode,
+                              enable_randomizer=randomizer, auto_reset=auto_reset, legacy_grid=legacy_grid)
+    orc = ol.OracleEnv(env.cfg, env.models, env.clips, n, robot_type=env.robot_type, clip_id=env.clip_id, threads=8)
+    return env, orc
+
+
+def gpu_state64(env):
+    return statemod.to_float64(env.layout, env.state.detach().cpu().numpy())
+
+
+def push_state(env, st64):
+    import torch
+    env.state.copy_(torch.from_numpy(statemod.from_float64(env.layout, st64)).to(env.device))
+
+
+def compare_fields(env, orc, names, atol, rtol=0.0, what=""):
+    g = gpu_state64(env)
+    for name in names:
+        sl = env.layout.sl(name)
+        if env.layout.is_int(name):
+            np.testing.assert_array_equal(g[:, sl], orc.state[:, sl], err_msg="%s %s" % (what, name))
+        else:
+            np.testing.assert_allclose(g[:, sl], orc.state[:, sl], atol=atol, rtol=rtol, err_msg="%s %s" % (what, name))
+
+
+RIGID = ["POS", "QUAT", "LINVEL", "ANGVEL", "Q", "QD"]
+
+
+@pytest.mark.parametrize("robot", ["laikago", "mini_cheetah"])
+def test_physics_substep_parity(robot):
+    """Row C in isolation: ABA + contact/limit/friction rows + PGS + integration, fixed torques."""
+    import torch
+    n = 64
+    env, orc = make_pair(robot, n=n)
+    env.reset(); orc.reset()
+    rng = np.random.RandomState(0)
+    st = gpu_state64(env)
+    lay = env.layout
+    # spread the robots over airborne / touching / penetrating configurations with random velocities
+    st[:, lay.sl("POS")][:, 2] += rng.uniform(-0.03, 0.15, n)
+    st[:, lay.sl("LINVEL")] += rng.randn(n, 3) * 0.3
+    st[:, lay.sl("ANGVEL")] += rng.randn(n, 3) * 0.5
+    st[:, lay.sl("QD")] += rng.randn(n, 12) * 1.0
+    st[:, lay.sl("KNEE_FRICTION")] = rng.uniform(0, 0.05, (n, 4)) * (rng.rand(n, 1) < 0.5)
+    st[:, lay.sl("FOOT_MU")] = rng.uniform(0.5, 1.25, (n, 1))
+    st[: n // 8, lay.sl("Q")][:, 2] = -2.2 if robot == "laikago" else st[: n // 8, lay.sl("Q")][:, 2]  # knee into its limit
+    st = statemod.to_float64(lay, statemod.from_float64(lay, st))   # both sides start from float32-representable numbers
+    push_state(env, st); orc.state[:] = st
+    tau = rng.uniform(-15, 15, (n, 12))
+    tg = torch.tensor(tau, dtype=torch.float32, device=env.device)
+    tau = tg.cpu().numpy().astype(np.float64)
+    for nsub, tol in ((1, 2e-5), (8, 2e-4)):
+        fall_g = env.debug_physics(tg, nsub).cpu().numpy()
+        fall_o = np.zeros(n, dtype=int)
+        for i in range(n):
+            for _ in range(nsub):
+                fall_o[i] = orc.L.orc_physics_substep(orc.h, ol.P(orc.state[i]), ol.P(np.ascontiguousarray(tau[i])))
+        compare_fields(env, orc, RIGID, atol=tol, rtol=tol, what="nsub=%d" % nsub)
+        compare_fields(env, orc, ["LAMBDA"], atol=5e-4 if nsub == 1 else 5e-3, what="nsub=%d" % nsub)
+        assert (fall_g.astype(int) == fall_o).mean() > 0.95
+    env.close(); orc.close()
+
+
+@pytest.mark.parametrize("robot,randomizer", [("laikago", False), ("laikago", True), ("mini_cheetah", True)])
+def test_reset_parity(robot, randomizer):
+    env, orc = make_pair(robot, n=128, randomizer=randomizer, mode="train" if randomizer else "test")
+    og = env.reset().cpu().numpy()
+    oo = orc.reset()
+    np.testing.assert_allclose(og, oo, atol=2e-6)
+    names = [f for f in env.layout.order if f not in ("RING", "RESERVED_I")]
+    compare_fields(env, orc, names, atol=2e-6, what="reset")
+    # ring: entries 0 and 1 were written
+    g = gpu_state64(env)
+    sl = env.layout.sl("RING")
+    np.testing.assert_allclose(g[:, sl][:, :2 * _abi.RING_ENTRY], orc.state[:, sl][:, :2 * _abi.RING_ENTRY], atol=2e-6)
+    env.close(); orc.close()
+
+
+@pytest.mark.parametrize("robot,randomizer", [("laikago", False), ("laikago", True), ("mini_cheetah", False)])
+def test_step_parity(robot, randomizer):
+    import torch
+    n = 64
+    env, orc = make_pair(robot, n=n, randomizer=randomizer, mode="train" if randomizer else "test")
+    env.reset(); orc.reset()
+    # identical starting point on both sides (float32-representable)
+    st = gpu_state64(env)
+    orc.state[:] = st
+    rng = np.random.RandomState(5)
+    act = torch.tensor(rng.uniform(-0.3, 0.3, (n, 12)), dtype=torch.float32, device=env.device)
+    og, rg, dg, _ = env.step(act)
+    oo, ro, do = orc.step(act.cpu().numpy().astype(np.float64))
+    og, rg, dg = og.cpu().numpy(), rg.cpu().numpy(), dg.cpu().numpy().astype(bool)
+    compare_fields(env, orc, ["POS", "QUAT", "Q"], atol=2e-4, what="step")
+    compare_fields(env, orc, ["LINVEL", "ANGVEL", "QD"], atol=2e-2, rtol=2e-3, what="step")
+    compare_fields(env, orc, ["ACTION", "FILTER_ACTION", "LAST_ACTION", "XHIST", "YHIST", "TIME_OFFSET", "ORIGIN_ROT",
+                              "PREV_PHASE", "REF_POSE"], atol=5e-6, what="step")
+    compare_fields(env, orc, ["STATE_ACTION_COUNTER", "STEP_COUNTER", "FILTER_VALID", "RING_LEN", "RING_HEAD", "EP_STEP",
+                              "WARMUP", "MAX_EP_STEPS", "EPISODE_IDX"], atol=0, what="step")
+    np.testing.assert_allclose(rg, ro, atol=3e-3)
+    np.testing.assert_allclose(og[:, :12], oo[:, :12], atol=2e-2, rtol=1e-2)       # IMU (rates are noisy)
+    np.testing.assert_allclose(og[:, 12:84], oo[:, 12:84], atol=5e-4)              # last action + motor angles
+    np.testing.assert_allclose(og[:, 84:], oo[:, 84:], atol=5e-4)                  # target frames
+    assert (dg == do).mean() > 0.97
+    env.close(); orc.close()
+
+
+def test_short_rollout_tracks_oracle():
+    """10 env steps from an identical start: trajectories stay close (loose: contact dynamics amplify rounding)."""
+    import torch
+    n = 32
+    env, orc = make_pair("laikago", n=n)
+    env.reset(); orc.reset()
+    orc.state[:] = gpu_state64(env)
+    rng = np.random.RandomState(9)
+    for k in range(10):
+        a = rng.uniform(-0.2, 0.2, (n, 12)).astype(np.float32)
+        og, rg, dg, _ = env.step(torch.from_numpy(a).to(env.device))
+        oo, ro, do = orc.step(a.astype(np.float64))
+    np.testing.assert_allclose(rg.cpu().numpy(), ro, atol=0.05)
+    g = gpu_state64(env)
+    sl = env.layout.sl("POS")
+    assert np.median(np.abs(g[:, sl] - orc.state[:, sl])) < 2e-3
+    env.close(); orc.close()
+
+
+def test_mixed_batch_parity():
+    """BASELINE config 5: interleaved Laikago / mini-cheetah robots in one launch (divergent wavefronts)."""
+    import torch
+    n = 64
+    env, orc = make_pair(n=n, mixed=["laikago", "mini_cheetah"])
+    og = env.reset().cpu().numpy()
+    oo = orc.reset()
+    np.testing.assert_allclose(og, oo, atol=2e-6)
+    orc.state[:] = gpu_state64(env)
+    a = np.random.RandomState(1).uniform(-0.2, 0.2, (n, 12)).astype(np.float32)
+    og, rg, dg, _ = env.step(torch.from_numpy(a).to(env.device))
+    oo, ro, do = orc.step(a.astype(np.float64))
+    np.testing.assert_allclose(rg.cpu().numpy(), ro, atol=3e-3)
+    np.testing.assert_allclose(og.cpu().numpy()[:, 84:], oo[:, 84:], atol=5e-4)
+    env.close(); orc.close()
+
+
+def test_shipped_policy_on_gpu():
+    """Behavioural probe on the HIP path: the reference's laikago_pace policy keeps 64 robots on the clip for
+    the full 600-step episode."""
+    import torch
+    W = np.load(os.path.join(ol.GOLDEN, "policy_laikago_pace.npz"))
+    n = 64
+    env, orc = make_pair("laikago", n=n, seed=1)
+    orc.close()
+    dev = env.device
+    w = {k: torch.tensor(W[k], device=dev) for k in W.files}
+    obs = env.reset()
+    ret = torch.zeros(n, device=dev)
+    alive = torch.ones(n, dtype=torch.bool, device=dev)
+    for step in range(600):
+        h = torch.relu(obs @ w["model__pi_fc0__w_0"] + w["model__pi_fc0__b_0"])
+        h = torch.relu(h @ w["model__pi_fc1__w_0"] + w["model__pi_fc1__b_0"])
+        a = torch.clamp(h @ w["model__pi__w_0"] + w["model__pi__b_0"], -2 * np.pi, 2 * np.pi)
+        obs, rew, done, _ = env.step(a.contiguous())
+        ret += rew * alive
+        if step < 599:
+            alive &= ~done.bool()
+    assert alive.float().mean().item() > 0.95, alive.float().mean().item()
+    assert ret[alive].mean().item() > 350.0
+    reasons = env.field_int("DONE_REASON")[:, 0].cpu().numpy()
+    assert np.all(reasons[alive.cpu().numpy()] == _abi.DONE_TIME_LIMIT)
+    env.close()
+
+
+def test_full_size_properties():
+    """BASELINE config 2 size (4096 Laikago robots, randomiser on, auto-reset): size-independent properties."""
+    import torch
+    n = 4096
+    outs = []
+    for rep in range(2):
+        env, orc = make_pair("laikago", n=n, randomizer=True, auto_reset=True, mode="train", seed=21)
+        orc.close()
+        obs = env.reset()
+        g = torch.Generator(device="cpu"); g.manual_seed(0)
+        total_done = 0
+        for k in range(40):
+            a = (torch.randn(n, 12, generator=g) * 0.125).to(env.device)
+            obs, rew, done, _ = env.step(a)
+            assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
+            assert (rew >= 0).all() and (rew <= 1.0 + 1e-6).all()
+            total_done += int(done.sum().item())
+        torch.cuda.synchronize()
+        cnt = env.counters.cpu().numpy()
+        assert cnt[_abi.CNT_TOTAL_STEP_COUNT] == total_done          # wrapper_env.py:82-83 per reset robot
+        assert cnt[_abi.CNT_TOTAL_TIMESTEPS] == 40 * n
+        assert cnt[_abi.CNT_TICKET] == 0 and cnt[_abi.CNT_DONE_ACCUM] == 0
+        assert total_done > 0                                          # curriculum start: 20-step episodes
+        ep = env.field_int("EP_STEP")[:, 0].cpu().numpy()
+        assert ep.max() < 20 and ep.min() >= 0
+        low = torch.tensor(env.observation_space.low[48:84], device=env.device)
+        assert (obs[:, 48:84] >= low - 1e-5).all()
+        outs.append((obs.cpu().numpy().copy(), env.state.cpu().numpy().copy()))
+        env.close()
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])              # bitwise reproducible for a fixed seed
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+
+
+def test_masked_reset_and_legacy_protocol():
+    import torch
+    from openroborl_amd.env import VecQuadrupedEnv, LegacyListEnv
+    env = VecQuadrupedEnv(task_name="imitation_learning_laikago", num_robot=6, mode="test", auto_reset=False, seed=2)
+    leg = LegacyListEnv(env)
+    o = leg.reset()
+    assert len(o) == 6 and o[0].shape == (160,) and o[0].dtype == np.float64
+    acts = [np.zeros(12, dtype=np.float32) for _ in range(6)]
+    o, r, d, info = leg.step(acts)
+    assert isinstance(r[0], float) and isinstance(d[0], bool) and info[0]["terminated"] is d or info[0]["terminated"] == d
+    np.testing.assert_allclose(acts[0], env.models[0]["init_motor_angles"], atol=1e-6)   # in-place += INIT (minitaur.py:281)
+    assert leg.env_step_counter == 1 and leg.num_robot == 6
+    assert leg.observation_space.shape == (160,) and leg.action_space.shape == (12,)
+    # masked reset leaves the other robots untouched
+    before = env.state.clone()
+    mask = torch.tensor([1, 0, 0, 1, 0, 0], dtype=torch.uint8, device=env.device)
+    env.reset(mask)
+    after = env.state
+    assert torch.equal(before[1], after[1]) and torch.equal(before[4], after[4])
+    assert not torch.equal(before[0], after[0])
+    env.close()
