@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env steps/sec at N parallel robots (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1]): imitation_learning_laikago, 4096 robots per GPU, laikago_pace clip,
+train semantics (domain randomiser on, 20->600 step curriculum, per-robot auto-reset).  A "step" is one
+env.step() of all robots of a GPU = one launch of the fused HIP kernel = 33 physics sub-steps +
+observation + reward + termination (+ auto-reset) per robot.  Actions are the policy-free stress input of
+SURVEY.md section 8d: reference joint pose one control step ahead (taken from the observation), in
+motor space, plus N(0, 0.125^2) noise, generated on the device.  N > 1: independent shards, one process
+per GPU, and the rollout-boundary all_gather of episode returns (RCCL) every 256 steps and at the end.
+
+Prints ONE JSON line (rank 0).  The roofline object prices the step kernel against HBM bandwidth as the
+north star asks; DESIGN.md section 6 explains why the kernel is VALU-latency bound and nowhere near it.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ROBOTS_PER_GPU = 4096
+ROLLOUT = 256
+# algorithmic HBM bytes per robot-step of the step kernel: actions 48 + obs 640 +
+# reward 4 + done 1 = 693; state head 307 words read + written = 2456; latency ring 33 entries written
+# (2640) + 35 distinct entries read (2660).  Model tables and clip frames are shared and L2-resident.
+B_ALG = 693 + 2456 + 2640 + 2660
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(env, seconds_target=12.0):
+    """Time the CPU oracle (kind "port") on the host cores on a bounded sample of the same workload."""
+    import numpy as np
+    from tests import oracle_lib as ol
+    cores = os.cpu_count() or 1
+    n = 32 * cores
+    orc = ol.OracleEnv(env.cfg, env.models, env.clips, n, robot_type=0, clip_id=0, threads=cores)
+    obs = orc.reset()
+    jom = env.models[0]["joint_of_motor"]
+    m = env.models[0]
+    rng = np.random.RandomState(0)
+
+    def act(o):
+        tar = o[:, 84 + 7:84 + 19]
+        a = (tar[:, jom] - m["motor_offset"]) * m["motor_dir"] - m["init_motor_angles"] + rng.randn(n, 12) * 0.125
+        return np.clip(a, -2 * np.pi, 2 * np.pi)
+    for _ in range(2):
+        obs, _, _ = orc.step(act(obs))
+    t0 = time.time()
+    steps = 0
+    while time.time() - t0 < seconds_target:
+        obs, _, _ = orc.step(act(obs))
+        steps += 1
+    dt = time.time() - t0
+    orc.close()
+    return {"value": n * steps / dt, "unit": "env steps/s", "cores": cores, "kind": "port",
+            "sample": "%d robots x %d env steps of the same workload, oracle/orr_oracle.c with %d OpenMP threads" % (n, steps, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--robots-per-gpu", type=int, default=ROBOTS_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from openroborl_amd import dist as odist
+    from openroborl_amd.env import VecQuadrupedEnv
+
+    rank, world, local = odist.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus > 1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    n = args.robots_per_gpu
+    env = VecQuadrupedEnv(task_name="imitation_learning_laikago", num_robot=n, mode="train", enable_randomizer=True,
+                          auto_reset=True, seed=0, device=dev, num_procs=world, robot_index_offset=rank * n)
+    m = env.models[0]
+    jom = torch.tensor(m["joint_of_motor"], dtype=torch.long, device=dev)
+    off = torch.tensor(m["motor_offset"], dtype=torch.float32, device=dev)
+    mdir = torch.tensor(m["motor_dir"], dtype=torch.float32, device=dev)
+    init = torch.tensor(m["init_motor_angles"], dtype=torch.float32, device=dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    noise_pool = torch.randn(64, n, 12, generator=gen, device=dev) * 0.125
+    two_pi = 2.0 * 3.141592653589793
+
+    def make_action(obs, k):
+        tar = obs[:, 84 + 7:84 + 19]
+        return torch.clamp((tar.index_select(1, jom) - off) * mdir - init + noise_pool[k & 63], -two_pi, two_pi)
+
+    def sync_all():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(dev)
+
+    obs = env.reset()
+    for k in range(args.warmup):
+        obs, rew, done, _ = env.step(make_action(obs, k))
+    env.episode_log()
+    sync_all()
+    t0 = time.perf_counter()
+    since = 0
+    n_eps = 0
+    for k in range(args.steps):
+        obs, rew, done, _ = env.step(make_action(obs, k))
+        since += 1
+        if since == ROLLOUT or k == args.steps - 1:
+            rets, lens, ts, dropped = odist.gather_env_episodes(env, since)
+            n_eps += int(rets.numel())
+            since = 0
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
+    elapsed = float(el.item())
+
+    # dominant kernel: average launch duration with hipEvents on the launch stream (same workload state)
+    act = make_action(obs, 0).contiguous()
+    torch.cuda.synchronize(dev)
+    kern_ms = env.time_steps(act, 50) / 50.0
+    achieved = B_ALG * n / (kern_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "env steps/sec at N parallel robots", "value": world * n * args.steps / elapsed, "unit": "env steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "imitation_learning_laikago, %d parallel robots per GPU, laikago_pace motion_file "
+                                   "(BASELINE configs[1]; configs[3] when n_gpus=8)" % n,
+                       "robots_per_gpu": n, "total_robots": world * n, "substeps_per_step": 33, "solver_iters": 9,
+                       "randomizer": True, "auto_reset": True, "actions": "reference pose + N(0,0.125^2), on device",
+                       "collective": "all_gather of episode returns every %d steps" % ROLLOUT,
+                       "episodes_gathered": n_eps},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "orr_step_kernel<0>", "kernel_ms": kern_ms, "alg_bytes_per_robot_step": B_ALG,
+                         "note": "VALU/latency-bound serial chain (33 x (ABA + 9 PGS sweeps)); HBM fraction is reported "
+                                 "because the north star asks for it, see DESIGN.md section 6"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(env)
+        print(json.dumps(out))
+    env.close()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
