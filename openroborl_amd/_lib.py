@@ -38,6 +38,8 @@ def build(force=False, verbose=False):
         return LIB_PATH
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-Wno-unused-value",
            "-o", LIB_PATH, SRC]
+    if os.environ.get("ORR_WAVES_PER_EU"):
+        cmd.insert(-3, "-DORR_WAVES_PER_EU=%d" % int(os.environ["ORR_WAVES_PER_EU"]))
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -10,6 +10,7 @@
 // Arithmetic: float32.  Reference citations are relative to /root/reference/OpenRoboRL/.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "../../include/openroborl_hip.h"
@@ -21,7 +22,6 @@ namespace orr {
 
 constexpr int kMaxRows = 28;  // 4 knee-friction + <=12 joint-limit + 12 contact rows
 constexpr int kHead = 320;    // words of the state record staged in LDS (everything before the ring)
-constexpr int kLinkCache = 36;
 
 struct DevClip {
   const float* frames;
@@ -32,8 +32,44 @@ struct DevClip {
   float cdh;
 };
 
+// Compact, kernel-facing robot model; built on the host by orr_set_model from orr_model.
+// All joints are required to turn about coordinate axes of the kinematic frame: the hip (k = 0) about
+// +-x, upper and lower leg (k = 1, 2) about +-y.  The sign is folded into the internal joint angle
+//   a = jdir * (q_urdf - joff),  jdir = JOINT_DIRECTION * axis_sign,
+// so that inside the kernels every joint turns about +x or +y.
+struct ModelHot {
+  float init_pos[3];
+  float init_quat[4];
+  float init_motor_angles[12], motor_dir[12], motor_offset[12];
+  int joint_of_motor[12];
+  int motor_of_joint[12];
+  float kp[12], kd[12];
+  float jdir[12], joff[12];   // per JOINT (URDF order)
+  float tau_sign[12];         // per joint: internal torque = tau_sign * motor torque
+  float link_com[12][3];
+  float joint_pos[12][3];
+  float joint_lo[12], joint_hi[12];  // limits of the internal angle
+  float toe_pos[4][3];
+  float lower_com[4][3];
+  float default_joints[12];   // (INIT_MOTOR_ANGLES + OFFSET) * DIR, motor order (imitation_task.py:1245-1252)
+  float toe_radius, foot_friction;
+  int num_fall;
+  int fall_body[ORR_MAX_FALL_PROXIES];
+  float fall_pos[ORR_MAX_FALL_PROXIES][3];
+  float fall_radius[ORR_MAX_FALL_PROXIES];
+};
+struct DevModel {
+  ModelHot hot;  // staged in LDS by every wave
+  // ---- not staged in LDS: read once per launch by lanes 0..12
+  float mass[13];
+  float inertia[13][6];
+  float inertia_pa[13][6];
+  int group[13];
+};
+constexpr int kModelLdsWords = (int)(sizeof(ModelHot) / 4);
+
 struct DevTables {
-  orr_model model[ORR_MAX_ROBOT_TYPES];
+  DevModel model[ORR_MAX_ROBOT_TYPES];
   DevClip clip[ORR_MAX_CLIPS];
 };
 
@@ -48,44 +84,50 @@ struct KParams {
 };
 
 // ------------------------------------------------------------------------------------------------
-// LDS image of one robot (one wave).  ~2.7 K words.
+// LDS image of one robot (one wave): ~1.9 K words (7.6 KB) -> 16 waves per CU (4 per SIMD) fit in 160 KB
 // ------------------------------------------------------------------------------------------------
-struct LinkCache {  // per movable link, written by the leg lanes, read by the row lanes
-  float R[9];       // child -> parent rotation
+struct LinkCache {  // per movable link, written by the leg lanes (0..3), read by the row lanes
+  float c, s;       // cos / sin of the internal joint angle
   float U[6];
   float invD;
   float u;          // tau - S.pA
   float Rw[9];      // link -> world
   float ow[3];      // link origin, world
-  float pad;
+  float cv[6];      // velocity-product acceleration
+  float pA[6];      // bias force of the link itself
+};
+
+struct SubstepBuf {           // live only inside a physics sub-step
+  float W[kMaxRows][18];      // M^-1 J^T per row slot
+};
+struct StepEndBuf {           // live only at reset / end of step
+  float frames[11][19];       // staged clip frames: 5 sample times x (f0, f1) + frame 0
+  float fvel[2][18];
+  float pose[5][19];          // sampled reference poses (update time + 4 target times)
+  float vel[18];
+  float ee[2][8][3];          // end-effector world positions, [0] sim [1] ref
+  float obs[ORR_OBS_DIM];
+};
+union PhaseBuf {
+  SubstepBuf sub;
+  StepEndBuf end;
 };
 
 struct Shared {
-  float s[kHead];                // state head (float / int bit patterns)
-  orr_model m;                   // model table of this robot's type
-  float jdir[12], joff[12];      // per JOINT (URDF order) direction / offset
-  int motor_of_joint[12];
-  float mass[13];                // after randomisation ratios
+  float s[kHead];             // state head (float / int bit patterns)
+  ModelHot m;                 // robot model (hot part)
+  float mass[13];             // after randomisation ratios
   float Ic[13][6];
   LinkCache lc[12];
-  float Rb[9];                   // kinematic base frame -> world
+  float Rb[9];                // kinematic base frame -> world
   float IA0inv[36];
-  float tau[12];                 // joint torques, kinematic convention, joint order
+  float tau[12];              // joint torques (internal sign convention), joint order
   float acc[18];
   float ustar[18];
   float du[18];
-  float W[kMaxRows][18];         // M^-1 J^T per dense row
-  float A[kMaxRows][kMaxRows + 1];
-  float lam[kMaxRows];
-  float rowdata[kMaxRows][8];    // per dense row: rhs*jdi, jdi, lo, hi, mu, normal row, warm slot, lambda0
-  float co[20];                  // control (latency-delayed) observation
-  float frames[10][19];          // staged clip frames: 5 sample times x (f0, f1)
-  float fvel[2][18];
-  float pose[5][19];             // sampled reference poses (update time + 4 target times)
-  float vel[18];
-  float ee[2][8][3];             // end-effector world positions, [0] sim [1] ref
+  float co[20];               // control (latency-delayed) observation
   float red[64];
-  int imisc[16];
+  PhaseBuf ph;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -164,6 +206,78 @@ __device__ __forceinline__ void rodrigues(const float ax[3], float ang, float R[
   R[3] = t * x * y + s * z; R[4] = t * y * y + c; R[5] = t * y * z - s * x;
   R[6] = t * x * z - s * y; R[7] = t * y * z + s * x; R[8] = t * z * z + c;
 }
+
+// ------------------------------------------------------------------------------------------------
+// rotations about a coordinate axis AX (0 = x, 1 = y) by the angle with cosine c, sine s.
+// R maps child-frame coordinates to parent-frame coordinates.
+// ------------------------------------------------------------------------------------------------
+template <int AX>
+__device__ __forceinline__ void rot_fwd(float c, float s, const float v[3], float o[3]) {  // o = R v
+  const float v0 = v[0], v1 = v[1], v2 = v[2];
+  if (AX == 0) { o[0] = v0; o[1] = c * v1 - s * v2; o[2] = s * v1 + c * v2; }
+  else { o[0] = c * v0 + s * v2; o[1] = v1; o[2] = -s * v0 + c * v2; }
+}
+template <int AX>
+__device__ __forceinline__ void rot_inv(float c, float s, const float v[3], float o[3]) {  // o = R^T v
+  const float v0 = v[0], v1 = v[1], v2 = v[2];
+  if (AX == 0) { o[0] = v0; o[1] = c * v1 + s * v2; o[2] = -s * v1 + c * v2; }
+  else { o[0] = c * v0 - s * v2; o[1] = v1; o[2] = s * v0 + c * v2; }
+}
+// O = R S R^T for symmetric S = (xx yy zz xy xz yz)
+template <int AX>
+__device__ __forceinline__ void rot_sym(float c, float s, const float S[6], float O[6]) {
+  const float cc = c * c, ss = s * s, cs = c * s;
+  const float xx = S[0], yy = S[1], zz = S[2], xy = S[3], xz = S[4], yz = S[5];
+  if (AX == 0) {
+    O[0] = xx;
+    O[1] = cc * yy - 2.0f * cs * yz + ss * zz;
+    O[2] = ss * yy + 2.0f * cs * yz + cc * zz;
+    O[3] = c * xy - s * xz;
+    O[4] = s * xy + c * xz;
+    O[5] = cs * (yy - zz) + (cc - ss) * yz;
+  } else {
+    O[0] = cc * xx + 2.0f * cs * xz + ss * zz;
+    O[1] = yy;
+    O[2] = ss * xx - 2.0f * cs * xz + cc * zz;
+    O[3] = c * xy + s * yz;
+    O[4] = cs * (zz - xx) + (cc - ss) * xz;
+    O[5] = -s * xy + c * yz;
+  }
+}
+// O = R H R^T for a general 3x3 H (row-major)
+template <int AX>
+__device__ __forceinline__ void rot_gen(float c, float s, const float H[9], float O[9]) {
+  float T[9];
+#pragma unroll
+  for (int j = 0; j < 3; j++) {  // T = R H : rotate every column
+    const float col[3] = {H[j], H[3 + j], H[6 + j]};
+    float o[3];
+    rot_fwd<AX>(c, s, col, o);
+    T[j] = o[0]; T[3 + j] = o[1]; T[6 + j] = o[2];
+  }
+#pragma unroll
+  for (int i = 0; i < 3; i++) {  // O = T R^T : rotate every row
+    float o[3];
+    rot_fwd<AX>(c, s, &T[3 * i], o);
+    O[3 * i] = o[0]; O[3 * i + 1] = o[1]; O[3 * i + 2] = o[2];
+  }
+}
+__device__ __forceinline__ void symv(const float S[6], const float v[3], float o[3]) {
+  const float a = S[0] * v[0] + S[3] * v[1] + S[4] * v[2];
+  const float b = S[3] * v[0] + S[1] * v[1] + S[5] * v[2];
+  const float c = S[4] * v[0] + S[5] * v[1] + S[2] * v[2];
+  o[0] = a; o[1] = b; o[2] = c;
+}
+
+// sine / cosine of a joint angle
+__device__ __forceinline__ void joint_sincos(float a, float* s, float* c) {
+#ifdef ORR_FAST_TRIG
+  *s = __sinf(a); *c = __cosf(a);  // v_sin_f32 / v_cos_f32: ~1e-6 absolute error
+#else
+  sincosf(a, s, c);
+#endif
+}
+
 // transformations.quaternion_multiply(a, b): Hamilton product (pose3d.py:228-230)
 __device__ __forceinline__ void qmul(const float a[4], const float b[4], float o[4]) {
   float x1 = a[0], y1 = a[1], z1 = a[2], w1 = a[3], x0 = b[0], y0 = b[1], z0 = b[2], w0 = b[3];

@@ -19,29 +19,25 @@ using namespace orr;
 // ================================================================================================
 // load / store of the per-robot record
 // ================================================================================================
+__device__ static void refresh_mass(const DevModel& gm, Shared& S, int lane) {
+  // randomised mass properties (controllable_env_randomizer_from_config.py:193-222,309-335)
+  if (lane < 13) {
+    const int g = gm.group[lane];
+    const float mr = S.s[O(MASS_RATIO) + g], ir = S.s[O(INERTIA_RATIO) + g];
+    S.mass[lane] = gm.mass[lane] * mr;
+#pragma unroll
+    for (int k = 0; k < 6; k++) S.Ic[lane][k] = gm.inertia[lane][k] * ir + gm.inertia_pa[lane][k] * mr;
+  }
+}
+
 __device__ static void load_robot(const KParams& P, const float* rec, Shared& S, int lane) {
   for (int i = lane; i < kHead; i += 64) S.s[i] = rec[i];
   WSYNC();
-  const int type = geti(S, O(ROBOT_TYPE));
-  const float* mp = reinterpret_cast<const float*>(&P.tab->model[type]);
+  const DevModel& gm = P.tab->model[geti(S, O(ROBOT_TYPE))];
+  const float* mp = reinterpret_cast<const float*>(&gm.hot);
   float* dst = reinterpret_cast<float*>(&S.m);
-  for (int i = lane; i < (int)(sizeof(orr_model) / 4); i += 64) dst[i] = mp[i];
-  WSYNC();
-  if (lane < 12) {
-    int j = S.m.joint_of_motor[lane];
-    S.jdir[j] = S.m.motor_dir[lane];
-    S.joff[j] = S.m.motor_offset[lane];
-    S.motor_of_joint[j] = lane;
-  }
-  // randomised mass properties (controllable_env_randomizer_from_config.py:193-222,309-335)
-  if (lane < 13) {
-    int g = lane == 0 ? 0 : S.m.link_group[lane - 1];
-    float mr = S.s[O(MASS_RATIO) + g], ir = S.s[O(INERTIA_RATIO) + g];
-    S.mass[lane] = (lane == 0 ? S.m.base_mass : S.m.link_mass[lane - 1]) * mr;
-#pragma unroll
-    for (int k = 0; k < 6; k++)
-      S.Ic[lane][k] = lane == 0 ? S.m.base_inertia[k] * ir : S.m.link_inertia[lane - 1][k] * ir + S.m.link_inertia_pa[lane - 1][k] * mr;
-  }
+  for (int i = lane; i < kModelLdsWords; i += 64) dst[i] = mp[i];
+  refresh_mass(gm, S, lane);
   WSYNC();
 }
 
@@ -101,9 +97,8 @@ __device__ static void receive_obs(float* rec, Shared& S, int lane) {
 // physics sub-step (pybullet stepSimulation, quadruped_gym_env.py:223)
 // ================================================================================================
 
-// Cholesky factor of a 6x6 SPD matrix (row-major full storage), in place lower triangle; returns via L
+// Cholesky factor of a 6x6 SPD matrix (row-major full storage); L packed row-wise, (i,j) -> i(i+1)/2 + j
 __device__ __forceinline__ void chol6(const float A[36], float L[21], float invdiag[6]) {
-  // L packed row-wise: index (i,j) j<=i -> i*(i+1)/2 + j
 #pragma unroll
   for (int i = 0; i < 6; i++) {
 #pragma unroll
@@ -112,9 +107,9 @@ __device__ __forceinline__ void chol6(const float A[36], float L[21], float invd
 #pragma unroll
       for (int k = 0; k < j; k++) s -= L[i * (i + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
       if (i == j) {
-        float d = sqrtf(s);
-        L[i * (i + 1) / 2 + j] = d;
-        invdiag[i] = 1.0f / d;
+        const float rs = rsqrtf(s);
+        L[i * (i + 1) / 2 + j] = s * rs;
+        invdiag[i] = rs;
       } else {
         L[i * (i + 1) / 2 + j] = s * invdiag[j];
       }
@@ -139,170 +134,209 @@ __device__ __forceinline__ void chol6_solve(const float L[21], const float invdi
   }
 }
 
-// Articulated-body passes.  Lanes with the same (lane & 3) do the same leg; results are written by lanes 0..3.
+// ---- pass 1 for one link: velocities, velocity-product terms, bias force, world pose ----
+template <int AX>
+__device__ __forceinline__ void pass1_link(Shared& S, int j, bool wr, float wp[3], float vp[3], float Rwp[9], float owp[3]) {
+  const float r[3] = {S.m.joint_pos[j][0], S.m.joint_pos[j][1], S.m.joint_pos[j][2]};
+  const float a = S.m.jdir[j] * (S.s[O(Q) + j] - S.m.joff[j]);
+  const float ad = S.m.jdir[j] * S.s[O(QD) + j];
+  float sn, cs;
+  joint_sincos(a, &sn, &cs);
+  float t[3], w[3], v[3];
+  cross3(wp, r, t);
+  t[0] += vp[0]; t[1] += vp[1]; t[2] += vp[2];
+  rot_inv<AX>(cs, sn, wp, w);
+  rot_inv<AX>(cs, sn, t, v);
+  w[AX] += ad;
+  float cv[6];  // c = [w x (e ad); v x (e ad)]
+  if (AX == 0) { cv[0] = 0.0f; cv[1] = w[2] * ad; cv[2] = -w[1] * ad; cv[3] = 0.0f; cv[4] = v[2] * ad; cv[5] = -v[1] * ad; }
+  else { cv[0] = -w[2] * ad; cv[1] = 0.0f; cv[2] = w[0] * ad; cv[3] = -v[2] * ad; cv[4] = 0.0f; cv[5] = v[0] * ad; }
+  const float m = S.mass[j + 1];
+  const float com[3] = {S.m.link_com[j][0], S.m.link_com[j][1], S.m.link_com[j][2]};
+  float wxc[3], f[3], n[3], cxf[3], t1[3], t2[3], pA[6];
+  cross3(w, com, wxc);
+  f[0] = m * (v[0] + wxc[0]); f[1] = m * (v[1] + wxc[1]); f[2] = m * (v[2] + wxc[2]);
+  symv(S.Ic[j + 1], w, n);
+  cross3(com, f, cxf);
+  n[0] += cxf[0]; n[1] += cxf[1]; n[2] += cxf[2];
+  cross3(w, n, t1);
+  cross3(v, f, t2);
+  pA[0] = t1[0] + t2[0]; pA[1] = t1[1] + t2[1]; pA[2] = t1[2] + t2[2];
+  cross3(w, f, &pA[3]);
+  // forward kinematics: Rw = Rwp R, ow = owp + Rwp r
+  float Rw[9], ow[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const float p0 = Rwp[3 * i], p1 = Rwp[3 * i + 1], p2 = Rwp[3 * i + 2];
+    if (AX == 0) { Rw[3 * i] = p0; Rw[3 * i + 1] = cs * p1 + sn * p2; Rw[3 * i + 2] = -sn * p1 + cs * p2; }
+    else { Rw[3 * i] = cs * p0 - sn * p2; Rw[3 * i + 1] = p1; Rw[3 * i + 2] = sn * p0 + cs * p2; }
+  }
+  mv3(Rwp, r, ow);
+  ow[0] += owp[0]; ow[1] += owp[1]; ow[2] += owp[2];
+  if (wr) {
+    LinkCache& L = S.lc[j];
+    L.c = cs; L.s = sn;
+#pragma unroll
+    for (int i = 0; i < 9; i++) L.Rw[i] = Rw[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) L.ow[i] = ow[i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) { L.cv[i] = cv[i]; L.pA[i] = pA[i]; }
+  }
+#pragma unroll
+  for (int i = 0; i < 3; i++) { wp[i] = w[i]; vp[i] = v[i]; owp[i] = ow[i]; }
+#pragma unroll
+  for (int i = 0; i < 9; i++) Rwp[i] = Rw[i];
+}
+
+// ---- pass 2 for one link: articulated inertia / bias, eliminated along the joint, expressed in the parent ----
+// (Iacc, Hacc, Macc, pacc): contribution of the child subtree on entry, of this subtree (parent coords) on exit.
+// I and M symmetric (xx yy zz xy xz yz), H general row-major; 6x6 = [[I, H], [H^T, M]].
+template <int AX>
+__device__ __forceinline__ void pass2_link(Shared& S, int j, bool wr, float Iacc[6], float Hacc[9], float Macc[6], float pacc[6]) {
+  LinkCache& L = S.lc[j];
+  const float m = S.mass[j + 1];
+  const float c0 = S.m.link_com[j][0], c1 = S.m.link_com[j][1], c2 = S.m.link_com[j][2];
+  const float cc = c0 * c0 + c1 * c1 + c2 * c2;
+  float I[6], H[9], M[6], pA[6];
+  I[0] = S.Ic[j + 1][0] + m * (cc - c0 * c0) + Iacc[0];
+  I[1] = S.Ic[j + 1][1] + m * (cc - c1 * c1) + Iacc[1];
+  I[2] = S.Ic[j + 1][2] + m * (cc - c2 * c2) + Iacc[2];
+  I[3] = S.Ic[j + 1][3] - m * c0 * c1 + Iacc[3];
+  I[4] = S.Ic[j + 1][4] - m * c0 * c2 + Iacc[4];
+  I[5] = S.Ic[j + 1][5] - m * c1 * c2 + Iacc[5];
+  M[0] = m + Macc[0]; M[1] = m + Macc[1]; M[2] = m + Macc[2]; M[3] = Macc[3]; M[4] = Macc[4]; M[5] = Macc[5];
+  H[0] = Hacc[0]; H[1] = -m * c2 + Hacc[1]; H[2] = m * c1 + Hacc[2];
+  H[3] = m * c2 + Hacc[3]; H[4] = Hacc[4]; H[5] = -m * c0 + Hacc[5];
+  H[6] = -m * c1 + Hacc[6]; H[7] = m * c0 + Hacc[7]; H[8] = Hacc[8];
+#pragma unroll
+  for (int i = 0; i < 6; i++) pA[i] = L.pA[i] + pacc[i];
+  // U = IA S with S = e_AX: column AX of I on top, row AX of H below
+  float Ut[3], Ub[3];
+  if (AX == 0) { Ut[0] = I[0]; Ut[1] = I[3]; Ut[2] = I[4]; Ub[0] = H[0]; Ub[1] = H[1]; Ub[2] = H[2]; }
+  else { Ut[0] = I[3]; Ut[1] = I[1]; Ut[2] = I[5]; Ub[0] = H[3]; Ub[1] = H[4]; Ub[2] = H[5]; }
+  const float invD = 1.0f / Ut[AX];
+  const float u = S.tau[j] - pA[AX];
+  const float uD = u * invD;
+  if (wr) {
+    L.U[0] = Ut[0]; L.U[1] = Ut[1]; L.U[2] = Ut[2]; L.U[3] = Ub[0]; L.U[4] = Ub[1]; L.U[5] = Ub[2];
+    L.invD = invD; L.u = u;
+  }
+  // Ia = IA - U U^T / D  (row / column AX of I and row AX of H vanish identically)
+  {
+    const float a0 = Ut[0] * invD, a1 = Ut[1] * invD, a2 = Ut[2] * invD;
+    I[0] -= a0 * Ut[0]; I[1] -= a1 * Ut[1]; I[2] -= a2 * Ut[2]; I[3] -= a0 * Ut[1]; I[4] -= a0 * Ut[2]; I[5] -= a1 * Ut[2];
+    H[0] -= a0 * Ub[0]; H[1] -= a0 * Ub[1]; H[2] -= a0 * Ub[2];
+    H[3] -= a1 * Ub[0]; H[4] -= a1 * Ub[1]; H[5] -= a1 * Ub[2];
+    H[6] -= a2 * Ub[0]; H[7] -= a2 * Ub[1]; H[8] -= a2 * Ub[2];
+    const float b0 = Ub[0] * invD, b1 = Ub[1] * invD, b2 = Ub[2] * invD;
+    M[0] -= b0 * Ub[0]; M[1] -= b1 * Ub[1]; M[2] -= b2 * Ub[2]; M[3] -= b0 * Ub[1]; M[4] -= b0 * Ub[2]; M[5] -= b1 * Ub[2];
+    if (AX == 0) { I[0] = 0.0f; I[3] = 0.0f; I[4] = 0.0f; H[0] = 0.0f; H[1] = 0.0f; H[2] = 0.0f; }
+    else { I[1] = 0.0f; I[3] = 0.0f; I[5] = 0.0f; H[3] = 0.0f; H[4] = 0.0f; H[5] = 0.0f; }
+  }
+  // pa = pA + Ia c + U u / D
+  float pat[3], pab[3], t1[3], t2[3], t3[3];
+  symv(I, &L.cv[0], t1);
+  mv3(H, &L.cv[3], t2);
+#pragma unroll
+  for (int i = 0; i < 3; i++) pat[i] = pA[i] + t1[i] + t2[i] + Ut[i] * uD;
+  mtv3(H, &L.cv[0], t1);
+  symv(M, &L.cv[3], t3);
+#pragma unroll
+  for (int i = 0; i < 3; i++) pab[i] = pA[3 + i] + t1[i] + t3[i] + Ub[i] * uD;
+  // rotate into the parent orientation, then shift by r
+  const float cs = L.c, sn = L.s;
+  const float r[3] = {S.m.joint_pos[j][0], S.m.joint_pos[j][1], S.m.joint_pos[j][2]};
+  float Ip[6], Hp[9], Mp[6];
+  rot_sym<AX>(cs, sn, I, Ip);
+  rot_gen<AX>(cs, sn, H, Hp);
+  rot_sym<AX>(cs, sn, M, Mp);
+  // K = Hp + rx Mp
+  float Mm[9], K[9];
+  sym_to_m3(Mp, Mm);
+  skewmul(r, Mm, K);
+#pragma unroll
+  for (int i = 0; i < 9; i++) K[i] += Hp[i];
+  // Ipar = Ip + rx Hp^T - K rx   (symmetric: only the 6 unique entries)
+  {
+    // (rx Hp^T)[a][b] = sum_k rx[a][k] Hp[b][k];  (K rx)[a][b] = sum_k K[a][k] rx[k][b]
+    const float r0 = r[0], r1 = r[1], r2 = r[2];
+    // rows of rx: [0,-r2,r1], [r2,0,-r0], [-r1,r0,0]
+#define RXHT(a, b) ((a) == 0 ? (-r2 * Hp[3 * (b) + 1] + r1 * Hp[3 * (b) + 2]) : ((a) == 1 ? (r2 * Hp[3 * (b)] - r0 * Hp[3 * (b) + 2]) : (-r1 * Hp[3 * (b)] + r0 * Hp[3 * (b) + 1])))
+#define KRX(a, b) ((b) == 0 ? (K[3 * (a) + 1] * r2 - K[3 * (a) + 2] * r1) : ((b) == 1 ? (-K[3 * (a)] * r2 + K[3 * (a) + 2] * r0) : (K[3 * (a)] * r1 - K[3 * (a) + 1] * r0)))
+    Iacc[0] = Ip[0] + RXHT(0, 0) - KRX(0, 0);
+    Iacc[1] = Ip[1] + RXHT(1, 1) - KRX(1, 1);
+    Iacc[2] = Ip[2] + RXHT(2, 2) - KRX(2, 2);
+    Iacc[3] = Ip[3] + 0.5f * (RXHT(0, 1) - KRX(0, 1) + RXHT(1, 0) - KRX(1, 0));
+    Iacc[4] = Ip[4] + 0.5f * (RXHT(0, 2) - KRX(0, 2) + RXHT(2, 0) - KRX(2, 0));
+    Iacc[5] = Ip[5] + 0.5f * (RXHT(1, 2) - KRX(1, 2) + RXHT(2, 1) - KRX(2, 1));
+#undef RXHT
+#undef KRX
+  }
+#pragma unroll
+  for (int i = 0; i < 9; i++) Hacc[i] = K[i];
+#pragma unroll
+  for (int i = 0; i < 6; i++) Macc[i] = Mp[i];
+  float fp[3], np_[3], rxf[3];
+  rot_fwd<AX>(cs, sn, pab, fp);
+  rot_fwd<AX>(cs, sn, pat, np_);
+  cross3(r, fp, rxf);
+  pacc[0] = np_[0] + rxf[0]; pacc[1] = np_[1] + rxf[1]; pacc[2] = np_[2] + rxf[2];
+  pacc[3] = fp[0]; pacc[4] = fp[1]; pacc[5] = fp[2];
+}
+
+// ---- pass 3 for one link: joint acceleration ----
+template <int AX>
+__device__ __forceinline__ void pass3_link(Shared& S, int j, bool wr, float ap[6]) {
+  const LinkCache& L = S.lc[j];
+  const float r[3] = {S.m.joint_pos[j][0], S.m.joint_pos[j][1], S.m.joint_pos[j][2]};
+  float t[3], at[3], ab[3];
+  cross3(&ap[0], r, t);
+  t[0] += ap[3]; t[1] += ap[4]; t[2] += ap[5];
+  rot_inv<AX>(L.c, L.s, &ap[0], at);
+  rot_inv<AX>(L.c, L.s, t, ab);
+#pragma unroll
+  for (int i = 0; i < 3; i++) { at[i] += L.cv[i]; ab[i] += L.cv[3 + i]; }
+  const float Ud = L.U[0] * at[0] + L.U[1] * at[1] + L.U[2] * at[2] + L.U[3] * ab[0] + L.U[4] * ab[1] + L.U[5] * ab[2];
+  const float qdd = (L.u - Ud) * L.invD;
+  at[AX] += qdd;
+  if (wr) S.acc[6 + j] = qdd;
+#pragma unroll
+  for (int i = 0; i < 3; i++) { ap[i] = at[i]; ap[3 + i] = ab[i]; }
+}
+
+// Articulated-body algorithm.  Lanes with the same (lane & 3) do the same leg; results are written by lanes 0..3.
 __device__ static void aba_legs(const KParams& P, Shared& S, int lane) {
   const int leg = lane & 3;
-  float qrel[4], Rb[9], wb[3], vb[3];
+  const bool wr = lane < 4;
+  float Rb[9], wb[3], vb[3];
   {
-    float qi[4];
+    float qi[4], qrel[4];
     qinv(S.m.init_quat, qi);
     qmul(&S.s[O(QUAT)], qi, qrel);
+    q_to_mat(qrel, Rb);
   }
-  q_to_mat(qrel, Rb);
   mtv3(Rb, &S.s[O(ANGVEL)], wb);
   mtv3(Rb, &S.s[O(LINVEL)], vb);
   if (lane == 0) {
 #pragma unroll
     for (int i = 0; i < 9; i++) S.Rb[i] = Rb[i];
   }
-
-  // ---------------- pass 1: velocities, bias terms, world poses ----------------
-  float Rk[3][9], ck[3][6], pAk[3][6];
   {
     float wp[3] = {wb[0], wb[1], wb[2]}, vp[3] = {vb[0], vb[1], vb[2]};
     float Rwp[9], owp[3] = {S.s[O(POS)], S.s[O(POS) + 1], S.s[O(POS) + 2]};
 #pragma unroll
     for (int i = 0; i < 9; i++) Rwp[i] = Rb[i];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      const int j = 3 * leg + k;
-      const float ax[3] = {S.m.joint_axis[j][0], S.m.joint_axis[j][1], S.m.joint_axis[j][2]};
-      const float r[3] = {S.m.joint_pos[j][0], S.m.joint_pos[j][1], S.m.joint_pos[j][2]};
-      const float a = S.jdir[j] * (S.s[O(Q) + j] - S.joff[j]);
-      const float ad = S.jdir[j] * S.s[O(QD) + j];
-      rodrigues(ax, a, Rk[k]);
-      float t[3], w[3], v[3];
-      cross3(wp, r, t);
-      t[0] += vp[0]; t[1] += vp[1]; t[2] += vp[2];
-      mtv3(Rk[k], wp, w);
-      mtv3(Rk[k], t, v);
-      const float sq[3] = {ax[0] * ad, ax[1] * ad, ax[2] * ad};
-      w[0] += sq[0]; w[1] += sq[1]; w[2] += sq[2];
-      cross3(w, sq, &ck[k][0]);
-      cross3(v, sq, &ck[k][3]);
-      const float m = S.mass[j + 1];
-      const float com[3] = {S.m.link_com[j][0], S.m.link_com[j][1], S.m.link_com[j][2]};
-      float wxc[3], f[3], n[3], cxf[3], Icm[9];
-      cross3(w, com, wxc);
-      f[0] = m * (v[0] + wxc[0]); f[1] = m * (v[1] + wxc[1]); f[2] = m * (v[2] + wxc[2]);
-      sym_to_m3(S.Ic[j + 1], Icm);
-      mv3(Icm, w, n);
-      cross3(com, f, cxf);
-      n[0] += cxf[0]; n[1] += cxf[1]; n[2] += cxf[2];
-      float t1[3], t2[3];
-      cross3(w, n, t1);
-      cross3(v, f, t2);
-      pAk[k][0] = t1[0] + t2[0]; pAk[k][1] = t1[1] + t2[1]; pAk[k][2] = t1[2] + t2[2];
-      cross3(w, f, &pAk[k][3]);
-      // forward kinematics
-      float Rw[9], ow[3];
-      mm3(Rwp, Rk[k], Rw);
-      mv3(Rwp, r, ow);
-      ow[0] += owp[0]; ow[1] += owp[1]; ow[2] += owp[2];
-      if (lane < 4) {
-        LinkCache& L = S.lc[j];
-#pragma unroll
-        for (int i = 0; i < 9; i++) { L.R[i] = Rk[k][i]; L.Rw[i] = Rw[i]; }
-#pragma unroll
-        for (int i = 0; i < 3; i++) L.ow[i] = ow[i];
-      }
-#pragma unroll
-      for (int i = 0; i < 3; i++) { wp[i] = w[i]; vp[i] = v[i]; owp[i] = ow[i]; }
-#pragma unroll
-      for (int i = 0; i < 9; i++) Rwp[i] = Rw[i];
-    }
+    pass1_link<0>(S, 3 * leg, wr, wp, vp, Rwp, owp);
+    pass1_link<1>(S, 3 * leg + 1, wr, wp, vp, Rwp, owp);
+    pass1_link<1>(S, 3 * leg + 2, wr, wp, vp, Rwp, owp);
   }
-
-  // ---------------- pass 2: articulated inertias, inward ----------------
   float Iacc[6] = {0, 0, 0, 0, 0, 0}, Hacc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Macc[6] = {0, 0, 0, 0, 0, 0};
   float pacc[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-  for (int k = 2; k >= 0; k--) {
-    const int j = 3 * leg + k;
-    const float ax[3] = {S.m.joint_axis[j][0], S.m.joint_axis[j][1], S.m.joint_axis[j][2]};
-    const float r[3] = {S.m.joint_pos[j][0], S.m.joint_pos[j][1], S.m.joint_pos[j][2]};
-    const float m = S.mass[j + 1];
-    const float c0 = S.m.link_com[j][0], c1 = S.m.link_com[j][1], c2 = S.m.link_com[j][2];
-    const float cc = c0 * c0 + c1 * c1 + c2 * c2;
-    float I[9], H[9], M[9];
-    {
-      float Is[6];
-      Is[0] = S.Ic[j + 1][0] + m * (cc - c0 * c0) + Iacc[0];
-      Is[1] = S.Ic[j + 1][1] + m * (cc - c1 * c1) + Iacc[1];
-      Is[2] = S.Ic[j + 1][2] + m * (cc - c2 * c2) + Iacc[2];
-      Is[3] = S.Ic[j + 1][3] - m * c0 * c1 + Iacc[3];
-      Is[4] = S.Ic[j + 1][4] - m * c0 * c2 + Iacc[4];
-      Is[5] = S.Ic[j + 1][5] - m * c1 * c2 + Iacc[5];
-      sym_to_m3(Is, I);
-      float Ms[6] = {m + Macc[0], m + Macc[1], m + Macc[2], Macc[3], Macc[4], Macc[5]};
-      sym_to_m3(Ms, M);
-      H[0] = Hacc[0]; H[1] = -m * c2 + Hacc[1]; H[2] = m * c1 + Hacc[2];
-      H[3] = m * c2 + Hacc[3]; H[4] = Hacc[4]; H[5] = -m * c0 + Hacc[5];
-      H[6] = -m * c1 + Hacc[6]; H[7] = m * c0 + Hacc[7]; H[8] = Hacc[8];
-    }
-    float pA[6];
-#pragma unroll
-    for (int i = 0; i < 6; i++) pA[i] = pAk[k][i] + pacc[i];
-    float Ut[3], Ub[3];
-    mv3(I, ax, Ut);
-    mtv3(H, ax, Ub);
-    const float D = dot3(ax, Ut), invD = 1.0f / D;
-    const float u = S.tau[j] - dot3(ax, pA);
-    const float uD = u * invD;
-    if (lane < 4) {
-      LinkCache& L = S.lc[j];
-      L.U[0] = Ut[0]; L.U[1] = Ut[1]; L.U[2] = Ut[2]; L.U[3] = Ub[0]; L.U[4] = Ub[1]; L.U[5] = Ub[2];
-      L.invD = invD; L.u = u;
-    }
-#pragma unroll
-    for (int a_ = 0; a_ < 3; a_++)
-#pragma unroll
-      for (int b_ = 0; b_ < 3; b_++) {
-        I[a_ * 3 + b_] -= Ut[a_] * Ut[b_] * invD;
-        H[a_ * 3 + b_] -= Ut[a_] * Ub[b_] * invD;
-        M[a_ * 3 + b_] -= Ub[a_] * Ub[b_] * invD;
-      }
-    // pa = pA + Ia c + U u / D
-    float pat[3], pab[3], t1[3], t2[3];
-    mv3(I, &ck[k][0], t1);
-    mv3(H, &ck[k][3], t2);
-#pragma unroll
-    for (int i = 0; i < 3; i++) pat[i] = pA[i] + t1[i] + t2[i] + Ut[i] * uD;
-    mtv3(H, &ck[k][0], t1);
-    mv3(M, &ck[k][3], t2);
-#pragma unroll
-    for (int i = 0; i < 3; i++) pab[i] = pA[3 + i] + t1[i] + t2[i] + Ub[i] * uD;
-    // express in the parent frame: rotate by R (child -> parent), then shift by r
-    float Ip[9], Hp[9], Mp[9], T[9];
-    mm3(Rk[k], I, T); mmt3(T, Rk[k], Ip);
-    mm3(Rk[k], H, T); mmt3(T, Rk[k], Hp);
-    mm3(Rk[k], M, T); mmt3(T, Rk[k], Mp);
-    float K[9], rxM[9], rxHt[9], Krx[9], Hpt[9];
-    skewmul(r, Mp, rxM);
-#pragma unroll
-    for (int i = 0; i < 9; i++) K[i] = Hp[i] + rxM[i];
-#pragma unroll
-    for (int a_ = 0; a_ < 3; a_++)
-#pragma unroll
-      for (int b_ = 0; b_ < 3; b_++) Hpt[a_ * 3 + b_] = Hp[b_ * 3 + a_];
-    skewmul(r, Hpt, rxHt);
-    mulskew(K, r, Krx);
-#pragma unroll
-    for (int i = 0; i < 9; i++) Ip[i] = Ip[i] + rxHt[i] - Krx[i];
-    Iacc[0] = Ip[0]; Iacc[1] = Ip[4]; Iacc[2] = Ip[8];
-    Iacc[3] = 0.5f * (Ip[1] + Ip[3]); Iacc[4] = 0.5f * (Ip[2] + Ip[6]); Iacc[5] = 0.5f * (Ip[5] + Ip[7]);
-#pragma unroll
-    for (int i = 0; i < 9; i++) Hacc[i] = K[i];
-    Macc[0] = Mp[0]; Macc[1] = Mp[4]; Macc[2] = Mp[8];
-    Macc[3] = 0.5f * (Mp[1] + Mp[3]); Macc[4] = 0.5f * (Mp[2] + Mp[6]); Macc[5] = 0.5f * (Mp[5] + Mp[7]);
-    float fp[3], np_[3], rxf[3];
-    mv3(Rk[k], pab, fp);
-    mv3(Rk[k], pat, np_);
-    cross3(r, fp, rxf);
-    pacc[0] = np_[0] + rxf[0]; pacc[1] = np_[1] + rxf[1]; pacc[2] = np_[2] + rxf[2];
-    pacc[3] = fp[0]; pacc[4] = fp[1]; pacc[5] = fp[2];
-  }
-  // ---------------- base: sum the four leg contributions (butterfly over lane bits 0,1) ----------------
+  pass2_link<1>(S, 3 * leg + 2, wr, Iacc, Hacc, Macc, pacc);
+  pass2_link<1>(S, 3 * leg + 1, wr, Iacc, Hacc, Macc, pacc);
+  pass2_link<0>(S, 3 * leg, wr, Iacc, Hacc, Macc, pacc);
+  // base: sum the four leg contributions (butterfly over lane bits 0, 1)
 #pragma unroll
   for (int i = 0; i < 6; i++) {
     Iacc[i] += __shfl_xor(Iacc[i], 1); Iacc[i] += __shfl_xor(Iacc[i], 2);
@@ -311,22 +345,20 @@ __device__ static void aba_legs(const KParams& P, Shared& S, int lane) {
   }
 #pragma unroll
   for (int i = 0; i < 9; i++) { Hacc[i] += __shfl_xor(Hacc[i], 1); Hacc[i] += __shfl_xor(Hacc[i], 2); }
-  float A6[36], pA0[6];
+  float a0[6];
   {
+    float A6[36], pA0[6];
     const float m0 = S.mass[0];
-    float Ib[9], Is[6];
-#pragma unroll
-    for (int i = 0; i < 6; i++) Is[i] = S.Ic[0][i];
-    sym_to_m3(Is, Ib);
     float n[3], f[3] = {m0 * vb[0], m0 * vb[1], m0 * vb[2]}, t1[3], t2[3];
-    mv3(Ib, wb, n);
+    symv(S.Ic[0], wb, n);
     cross3(wb, n, t1);
     cross3(wb, f, t2);
     // Bullet base damping (btMultiBody ABA): torque k_a I w, force k_l m v on the bias side
     const float kl = S.s[O(BASE_DAMPING)], ka = S.s[O(BASE_DAMPING) + 1];
 #pragma unroll
     for (int i = 0; i < 3; i++) { pA0[i] = t1[i] + ka * n[i] + pacc[i]; pA0[3 + i] = t2[i] + kl * f[i] + pacc[3 + i]; }
-    float Im[9], Mm[9];
+    float Ib[9], Im[9], Mm[9];
+    sym_to_m3(S.Ic[0], Ib);
     sym_to_m3(Iacc, Im);
     sym_to_m3(Macc, Mm);
 #pragma unroll
@@ -338,11 +370,8 @@ __device__ static void aba_legs(const KParams& P, Shared& S, int lane) {
         A6[(3 + a_) * 6 + b_] = Hacc[b_ * 3 + a_];
         A6[(3 + a_) * 6 + 3 + b_] = Mm[a_ * 3 + b_] + (a_ == b_ ? m0 : 0.0f);
       }
-  }
-  float Lc[21], idg[6], a0[6];
-  chol6(A6, Lc, idg);
-  {
-    float nb[6];
+    float Lc[21], idg[6], nb[6];
+    chol6(A6, Lc, idg);
 #pragma unroll
     for (int i = 0; i < 6; i++) nb[i] = -pA0[i];
     chol6_solve(Lc, idg, nb, a0);
@@ -357,34 +386,11 @@ __device__ static void aba_legs(const KParams& P, Shared& S, int lane) {
       for (int i = 0; i < 6; i++) S.IA0inv[i * 6 + col] = x[i];
     }
   }
-  // ---------------- pass 3: accelerations, outward ----------------
   {
     float ap[6] = {a0[0], a0[1], a0[2], a0[3], a0[4], a0[5]};
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      const int j = 3 * leg + k;
-      const float ax[3] = {S.m.joint_axis[j][0], S.m.joint_axis[j][1], S.m.joint_axis[j][2]};
-      const float r[3] = {S.m.joint_pos[j][0], S.m.joint_pos[j][1], S.m.joint_pos[j][2]};
-      const LinkCache& L = S.lc[j];  // U / invD / u written by this very lane (or its replica) above
-      float t[3], at[3], ab[3];
-      cross3(&ap[0], r, t);
-      t[0] += ap[3]; t[1] += ap[4]; t[2] += ap[5];
-      mtv3(Rk[k], &ap[0], at);
-      mtv3(Rk[k], t, ab);
-#pragma unroll
-      for (int i = 0; i < 3; i++) { at[i] += ck[k][i]; ab[i] += ck[k][3 + i]; }
-      // U, invD, u recomputed values are identical in replica lanes; read own copies from registers is
-      // not possible across the pass-2 loop, so take them from LDS (same wave, ordered by WSYNC below)
-      float qdd;
-      {
-        float Ud = L.U[0] * at[0] + L.U[1] * at[1] + L.U[2] * at[2] + L.U[3] * ab[0] + L.U[4] * ab[1] + L.U[5] * ab[2];
-        qdd = (L.u - Ud) * L.invD;
-      }
-      at[0] += ax[0] * qdd; at[1] += ax[1] * qdd; at[2] += ax[2] * qdd;
-      if (lane < 4) S.acc[6 + j] = qdd;
-#pragma unroll
-      for (int i = 0; i < 3; i++) { ap[i] = at[i]; ap[3 + i] = ab[i]; }
-    }
+    pass3_link<0>(S, 3 * leg, wr, ap);
+    pass3_link<1>(S, 3 * leg + 1, wr, ap);
+    pass3_link<1>(S, 3 * leg + 2, wr, ap);
   }
   if (lane == 0) {
     // world-frame base accelerations (Bullet: vdot = R (a_lin + w x v)); gravity = uniform-field offset
@@ -398,34 +404,61 @@ __device__ static void aba_legs(const KParams& P, Shared& S, int lane) {
   }
 }
 
+// impulse response helpers (btMultiBody::calcAccelerationDeltasMultiDof), one link each
+template <int AX>
+__device__ __forceinline__ void delta_in(const Shared& S, int j, float jl, float pA[6], float& ud) {
+  const LinkCache& L = S.lc[j];
+  ud = jl - pA[AX];
+  const float sc = ud * L.invD;
+  const float pat[3] = {pA[0] + L.U[0] * sc, pA[1] + L.U[1] * sc, pA[2] + L.U[2] * sc};
+  const float pab[3] = {pA[3] + L.U[3] * sc, pA[4] + L.U[4] * sc, pA[5] + L.U[5] * sc};
+  float fp[3], np_[3], rxf[3];
+  rot_fwd<AX>(L.c, L.s, pab, fp);
+  rot_fwd<AX>(L.c, L.s, pat, np_);
+  cross3(S.m.joint_pos[j], fp, rxf);
+  pA[0] = np_[0] + rxf[0]; pA[1] = np_[1] + rxf[1]; pA[2] = np_[2] + rxf[2];
+  pA[3] = fp[0]; pA[4] = fp[1]; pA[5] = fp[2];
+}
+template <int AX>
+__device__ __forceinline__ float delta_out(const Shared& S, int j, float ud, float ap[6]) {
+  const LinkCache& L = S.lc[j];
+  float t[3], at[3], ab[3];
+  cross3(&ap[0], S.m.joint_pos[j], t);
+  t[0] += ap[3]; t[1] += ap[4]; t[2] += ap[5];
+  rot_inv<AX>(L.c, L.s, &ap[0], at);
+  rot_inv<AX>(L.c, L.s, t, ab);
+  const float Ud = L.U[0] * at[0] + L.U[1] * at[1] + L.U[2] * at[2] + L.U[3] * ab[0] + L.U[4] * ab[1] + L.U[5] * ab[2];
+  const float qdd = (ud - Ud) * L.invD;
+  at[AX] += qdd;
+  ap[0] = at[0]; ap[1] = at[1]; ap[2] = at[2]; ap[3] = ab[0]; ap[4] = ab[1]; ap[5] = ab[2];
+  return qdd;
+}
+
 // One physics sub-step.  Returns the fall-proxy flag (wave-uniform) when want_fall.
 __device__ static int physics_substep(const KParams& P, Shared& S, int lane, bool want_fall) {
   const orr_config& cfg = P.cfg;
   const float dt = cfg.sim_dt;
-  // pass-3 of aba_legs reads U / invD / u that pass 2 wrote to LDS from the same lanes (lanes >= 4
-  // read what lanes 0..3 wrote): one barrier inside would be needed for lanes >= 4 only; they do not
-  // write anything, so their (possibly stale) values are harmless.
   aba_legs(P, S, lane);
   WSYNC();
   if (lane < 18) {
-    float u = lane < 3 ? S.s[O(ANGVEL) + lane] : (lane < 6 ? S.s[O(LINVEL) + lane - 3] : S.jdir[lane - 6] * S.s[O(QD) + lane - 6]);
+    float u = lane < 3 ? S.s[O(ANGVEL) + lane] : (lane < 6 ? S.s[O(LINVEL) + lane - 3] : S.m.jdir[lane - 6] * S.s[O(QD) + lane - 6]);
     S.ustar[lane] = u + dt * S.acc[lane];
   }
   int fall = 0;
   if (want_fall) {  // termination-only collision proxies (imitation_task.py:536-546)
     bool hit = false;
-    if (lane < S.m.num_fall_proxies) {
-      int b = S.m.fall_body[lane];
+    if (lane < S.m.num_fall) {
+      const int b = S.m.fall_body[lane];
       const float* Rw = b == 0 ? S.Rb : S.lc[b - 1].Rw;
-      float oz = b == 0 ? S.s[O(POS) + 2] : S.lc[b - 1].ow[2];
-      float wz = Rw[6] * S.m.fall_pos[lane][0] + Rw[7] * S.m.fall_pos[lane][1] + Rw[8] * S.m.fall_pos[lane][2];
+      const float oz = b == 0 ? S.s[O(POS) + 2] : S.lc[b - 1].ow[2];
+      const float wz = Rw[6] * S.m.fall_pos[lane][0] + Rw[7] * S.m.fall_pos[lane][1] + Rw[8] * S.m.fall_pos[lane][2];
       hit = (oz + wz - S.m.fall_radius[lane]) < cfg.contact_margin;
     }
     fall = __ballot(hit) != 0ull;
   }
   WSYNC();
 
-  // ---------------- constraint rows: one per lane (slot order = solve order) ----------------
+  // ---------------- constraint rows: one per lane; lane index = row slot = solve order ----------------
   //  0..3   knee joint-friction motors (minitaur.py:1063-1070)
   //  4..15  joint limits (joint j = lane-4; at most one side can be within limit_activation)
   //  16..19 toe contact normals, 20..27 pyramid friction (leg = (lane-20)/2, t1 = +x, t2 = +y)
@@ -435,31 +468,30 @@ __device__ static int physics_substep(const KParams& P, Shared& S, int lane, boo
   float rhs = 0.0f, lo = 0.0f, hi = 0.0f, mu = 0.0f;
   if (lane < 4) {
     leg = lane;
-    float fr = S.s[O(KNEE_FRICTION) + leg];
+    const float fr = S.s[O(KNEE_FRICTION) + leg];
     active = fr > 0.0f;
     jl[2] = 1.0f;
     lo = -fr * dt; hi = fr * dt;
     rhs = -S.ustar[6 + 3 * leg + 2];
   } else if (lane < 16) {
-    int j = lane - 4;
+    const int j = lane - 4;
     leg = j / 3;
-    int kk = j - 3 * leg;
-    float a = S.jdir[j] * (S.s[O(Q) + j] - S.joff[j]);
-    float pen_lo = a - S.m.joint_lo[j], pen_hi = S.m.joint_hi[j] - a;
-    bool use_lo = pen_lo < cfg.limit_activation;
-    bool use_hi = (!use_lo) && pen_hi < cfg.limit_activation;
+    const int kk = j - 3 * leg;
+    const float a = S.m.jdir[j] * (S.s[O(Q) + j] - S.m.joff[j]);
+    const float pen_lo = a - S.m.joint_lo[j], pen_hi = S.m.joint_hi[j] - a;
+    const bool use_lo = pen_lo < cfg.limit_activation;
+    const bool use_hi = (!use_lo) && pen_hi < cfg.limit_activation;
     active = use_lo || use_hi;
-    float sgn = use_lo ? 1.0f : -1.0f, pen = use_lo ? pen_lo : pen_hi;
+    const float sgn = use_lo ? 1.0f : -1.0f, pen = use_lo ? pen_lo : pen_hi;
     jl[0] = kk == 0 ? sgn : 0.0f; jl[1] = kk == 1 ? sgn : 0.0f; jl[2] = kk == 2 ? sgn : 0.0f;
-    float rel = sgn * S.ustar[6 + j];
+    const float rel = sgn * S.ustar[6 + j];
     lo = 0.0f; hi = 1e30f;
     rhs = pen > 0.0f ? -rel - pen / dt : -rel - pen * cfg.contact_erp / dt;
   } else if (lane < 28) {
     int d;
     if (lane < 20) { leg = lane - 16; d = 0; }
     else { leg = (lane - 20) >> 1; d = 1 + ((lane - 20) & 1); }
-    const int jb = 3 * leg + 2;
-    const LinkCache& Lb = S.lc[jb];
+    const LinkCache& Lb = S.lc[3 * leg + 2];
     float cw[3];
     mv3(Lb.Rw, S.m.toe_pos[leg], cw);
     cw[0] += Lb.ow[0]; cw[1] += Lb.ow[1]; cw[2] += Lb.ow[2];
@@ -474,8 +506,9 @@ __device__ static int physics_substep(const KParams& P, Shared& S, int lane, boo
 #pragma unroll
     for (int k = 0; k < 3; k++) {
       const LinkCache& L = S.lc[3 * leg + k];
-      float axw[3], cr[3];
-      mv3(L.Rw, S.m.joint_axis[3 * leg + k], axw);
+      const int ax = k == 0 ? 0 : 1;  // world joint axis = column ax of Rw
+      const float axw[3] = {L.Rw[ax], L.Rw[3 + ax], L.Rw[6 + ax]};
+      float cr[3];
       rr[0] = Pw[0] - L.ow[0]; rr[1] = Pw[1] - L.ow[1]; rr[2] = Pw[2] - L.ow[2];
       cross3(axw, rr, cr);
       jl[k] = dot3(dir, cr);
@@ -492,29 +525,15 @@ __device__ static int physics_substep(const KParams& P, Shared& S, int lane, boo
     }
   }
   const unsigned long long mask = __ballot(active);
-  const int nrows = __popcll(mask);
-  const int dense = __popcll(mask & ((1ull << lane) - 1ull));
 
-  // ---------------- impulse response M^-1 J^T (btMultiBody::calcAccelerationDeltasMultiDof) ----------------
-  float mj[6], mq[12], diag = 0.0f;
+  // ---------------- impulse response M^-1 J^T ----------------
+  float diag = 0.0f;
   {
-    // inward over the row's own leg
-    float pA[6] = {0, 0, 0, 0, 0, 0}, ud[3];
-#pragma unroll
-    for (int k = 2; k >= 0; k--) {
-      const int j = 3 * leg + k;
-      const LinkCache& L = S.lc[j];
-      ud[k] = jl[k] - dot3(S.m.joint_axis[j], pA);
-      const float s = ud[k] * L.invD;
-      float pat[3] = {pA[0] + L.U[0] * s, pA[1] + L.U[1] * s, pA[2] + L.U[2] * s};
-      float pab[3] = {pA[3] + L.U[3] * s, pA[4] + L.U[4] * s, pA[5] + L.U[5] * s};
-      float fp[3], np_[3], rxf[3];
-      mv3(L.R, pab, fp);
-      mv3(L.R, pat, np_);
-      cross3(S.m.joint_pos[j], fp, rxf);
-      pA[0] = np_[0] + rxf[0]; pA[1] = np_[1] + rxf[1]; pA[2] = np_[2] + rxf[2];
-      pA[3] = fp[0]; pA[4] = fp[1]; pA[5] = fp[2];
-    }
+    float mj[6], mq[12];
+    float pA[6] = {0, 0, 0, 0, 0, 0}, ud0, ud1, ud2;
+    delta_in<1>(S, 3 * leg + 2, jl[2], pA, ud2);
+    delta_in<1>(S, 3 * leg + 1, jl[1], pA, ud1);
+    delta_in<0>(S, 3 * leg, jl[0], pA, ud0);
     float fb[6], a0[6];
     mtv3(S.Rb, &Jb[0], &fb[0]);
     mtv3(S.Rb, &Jb[3], &fb[3]);
@@ -522,113 +541,90 @@ __device__ static int physics_substep(const KParams& P, Shared& S, int lane, boo
     for (int i = 0; i < 6; i++) fb[i] -= pA[i];
 #pragma unroll
     for (int i = 0; i < 6; i++) {
-      float s = 0.0f;
+      float sacc = 0.0f;
 #pragma unroll
-      for (int k = 0; k < 6; k++) s += S.IA0inv[i * 6 + k] * fb[k];
-      a0[i] = s;
+      for (int k = 0; k < 6; k++) sacc += S.IA0inv[i * 6 + k] * fb[k];
+      a0[i] = sacc;
     }
 #pragma unroll
     for (int L4 = 0; L4 < 4; L4++) {
       float ap[6] = {a0[0], a0[1], a0[2], a0[3], a0[4], a0[5]};
       const bool mine = (L4 == leg);
-#pragma unroll
-      for (int k = 0; k < 3; k++) {
-        const int j = 3 * L4 + k;
-        const LinkCache& L = S.lc[j];
-        float t[3], at[3], ab[3];
-        cross3(&ap[0], S.m.joint_pos[j], t);
-        t[0] += ap[3]; t[1] += ap[4]; t[2] += ap[5];
-        mtv3(L.R, &ap[0], at);
-        mtv3(L.R, t, ab);
-        const float Ud = L.U[0] * at[0] + L.U[1] * at[1] + L.U[2] * at[2] + L.U[3] * ab[0] + L.U[4] * ab[1] + L.U[5] * ab[2];
-        const float qdd = ((mine ? ud[k] : 0.0f) - Ud) * L.invD;
-        mq[j] = qdd;
-        diag += mine ? jl[k] * qdd : 0.0f;
-        ap[0] = at[0] + S.m.joint_axis[j][0] * qdd; ap[1] = at[1] + S.m.joint_axis[j][1] * qdd; ap[2] = at[2] + S.m.joint_axis[j][2] * qdd;
-        ap[3] = ab[0]; ap[4] = ab[1]; ap[5] = ab[2];
-      }
+      mq[3 * L4] = delta_out<0>(S, 3 * L4, mine ? ud0 : 0.0f, ap);
+      mq[3 * L4 + 1] = delta_out<1>(S, 3 * L4 + 1, mine ? ud1 : 0.0f, ap);
+      mq[3 * L4 + 2] = delta_out<1>(S, 3 * L4 + 2, mine ? ud2 : 0.0f, ap);
+      diag += mine ? (jl[0] * mq[3 * L4] + jl[1] * mq[3 * L4 + 1] + jl[2] * mq[3 * L4 + 2]) : 0.0f;
     }
     mv3(S.Rb, &a0[0], &mj[0]);
     mv3(S.Rb, &a0[3], &mj[3]);
 #pragma unroll
     for (int i = 0; i < 6; i++) diag += Jb[i] * mj[i];
+    if (active) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) S.ph.sub.W[lane][i] = mj[i];
+#pragma unroll
+      for (int i = 0; i < 12; i++) S.ph.sub.W[lane][6 + i] = mq[i];
+    }
   }
   const float jdi = 1.0f / diag;
-  float lam = 0.0f;
-  if (active) {
-#pragma unroll
-    for (int i = 0; i < 6; i++) S.W[dense][i] = mj[i];
-#pragma unroll
-    for (int i = 0; i < 12; i++) S.W[dense][6 + i] = mq[i];
-    lam = warm >= 0 ? cfg.warmstart_factor * S.s[O(LAMBDA) + warm] : 0.0f;
-    S.lam[dense] = lam;
-  }
+  float lam = (active && warm >= 0) ? cfg.warmstart_factor * S.s[O(LAMBDA) + warm] : 0.0f;
+  rhs *= jdi;
   WSYNC();
-  // Delassus rows A[i][s] = J_i . W[s]; stored transposed so that PGS step r reads a contiguous line
-  if (active) {
-    for (int s = 0; s < nrows; s++) {
-      float a = Jb[0] * S.W[s][0] + Jb[1] * S.W[s][1] + Jb[2] * S.W[s][2] + Jb[3] * S.W[s][3] + Jb[4] * S.W[s][4] + Jb[5] * S.W[s][5];
-      a += jl[0] * S.W[s][6 + 3 * leg] + jl[1] * S.W[s][6 + 3 * leg + 1] + jl[2] * S.W[s][6 + 3 * leg + 2];
-      S.A[s][dense] = a;
+  // Delassus column for this lane: Ac[r] = J_lane . W[r] (= A[lane][r] = A[r][lane]), kept in registers
+  float Ac[kMaxRows];
+  float w = 0.0f, lam_n = 0.0f;
+#pragma unroll
+  for (int r = 0; r < kMaxRows; r++) {
+    Ac[r] = 0.0f;
+    if ((mask >> r) & 1ull) {
+      const float* Wr = S.ph.sub.W[r];
+      float a = Jb[0] * Wr[0] + Jb[1] * Wr[1] + Jb[2] * Wr[2] + Jb[3] * Wr[3] + Jb[4] * Wr[4] + Jb[5] * Wr[5];
+      a += jl[0] * Wr[6 + 3 * leg] + jl[1] * Wr[6 + 3 * leg + 1] + jl[2] * Wr[6 + 3 * leg + 2];
+      Ac[r] = a;
+      const float l0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lam), r));
+      w += a * l0;  // warm-start contribution
+      if (r >= 16 && r < 20 && nrm_slot == r) lam_n = l0;
     }
   }
-  // move row state slot-lane -> dense-lane
-  float (*rowdata)[8] = S.rowdata;
-  if (active) {
-    rowdata[dense][0] = rhs * jdi;
-    rowdata[dense][1] = jdi;
-    rowdata[dense][2] = lo;
-    rowdata[dense][3] = hi;
-    rowdata[dense][4] = mu;
-    rowdata[dense][5] = __int_as_float(nrm_slot >= 0 ? __popcll(mask & ((1ull << nrm_slot) - 1ull)) : -1);
-    rowdata[dense][6] = __int_as_float(warm);
-    rowdata[dense][7] = lam;
-  }
-  WSYNC();
-  {
-    const bool mine = lane < nrows;
-    float r_rhs = 0, r_jdi = 0, r_lo = 0, r_hi = 0, r_mu = 0, r_lam = 0, w = 0, lam_n = 0;
-    int r_nrm = -1, r_warm = -1;
-    if (mine) {
-      r_rhs = rowdata[lane][0]; r_jdi = rowdata[lane][1]; r_lo = rowdata[lane][2]; r_hi = rowdata[lane][3];
-      r_mu = rowdata[lane][4]; r_nrm = __float_as_int(rowdata[lane][5]); r_warm = __float_as_int(rowdata[lane][6]);
-      r_lam = rowdata[lane][7];
-      for (int s = 0; s < nrows; s++) w += S.A[s][lane] * S.lam[s];  // warm-start contribution
-      if (r_nrm >= 0) lam_n = S.lam[r_nrm];
-    }
-    // projected Gauss-Seidel (btMultiBodyConstraintSolver::solveSingleIteration), Delassus form
-    for (int it = 0; it < cfg.solver_iters; it++) {
-      for (int r = 0; r < nrows; r++) {
-        const float acol = mine ? S.A[r][lane] : 0.0f;
-        float dl = r_rhs - w * r_jdi;
-        const float hi_e = r_nrm >= 0 ? r_mu * lam_n : r_hi;
-        const float lo_e = r_nrm >= 0 ? -hi_e : r_lo;
-        float sum = r_lam + dl;
+  // projected Gauss-Seidel (btMultiBodyConstraintSolver::solveSingleIteration), Delassus form:
+  // lane i keeps lambda_i and w_i = (A lambda)_i; one readlane per row update
+  const bool isfric = nrm_slot >= 0;
+  for (int it = 0; it < cfg.solver_iters; it++) {
+#pragma unroll
+    for (int r = 0; r < kMaxRows; r++) {
+      if ((mask >> r) & 1ull) {
+        float dl = rhs - w * jdi;
+        const float hi_e = isfric ? mu * lam_n : hi;
+        const float lo_e = isfric ? -hi_e : lo;
+        float sum = lam + dl;
         sum = sum < lo_e ? lo_e : (sum > hi_e ? hi_e : sum);
-        dl = sum - r_lam;
+        dl = sum - lam;
         const float d_r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dl), r));
-        if (lane == r) r_lam = sum;
-        w += acol * d_r;
-        if (r_nrm == r) lam_n += d_r;
+        if (lane == r) lam = sum;
+        w += Ac[r] * d_r;
+        if (r >= 16 && r < 20 && nrm_slot == r) lam_n += d_r;
       }
     }
-    WSYNC();
-    if (mine) {
-      S.lam[lane] = r_lam;
-      if (r_warm >= 0) S.s[O(LAMBDA) + r_warm] = r_lam;
-    }
-    // contact slots that are not active this sub-step forget their warm-start impulse
-    if (lane >= 16 && lane < 28 && !active) S.s[O(LAMBDA) + warm] = 0.0f;
   }
-  WSYNC();
+  // contact impulses are remembered for the next sub-step's warm start (0 for open contacts)
+  if (lane >= 16 && lane < 28) S.s[O(LAMBDA) + warm] = active ? lam : 0.0f;
   // ---------------- velocity update, Bullet coordinate-velocity clamp, semi-implicit Euler ----------------
   float unew = 0.0f;
-  if (lane < 18) {
+  {
     float du = 0.0f;
-    for (int s = 0; s < nrows; s++) du += S.W[s][lane] * S.lam[s];
-    unew = S.ustar[lane] + du;
-    unew = fminf(fmaxf(unew, -cfg.max_coord_velocity), cfg.max_coord_velocity);
-    S.du[lane] = unew;
+    const int kk = lane < 18 ? lane : 0;
+#pragma unroll
+    for (int r = 0; r < kMaxRows; r++) {
+      if ((mask >> r) & 1ull) {
+        const float lr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lam), r));
+        du += S.ph.sub.W[r][kk] * lr;
+      }
+    }
+    if (lane < 18) {
+      unew = S.ustar[lane] + du;
+      unew = fminf(fmaxf(unew, -cfg.max_coord_velocity), cfg.max_coord_velocity);
+      S.du[lane] = unew;
+    }
   }
   WSYNC();
   {
@@ -646,9 +642,9 @@ __device__ static int physics_substep(const KParams& P, Shared& S, int lane, boo
     else if (lane < 6) { S.s[O(LINVEL) + lane - 3] = unew; S.s[O(POS) + lane - 3] += dt * unew; }
     else if (lane < 18) {
       const int j = lane - 6;
-      const float a = S.jdir[j] * (S.s[O(Q) + j] - S.joff[j]) + dt * unew;
-      S.s[O(Q) + j] = a * S.jdir[j] + S.joff[j];
-      S.s[O(QD) + j] = unew * S.jdir[j];
+      const float a = S.m.jdir[j] * (S.s[O(Q) + j] - S.m.joff[j]) + dt * unew;
+      S.s[O(Q) + j] = a * S.m.jdir[j] + S.m.joff[j];
+      S.s[O(QD) + j] = unew * S.m.jdir[j];
     } else if (lane < 22) {
       const int i = lane - 18;
       S.s[O(QUAT) + i] = (i == 0 ? qn[0] : (i == 1 ? qn[1] : (i == 2 ? qn[2] : qn[3]))) * nn;
@@ -708,7 +704,7 @@ __device__ static void cycle_offset(const DevClip& c, int count, float pos[3], f
 
 // Sample the active clip at up to 5 times (lane l < nt samples time t_l): frames are staged into LDS by
 // coalesced row loads (lanes 0..18 read one 19-float frame row), then lanes 0..nt-1 blend serially.
-// Result: S.pose[l] = raw (no origin offset) pose; if with_vel, S.vel = raw frame velocity at time of lane 0.
+// Result: S.ph.end.pose[l] = raw (no origin offset) pose; if with_vel, S.vel = raw frame velocity at time of lane 0.
 // Warm-up poses (imitation_task.py:985-1009) are substituted where `warm` and -warmup <= t < 0.
 __device__ static void sample_poses(const KParams& P, Shared& S, int lane, int nt, float t_lane, bool with_vel) {
   const DevClip& c = P.tab->clip[geti(S, O(CLIP_ID))];
@@ -717,20 +713,21 @@ __device__ static void sample_poses(const KParams& P, Shared& S, int lane, int n
   for (int e = 0; e < 2 * nt; e++) {
     const int src = e >> 1;
     const int f = (e & 1) ? __shfl(sm.f1, src) : __shfl(sm.f0, src);
-    if (lane < 19) S.frames[e][lane] = c.frames[f * 19 + lane];
+    if (lane < 19) S.ph.end.frames[e][lane] = c.frames[f * 19 + lane];
   }
   if (with_vel) {
     const int f0 = __shfl(sm.f0, 0), f1 = __shfl(sm.f1, 0);
-    if (lane < 18) { S.fvel[0][lane] = c.vels[f0 * 18 + lane]; S.fvel[1][lane] = c.vels[f1 * 18 + lane]; }
+    if (lane < 18) { S.ph.end.fvel[0][lane] = c.vels[f0 * 18 + lane]; S.ph.end.fvel[1][lane] = c.vels[f1 * 18 + lane]; }
   }
-  if (lane < 19) S.red[lane] = c.frames[lane];  // frame 0 (warm-up heading)
+  if (lane < 19) S.ph.end.frames[10][lane] = c.frames[lane];  // frame 0 (warm-up heading)
   WSYNC();
   if (lane < nt) {
     const bool warm_pose = warm_ep && t_lane >= -P.cfg.warmup_time && t_lane < 0.0f;
     float out[19];
     if (warm_pose) {
       // default pose rotated to the heading of frame(0) (imitation_task.py:985-1009, 1245-1252)
-      float dr[4], pp[3], qq[4], q0[4] = {S.red[3], S.red[4], S.red[5], S.red[6]};
+      const float* fr0 = S.ph.end.frames[10];
+      float dr[4], pp[3], qq[4], q0[4] = {fr0[3], fr0[4], fr0[5], fr0[6]};
       const float dh = qheading(q0) - qheading(S.m.init_quat);
       q_about_z(dh, dr);
       qrot(S.m.init_pos, dr, pp);
@@ -738,10 +735,10 @@ __device__ static void sample_poses(const KParams& P, Shared& S, int lane, int n
       out[0] = pp[0]; out[1] = pp[1]; out[2] = pp[2];
       out[3] = qq[0]; out[4] = qq[1]; out[5] = qq[2]; out[6] = qq[3];
 #pragma unroll
-      for (int i = 0; i < 12; i++) out[7 + i] = (S.m.init_motor_angles[i] + S.m.motor_offset[i]) * S.m.motor_dir[i];
+      for (int i = 0; i < 12; i++) out[7 + i] = S.m.default_joints[i];
     } else {
-      const float* a = S.frames[2 * lane];
-      const float* b = S.frames[2 * lane + 1];
+      const float* a = S.ph.end.frames[2 * lane];
+      const float* b = S.ph.end.frames[2 * lane + 1];
       const float bl = sm.blend;
 #pragma unroll
       for (int k = 0; k < 3; k++) out[k] = (1.0f - bl) * a[k] + bl * b[k];
@@ -759,34 +756,34 @@ __device__ static void sample_poses(const KParams& P, Shared& S, int lane, int n
       out[3] = q2[0]; out[4] = q2[1]; out[5] = q2[2]; out[6] = q2[3];
     }
 #pragma unroll
-    for (int k = 0; k < 19; k++) S.pose[lane][k] = out[k];
+    for (int k = 0; k < 19; k++) S.ph.end.pose[lane][k] = out[k];
     if (with_vel && lane == 0) {
       if (warm_pose) {
 #pragma unroll
-        for (int k = 0; k < 18; k++) S.vel[k] = 0.0f;
+        for (int k = 0; k < 18; k++) S.ph.end.vel[k] = 0.0f;
       } else {
         float v[18], cp[3], cr[4], t3[3];
 #pragma unroll
-        for (int k = 0; k < 18; k++) v[k] = (1.0f - sm.blend) * S.fvel[0][k] + sm.blend * S.fvel[1][k];
+        for (int k = 0; k < 18; k++) v[k] = (1.0f - sm.blend) * S.ph.end.fvel[0][k] + sm.blend * S.ph.end.fvel[1][k];
         cycle_offset(c, sm.count, cp, cr);
         qrot(&v[0], cr, t3); v[0] = t3[0]; v[1] = t3[1]; v[2] = t3[2];
         qrot(&v[3], cr, t3); v[3] = t3[0]; v[4] = t3[1]; v[5] = t3[2];
 #pragma unroll
-        for (int k = 0; k < 18; k++) S.vel[k] = v[k];
+        for (int k = 0; k < 18; k++) S.ph.end.vel[k] = v[k];
       }
     }
   }
   WSYNC();
 }
 
-// apply the origin offset (imitation_task.py:938-951) to S.pose[l] in place (lane l < nt)
+// apply the origin offset (imitation_task.py:938-951) to S.ph.end.pose[l] in place (lane l < nt)
 __device__ static void apply_origin(Shared& S, int lane, int nt) {
   if (lane < nt) {
     float qq[4], pp[3];
-    qmul(&S.s[O(ORIGIN_ROT)], &S.pose[lane][3], qq);
-    qrot(&S.pose[lane][0], &S.s[O(ORIGIN_ROT)], pp);
-    S.pose[lane][0] = pp[0] + S.s[O(ORIGIN_POS)]; S.pose[lane][1] = pp[1] + S.s[O(ORIGIN_POS) + 1]; S.pose[lane][2] = pp[2] + S.s[O(ORIGIN_POS) + 2];
-    S.pose[lane][3] = qq[0]; S.pose[lane][4] = qq[1]; S.pose[lane][5] = qq[2]; S.pose[lane][6] = qq[3];
+    qmul(&S.s[O(ORIGIN_ROT)], &S.ph.end.pose[lane][3], qq);
+    qrot(&S.ph.end.pose[lane][0], &S.s[O(ORIGIN_ROT)], pp);
+    S.ph.end.pose[lane][0] = pp[0] + S.s[O(ORIGIN_POS)]; S.ph.end.pose[lane][1] = pp[1] + S.s[O(ORIGIN_POS) + 1]; S.ph.end.pose[lane][2] = pp[2] + S.s[O(ORIGIN_POS) + 2];
+    S.ph.end.pose[lane][3] = qq[0]; S.ph.end.pose[lane][4] = qq[1]; S.ph.end.pose[lane][5] = qq[2]; S.ph.end.pose[lane][6] = qq[3];
   }
   WSYNC();
 }
@@ -797,7 +794,7 @@ __device__ __forceinline__ float motion_time(const KParams& P, const Shared& S) 
   return t;
 }
 
-// build the 76-d target observation into obs76 (LDS) from S.pose[1..4] (already origin-offset) -- imitation_task.py:254-301
+// build the 76-d target observation into obs76 (LDS) from S.ph.end.pose[1..4] (already origin-offset) -- imitation_task.py:254-301
 __device__ static void target_obs(const KParams& P, const float* rec, Shared& S, int lane, float* obs76) {
   ctrl_obs(P, rec, S, lane);
   if (lane >= 1 && lane <= 4) {
@@ -810,7 +807,7 @@ __device__ static void target_obs(const KParams& P, const float* rec, Shared& S,
     const float heading = atan2f(sy * cpch, cy * cpch);
     float ih[4], p[3], pr[3], q[4];
     q_about_z(-heading, ih);
-    const float* pose = S.pose[lane];
+    const float* pose = S.ph.end.pose[lane];
     p[0] = pose[0] - S.s[O(REF_POSE)]; p[1] = pose[1] - S.s[O(REF_POSE) + 1]; p[2] = pose[2] - S.s[O(REF_POSE) + 2];
     qrot(p, ih, pr);
     qmul(ih, pose + 3, q);
@@ -834,13 +831,18 @@ __device__ static void leg_end_effectors(const Shared& S, const float pos[3], co
 #pragma unroll
   for (int k = 0; k < 3; k++) {
     const int j = 3 * leg + k;
-    float t[3], Rj[9], Rn[9];
+    float t[3];
     mv3(R, S.m.joint_pos[j], t);
     o[0] += t[0]; o[1] += t[1]; o[2] += t[2];
-    rodrigues(S.m.joint_axis[j], S.jdir[j] * (qj[j] - S.joff[j]), Rj);
-    mm3(R, Rj, Rn);
+    const float a = S.m.jdir[j] * (qj[j] - S.m.joff[j]);
+    float sn, cs;
+    joint_sincos(a, &sn, &cs);
 #pragma unroll
-    for (int i = 0; i < 9; i++) R[i] = Rn[i];
+    for (int i = 0; i < 3; i++) {  // R <- R Rj (joint k = 0 turns about x, k = 1, 2 about y)
+      const float p0 = R[3 * i], p1 = R[3 * i + 1], p2 = R[3 * i + 2];
+      if (k == 0) { R[3 * i + 1] = cs * p1 + sn * p2; R[3 * i + 2] = -sn * p1 + cs * p2; }
+      else { R[3 * i] = cs * p0 - sn * p2; R[3 * i + 2] = sn * p0 + cs * p2; }
+    }
   }
   float t[3];
   mv3(R, S.m.lower_com[leg], t); lower[0] = o[0] + t[0]; lower[1] = o[1] + t[1]; lower[2] = o[2] + t[2];
@@ -864,7 +866,7 @@ __device__ static float calc_reward(const KParams& P, Shared& S, int lane) {
     if (which == 0) leg_end_effectors(S, &S.s[O(POS)], &S.s[O(QUAT)], &S.s[O(Q)], leg, lower, toe);
     else leg_end_effectors(S, rp, rp + 3, rp + 7, leg, lower, toe);
 #pragma unroll
-    for (int i = 0; i < 3; i++) { S.ee[which][2 * leg][i] = lower[i]; S.ee[which][2 * leg + 1][i] = toe[i]; }
+    for (int i = 0; i < 3; i++) { S.ph.end.ee[which][2 * leg][i] = lower[i]; S.ph.end.ee[which][2 * leg + 1][i] = toe[i]; }
   }
   WSYNC();
   const orr_config& c = P.cfg;
@@ -887,10 +889,10 @@ __device__ static float calc_reward(const KParams& P, Shared& S, int lane) {
     if (lane < 8) {
       float a[3], b[3], ar[3], br[3];
 #pragma unroll
-      for (int k = 0; k < 3; k++) { a[k] = S.ee[1][lane][k] - rp[k]; b[k] = S.ee[0][lane][k] - S.s[O(POS) + k]; }
+      for (int k = 0; k < 3; k++) { a[k] = S.ph.end.ee[1][lane][k] - rp[k]; b[k] = S.ph.end.ee[0][lane][k] - S.s[O(POS) + k]; }
       qrot(a, ihr, ar);
       qrot(b, ihs, br);
-      const float dh = S.ee[1][lane][2] - S.ee[0][lane][2];
+      const float dh = S.ph.end.ee[1][lane][2] - S.ph.end.ee[0][lane][2];
       e = (ar[0] - br[0]) * (ar[0] - br[0]) + (ar[1] - br[1]) * (ar[1] - br[1]) + c.reward_scale[3] * dh * dh;
     }
     S.red[lane] = e;
@@ -994,14 +996,7 @@ __device__ static void reset_robot(const KParams& P, float* rec, Shared& S, int 
       else S.s[O(STRENGTH) + lane - 14] = 0.8f + u * 0.4f;
     }
     WSYNC();
-    if (lane < 13) {  // refresh the randomised mass properties
-      int g = lane == 0 ? 0 : S.m.link_group[lane - 1];
-      float mr = S.s[O(MASS_RATIO) + g], ir = S.s[O(INERTIA_RATIO) + g];
-      S.mass[lane] = (lane == 0 ? S.m.base_mass : S.m.link_mass[lane - 1]) * mr;
-#pragma unroll
-      for (int k = 0; k < 6; k++)
-        S.Ic[lane][k] = lane == 0 ? S.m.base_inertia[k] * ir : S.m.link_inertia[lane - 1][k] * ir + S.m.link_inertia_pa[lane - 1][k] * mr;
-    }
+    refresh_mass(P.tab->model[geti(S, O(ROBOT_TYPE))], S, lane);
     WSYNC();
   }
   // 5. task reset (imitation_task.py:183-199, 694-732, 1103-1110)
@@ -1026,27 +1021,27 @@ __device__ static void reset_robot(const KParams& P, float* rec, Shared& S, int 
   if (lane == 0) {
     // origin offset: position first (with identity rotation), then rotation; position is NOT recomputed
     // afterwards (imitation_task.py:712-723)
-    S.s[O(ORIGIN_POS)] = S.s[O(POS)] - S.pose[0][0];
-    S.s[O(ORIGIN_POS) + 1] = S.s[O(POS) + 1] - S.pose[0][1];
+    S.s[O(ORIGIN_POS)] = S.s[O(POS)] - S.ph.end.pose[0][0];
+    S.s[O(ORIGIN_POS) + 1] = S.s[O(POS) + 1] - S.ph.end.pose[0][1];
     S.s[O(ORIGIN_POS) + 2] = 0.0f;
-    const float dh = qheading(&S.s[O(QUAT)]) - qheading(&S.pose[0][3]);
+    const float dh = qheading(&S.s[O(QUAT)]) - qheading(&S.ph.end.pose[0][3]);
     q_about_z(dh, &S.s[O(ORIGIN_ROT)]);
     S.s[O(PREV_PHASE)] = clip_phase(clip, t);
   }
   WSYNC();
   apply_origin(S, lane, 5);
-  if (lane < 19) S.s[O(REF_POSE) + lane] = S.pose[0][lane];
+  if (lane < 19) S.s[O(REF_POSE) + lane] = S.ph.end.pose[0][lane];
   if (lane == 0) {
     float v[3];
-    qrot(&S.vel[0], &S.s[O(ORIGIN_ROT)], v); S.vel[0] = v[0]; S.vel[1] = v[1]; S.vel[2] = v[2];
-    qrot(&S.vel[3], &S.s[O(ORIGIN_ROT)], v); S.vel[3] = v[0]; S.vel[4] = v[1]; S.vel[5] = v[2];
+    qrot(&S.ph.end.vel[0], &S.s[O(ORIGIN_ROT)], v); S.ph.end.vel[0] = v[0]; S.ph.end.vel[1] = v[1]; S.ph.end.vel[2] = v[2];
+    qrot(&S.ph.end.vel[3], &S.s[O(ORIGIN_ROT)], v); S.ph.end.vel[3] = v[0]; S.ph.end.vel[4] = v[1]; S.ph.end.vel[5] = v[2];
   }
   WSYNC();
-  if (lane < 18) S.s[O(REF_VEL) + lane] = S.vel[lane];
+  if (lane < 18) S.s[O(REF_VEL) + lane] = S.ph.end.vel[lane];
   // 6. _sync_sim_model / _set_state (:778-829): teleport the sim robot onto the reference
-  if (lane < 3) { S.s[O(POS) + lane] = S.pose[0][lane]; S.s[O(LINVEL) + lane] = S.vel[lane]; S.s[O(ANGVEL) + lane] = S.vel[3 + lane]; }
-  if (lane < 4) S.s[O(QUAT) + lane] = S.pose[0][3 + lane];
-  if (lane < 12) { S.s[O(Q) + lane] = S.pose[0][7 + lane]; S.s[O(QD) + lane] = S.vel[6 + lane]; }
+  if (lane < 3) { S.s[O(POS) + lane] = S.ph.end.pose[0][lane]; S.s[O(LINVEL) + lane] = S.ph.end.vel[lane]; S.s[O(ANGVEL) + lane] = S.ph.end.vel[3 + lane]; }
+  if (lane < 4) S.s[O(QUAT) + lane] = S.ph.end.pose[0][3 + lane];
+  if (lane < 12) { S.s[O(Q) + lane] = S.ph.end.pose[0][7 + lane]; S.s[O(QD) + lane] = S.ph.end.vel[6 + lane]; }
   WSYNC();
   receive_obs(rec, S, lane);  // ring entry #2 (imitation_task.py:792)
   // 7. observation = histories from step 3 + target observation (quadruped_gym_env.py:100-102; wrapper_env.py:101-105)
@@ -1061,7 +1056,7 @@ __device__ static void reset_robot(const KParams& P, float* rec, Shared& S, int 
 // ================================================================================================
 __global__ __launch_bounds__(64) void orr_reset_kernel(KParams P, const uint8_t* mask, float* obs_out) {
   __shared__ Shared S;
-  __shared__ float obs[ORR_OBS_DIM];
+  float* obs = S.ph.end.obs;
   const int robot = blockIdx.x, lane = threadIdx.x;
   if (mask && !mask[robot]) return;
   float* rec = P.state + (size_t)robot * ORR_STATE_STRIDE;
@@ -1076,18 +1071,21 @@ __global__ __launch_bounds__(64) void orr_reset_kernel(KParams P, const uint8_t*
 
 // mode 0: full env step.  mode 1 (debug / parity of row C): nsub physics sub-steps with the given
 // motor torques (actions = torques), no robot or task logic.
+#ifndef ORR_WAVES_PER_EU
+#define ORR_WAVES_PER_EU 4  // 4096 robots = 4 waves on each of the 1024 SIMDs: the whole batch is resident at once
+#endif
 template <int MODE>
-__global__ __launch_bounds__(64) void orr_step_kernel(KParams P, const float* actions, float* obs_out, float* reward_out,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PER_EU, 8))) void orr_step_kernel(KParams P, const float* actions, float* obs_out, float* reward_out,
                                                       uint8_t* done_out, int nsub) {
   __shared__ Shared S;
-  __shared__ float obs[ORR_OBS_DIM];
+  float* obs = S.ph.end.obs;
   const int robot = blockIdx.x, lane = threadIdx.x;
   float* rec = P.state + (size_t)robot * ORR_STATE_STRIDE;
   const orr_config& c = P.cfg;
   load_robot(P, rec, S, lane);
 
   if (MODE == 1) {
-    if (lane < 12) S.tau[S.m.joint_of_motor[lane]] = actions[(size_t)robot * 12 + lane];
+    if (lane < 12) { const int j = S.m.joint_of_motor[lane]; S.tau[j] = S.m.tau_sign[j] * actions[(size_t)robot * 12 + lane]; }
     WSYNC();
     int fall = 0;
     for (int s = 0; s < nsub; s++) fall = physics_substep(P, S, lane, true);
@@ -1125,7 +1123,7 @@ __global__ __launch_bounds__(64) void orr_step_kernel(KParams P, const float* ac
       const float qm = (S.s[O(Q) + j] - S.m.motor_offset[lane]) * S.m.motor_dir[lane];  // pd latency 0 (:359-363)
       const float qdm = S.s[O(QD) + j] * S.m.motor_dir[lane];
       // MotorModel.convert_to_torque, POSITION mode (minitaur_motor.py:163-171)
-      S.tau[j] = S.s[O(STRENGTH) + lane] * (-1.0f * (S.m.kp[lane] * (qm - cmd)) - S.m.kd[lane] * qdm);
+      S.tau[j] = S.m.tau_sign[j] * (S.s[O(STRENGTH) + lane] * (-1.0f * (S.m.kp[lane] * (qm - cmd)) - S.m.kd[lane] * qdm));
     }
     WSYNC();
     if (lane == 0) {  // robot_step bookkeeping (minitaur.py:287-293)
@@ -1153,20 +1151,20 @@ __global__ __launch_bounds__(64) void orr_step_kernel(KParams P, const float* ac
     if (lane == 0) {
       if ((c.flags & ORR_FLAG_CYCLE_SYNC) && ph < S.s[O(PREV_PHASE)]) {
         float pr[3];
-        qrot(&S.pose[0][0], &S.s[O(ORIGIN_ROT)], pr);
+        qrot(&S.ph.end.pose[0][0], &S.s[O(ORIGIN_ROT)], pr);
         S.s[O(ORIGIN_POS)] = S.s[O(POS)] - pr[0];
         S.s[O(ORIGIN_POS) + 1] = S.s[O(POS) + 1] - pr[1];
         S.s[O(ORIGIN_POS) + 2] = 0.0f;
       }
       S.s[O(PREV_PHASE)] = ph;
       float v[3];
-      qrot(&S.vel[0], &S.s[O(ORIGIN_ROT)], v); S.vel[0] = v[0]; S.vel[1] = v[1]; S.vel[2] = v[2];
-      qrot(&S.vel[3], &S.s[O(ORIGIN_ROT)], v); S.vel[3] = v[0]; S.vel[4] = v[1]; S.vel[5] = v[2];
+      qrot(&S.ph.end.vel[0], &S.s[O(ORIGIN_ROT)], v); S.ph.end.vel[0] = v[0]; S.ph.end.vel[1] = v[1]; S.ph.end.vel[2] = v[2];
+      qrot(&S.ph.end.vel[3], &S.s[O(ORIGIN_ROT)], v); S.ph.end.vel[3] = v[0]; S.ph.end.vel[4] = v[1]; S.ph.end.vel[5] = v[2];
     }
     WSYNC();
     apply_origin(S, lane, 5);
-    if (lane < 19) S.s[O(REF_POSE) + lane] = S.pose[0][lane];
-    if (lane < 18) S.s[O(REF_VEL) + lane] = S.vel[lane];
+    if (lane < 19) S.s[O(REF_POSE) + lane] = S.ph.end.pose[0][lane];
+    if (lane < 18) S.s[O(REF_VEL) + lane] = S.ph.end.vel[lane];
     WSYNC();
   }
   // _terminal_condition (imitation_task.py:518-572) + time limit (wrapper_env.py:79) + non-finite guard
@@ -1335,8 +1333,62 @@ int32_t orr_set_model(orr_handle* h, int32_t robot_type, const orr_model* m) {
   }
   for (int i = 0; i < m->num_fall_proxies; i++)
     if (m->fall_body[i] < 0 || m->fall_body[i] > 12) return fail(-1, "orr_set_model: fall_body out of range");
-  h->tab_host.model[robot_type] = *m;
-  HIPCHK(hipMemcpy(&h->tab_dev->model[robot_type], m, sizeof(orr_model), hipMemcpyHostToDevice), "orr_set_model: hipMemcpy");
+  // every joint must turn about a coordinate axis of the kinematic frame: hip about +-x, upper / lower leg about +-y
+  DevModel& d = h->tab_host.model[robot_type];
+  memset(&d, 0, sizeof(d));
+  float axsgn[12];
+  for (int j = 0; j < 12; j++) {
+    const int ax = (j % 3 == 0) ? 0 : 1;
+    const float* a = m->joint_axis[j];
+    for (int k = 0; k < 3; k++)
+      if (k != ax && fabsf(a[k]) > 1e-6f) return fail(-1, "orr_set_model: joint axes must be +-x (hip) / +-y (upper, lower leg)");
+    if (fabsf(fabsf(a[ax]) - 1.0f) > 1e-5f) return fail(-1, "orr_set_model: joint axis is not a unit coordinate axis");
+    axsgn[j] = a[ax] > 0 ? 1.0f : -1.0f;
+  }
+  ModelHot& H = d.hot;
+  for (int i = 0; i < 3; i++) H.init_pos[i] = m->init_pos[i];
+  for (int i = 0; i < 4; i++) H.init_quat[i] = m->init_quat[i];
+  for (int i = 0; i < 12; i++) {
+    const int j = m->joint_of_motor[i];
+    H.init_motor_angles[i] = m->init_motor_angles[i];
+    H.motor_dir[i] = m->motor_dir[i];
+    H.motor_offset[i] = m->motor_offset[i];
+    H.joint_of_motor[i] = j;
+    H.motor_of_joint[j] = i;
+    H.kp[i] = m->kp[i];
+    H.kd[i] = m->kd[i];
+    H.jdir[j] = m->motor_dir[i] * axsgn[j];
+    H.joff[j] = m->motor_offset[i];
+    H.tau_sign[j] = axsgn[j];
+    H.default_joints[i] = (m->init_motor_angles[i] + m->motor_offset[i]) * m->motor_dir[i];
+  }
+  for (int j = 0; j < 12; j++) {
+    for (int k = 0; k < 3; k++) { H.link_com[j][k] = m->link_com[j][k]; H.joint_pos[j][k] = m->joint_pos[j][k]; }
+    // limits are given for the kinematic angle; the internal angle is axis_sign times it
+    H.joint_lo[j] = axsgn[j] > 0 ? m->joint_lo[j] : -m->joint_hi[j];
+    H.joint_hi[j] = axsgn[j] > 0 ? m->joint_hi[j] : -m->joint_lo[j];
+    if (!(H.joint_hi[j] - H.joint_lo[j] >= 2.0f * h->cfg.limit_activation))
+      return fail(-1, "orr_set_model: joint range must be at least 2 * limit_activation");
+  }
+  for (int l = 0; l < 4; l++)
+    for (int k = 0; k < 3; k++) { H.toe_pos[l][k] = m->toe_pos[l][k]; H.lower_com[l][k] = m->lower_com[l][k]; }
+  H.toe_radius = m->toe_radius;
+  H.foot_friction = m->foot_friction;
+  H.num_fall = m->num_fall_proxies;
+  for (int i = 0; i < ORR_MAX_FALL_PROXIES; i++) {
+    H.fall_body[i] = m->fall_body[i];
+    H.fall_radius[i] = m->fall_radius[i];
+    for (int k = 0; k < 3; k++) H.fall_pos[i][k] = m->fall_pos[i][k];
+  }
+  d.mass[0] = m->base_mass;
+  d.group[0] = 0;
+  for (int k = 0; k < 6; k++) { d.inertia[0][k] = m->base_inertia[k]; d.inertia_pa[0][k] = 0.0f; }
+  for (int j = 0; j < 12; j++) {
+    d.mass[j + 1] = m->link_mass[j];
+    d.group[j + 1] = m->link_group[j];
+    for (int k = 0; k < 6; k++) { d.inertia[j + 1][k] = m->link_inertia[j][k]; d.inertia_pa[j + 1][k] = m->link_inertia_pa[j][k]; }
+  }
+  HIPCHK(hipMemcpy(&h->tab_dev->model[robot_type], &d, sizeof(DevModel), hipMemcpyHostToDevice), "orr_set_model: hipMemcpy");
   return 0;
 }
 
