@@ -16,10 +16,33 @@
 #include "../../include/openroborl_hip.h"
 
 #define ORR_PI_F 3.14159265358979323846f
-#define WSYNC() __syncthreads()
+// A workgroup is exactly one wavefront, so LDS hand-offs between lanes only need the LDS operations to be
+// complete and ordered (workgroup-scope fence -> s_waitcnt) and the compiler not to move code across:
+// no s_barrier, and safe inside divergent (per-robot) control flow.
+#define WSYNC()                                           \
+  do {                                                    \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); \
+    __builtin_amdgcn_wave_barrier();                      \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); \
+  } while (0)
+#ifdef ORR_NO_SCHED_FENCE
+#define SCHED_FENCE()
+#else
+#ifdef ORR_SCHED_FENCE
+#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define SCHED_FENCE()  // measured: fencing the scheduler RAISES spills (104 vs 0 at 256 VGPRs); kept for experiments
+#endif
+#endif
 
 namespace orr {
 
+#ifndef ORR_LANES_PER_ROBOT
+#define ORR_LANES_PER_ROBOT 32
+#endif
+constexpr int kLanes = ORR_LANES_PER_ROBOT;  // lanes of a wavefront that serve one robot (32 -> two robots per wave)
+constexpr int kRPW = 64 / kLanes;            // robots per wavefront
+static_assert(kLanes == 32 || kLanes == 64, "rows need 28 lanes per robot");
 constexpr int kMaxRows = 28;  // 4 knee-friction + <=12 joint-limit + 12 contact rows
 constexpr int kHead = 320;    // words of the state record staged in LDS (everything before the ring)
 
@@ -267,6 +290,14 @@ __device__ __forceinline__ void symv(const float S[6], const float v[3], float o
   const float b = S[3] * v[0] + S[1] * v[1] + S[5] * v[2];
   const float c = S[4] * v[0] + S[5] * v[1] + S[2] * v[2];
   o[0] = a; o[1] = b; o[2] = c;
+}
+
+// value of x in lane r of the robot's lane group (r is a compile-time constant at every call site)
+__device__ __forceinline__ float bcast_row(float x, int r, int sub) {
+  const int v = __float_as_int(x);
+  if (kRPW == 1) return __int_as_float(__builtin_amdgcn_readlane(v, r));
+  const int a = __builtin_amdgcn_readlane(v, r), b = __builtin_amdgcn_readlane(v, r + 32);
+  return __int_as_float(sub ? b : a);
 }
 
 // sine / cosine of a joint angle

@@ -31,18 +31,19 @@ __device__ static void refresh_mass(const DevModel& gm, Shared& S, int lane) {
 }
 
 __device__ static void load_robot(const KParams& P, const float* rec, Shared& S, int lane) {
-  for (int i = lane; i < kHead; i += 64) S.s[i] = rec[i];
+  for (int i = lane; i < kHead; i += kLanes) S.s[i] = rec[i];
   WSYNC();
   const DevModel& gm = P.tab->model[geti(S, O(ROBOT_TYPE))];
   const float* mp = reinterpret_cast<const float*>(&gm.hot);
   float* dst = reinterpret_cast<float*>(&S.m);
-  for (int i = lane; i < kModelLdsWords; i += 64) dst[i] = mp[i];
+  for (int i = lane; i < kModelLdsWords; i += kLanes) dst[i] = mp[i];
   refresh_mass(gm, S, lane);
   WSYNC();
 }
 
-__device__ static void store_robot(float* rec, const Shared& S, int lane) {
-  for (int i = lane; i < O(RING); i += 64) rec[i] = S.s[i];
+__device__ static void store_robot(float* rec, const Shared& S, int lane, bool valid) {
+  if (valid)
+    for (int i = lane; i < O(RING); i += kLanes) rec[i] = S.s[i];
 }
 
 // ================================================================================================
@@ -67,7 +68,7 @@ __device__ static void ctrl_obs(const KParams& P, const float* rec, Shared& S, i
 }
 
 // Minitaur.receive_obs + get_true_obs (minitaur.py:304-334): push the true observation
-__device__ static void receive_obs(float* rec, Shared& S, int lane) {
+__device__ static void receive_obs(float* rec, Shared& S, int lane, bool valid) {
   const int head = (geti(S, O(RING_HEAD)) + 1) % ORR_RING_DEPTH, len = geti(S, O(RING_LEN));
   float qi[4], rel[4], ri[4], Rm[9], rate[3];
   qinv(S.m.init_quat, qi);
@@ -84,7 +85,7 @@ __device__ static void receive_obs(float* rec, Shared& S, int lane) {
   } else if (lane < 19) {
     val = lane == 16 ? rate[0] : (lane == 17 ? rate[1] : rate[2]);
   }
-  if (lane < ORR_RING_ENTRY) rec[O(RING) + head * ORR_RING_ENTRY + lane] = val;
+  if (valid && lane < ORR_RING_ENTRY) rec[O(RING) + head * ORR_RING_ENTRY + lane] = val;
   WSYNC();
   if (lane == 0) {
     seti(S, O(RING_HEAD), head);
@@ -328,14 +329,20 @@ __device__ static void aba_legs(const KParams& P, Shared& S, int lane) {
 #pragma unroll
     for (int i = 0; i < 9; i++) Rwp[i] = Rb[i];
     pass1_link<0>(S, 3 * leg, wr, wp, vp, Rwp, owp);
+    SCHED_FENCE();
     pass1_link<1>(S, 3 * leg + 1, wr, wp, vp, Rwp, owp);
+    SCHED_FENCE();
     pass1_link<1>(S, 3 * leg + 2, wr, wp, vp, Rwp, owp);
   }
+  SCHED_FENCE();
   float Iacc[6] = {0, 0, 0, 0, 0, 0}, Hacc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Macc[6] = {0, 0, 0, 0, 0, 0};
   float pacc[6] = {0, 0, 0, 0, 0, 0};
   pass2_link<1>(S, 3 * leg + 2, wr, Iacc, Hacc, Macc, pacc);
+  SCHED_FENCE();
   pass2_link<1>(S, 3 * leg + 1, wr, Iacc, Hacc, Macc, pacc);
+  SCHED_FENCE();
   pass2_link<0>(S, 3 * leg, wr, Iacc, Hacc, Macc, pacc);
+  SCHED_FENCE();
   // base: sum the four leg contributions (butterfly over lane bits 0, 1)
 #pragma unroll
   for (int i = 0; i < 6; i++) {
@@ -388,9 +395,13 @@ __device__ static void aba_legs(const KParams& P, Shared& S, int lane) {
   }
   {
     float ap[6] = {a0[0], a0[1], a0[2], a0[3], a0[4], a0[5]};
+    SCHED_FENCE();
     pass3_link<0>(S, 3 * leg, wr, ap);
+    SCHED_FENCE();
     pass3_link<1>(S, 3 * leg + 1, wr, ap);
+    SCHED_FENCE();
     pass3_link<1>(S, 3 * leg + 2, wr, ap);
+    SCHED_FENCE();
   }
   if (lane == 0) {
     // world-frame base accelerations (Bullet: vdot = R (a_lin + w x v)); gravity = uniform-field offset
@@ -435,7 +446,7 @@ __device__ __forceinline__ float delta_out(const Shared& S, int j, float ud, flo
 }
 
 // One physics sub-step.  Returns the fall-proxy flag (wave-uniform) when want_fall.
-__device__ static int physics_substep(const KParams& P, Shared& S, int lane, bool want_fall) {
+__device__ static int physics_substep(const KParams& P, Shared& S, int lane, int sub, bool want_fall) {
   const orr_config& cfg = P.cfg;
   const float dt = cfg.sim_dt;
   aba_legs(P, S, lane);
@@ -454,7 +465,7 @@ __device__ static int physics_substep(const KParams& P, Shared& S, int lane, boo
       const float wz = Rw[6] * S.m.fall_pos[lane][0] + Rw[7] * S.m.fall_pos[lane][1] + Rw[8] * S.m.fall_pos[lane][2];
       hit = (oz + wz - S.m.fall_radius[lane]) < cfg.contact_margin;
     }
-    fall = __ballot(hit) != 0ull;
+    fall = ((__ballot(hit) >> (sub * kLanes)) & ((1ull << (kLanes - 1)) * 2ull - 1ull)) != 0ull;
   }
   WSYNC();
 
@@ -524,16 +535,23 @@ __device__ static int physics_substep(const KParams& P, Shared& S, int lane, boo
       rhs = -rel;
     }
   }
-  const unsigned long long mask = __ballot(active);
+  const unsigned long long bal = __ballot(active);
+  // rows of the robots sharing this wave are solved side by side: a row slot is visited when it is active for any
+  // of them; a robot whose slot is inactive carries lambda = rhs = 0 there, so the visit is a no-op for it
+  const unsigned int mask = kRPW == 1 ? (unsigned int)(bal | (bal >> 32)) : ((unsigned int)bal | (unsigned int)(bal >> 32));
 
   // ---------------- impulse response M^-1 J^T ----------------
   float diag = 0.0f;
   {
     float mj[6], mq[12];
     float pA[6] = {0, 0, 0, 0, 0, 0}, ud0, ud1, ud2;
+    SCHED_FENCE();
     delta_in<1>(S, 3 * leg + 2, jl[2], pA, ud2);
+    SCHED_FENCE();
     delta_in<1>(S, 3 * leg + 1, jl[1], pA, ud1);
+    SCHED_FENCE();
     delta_in<0>(S, 3 * leg, jl[0], pA, ud0);
+    SCHED_FENCE();
     float fb[6], a0[6];
     mtv3(S.Rb, &Jb[0], &fb[0]);
     mtv3(S.Rb, &Jb[3], &fb[3]);
@@ -550,8 +568,11 @@ __device__ static int physics_substep(const KParams& P, Shared& S, int lane, boo
     for (int L4 = 0; L4 < 4; L4++) {
       float ap[6] = {a0[0], a0[1], a0[2], a0[3], a0[4], a0[5]};
       const bool mine = (L4 == leg);
+      SCHED_FENCE();
       mq[3 * L4] = delta_out<0>(S, 3 * L4, mine ? ud0 : 0.0f, ap);
+      SCHED_FENCE();
       mq[3 * L4 + 1] = delta_out<1>(S, 3 * L4 + 1, mine ? ud1 : 0.0f, ap);
+      SCHED_FENCE();
       mq[3 * L4 + 2] = delta_out<1>(S, 3 * L4 + 2, mine ? ud2 : 0.0f, ap);
       diag += mine ? (jl[0] * mq[3 * L4] + jl[1] * mq[3 * L4 + 1] + jl[2] * mq[3 * L4 + 2]) : 0.0f;
     }
@@ -566,9 +587,10 @@ __device__ static int physics_substep(const KParams& P, Shared& S, int lane, boo
       for (int i = 0; i < 12; i++) S.ph.sub.W[lane][6 + i] = mq[i];
     }
   }
-  const float jdi = 1.0f / diag;
+  const float jdi = active ? 1.0f / diag : 0.0f;
   float lam = (active && warm >= 0) ? cfg.warmstart_factor * S.s[O(LAMBDA) + warm] : 0.0f;
-  rhs *= jdi;
+  rhs = active ? rhs * jdi : 0.0f;
+  if (!active) { lo = 0.0f; hi = 0.0f; mu = 0.0f; }
   WSYNC();
   // Delassus column for this lane: Ac[r] = J_lane . W[r] (= A[lane][r] = A[r][lane]), kept in registers
   float Ac[kMaxRows];
@@ -576,12 +598,13 @@ __device__ static int physics_substep(const KParams& P, Shared& S, int lane, boo
 #pragma unroll
   for (int r = 0; r < kMaxRows; r++) {
     Ac[r] = 0.0f;
-    if ((mask >> r) & 1ull) {
+    if ((mask >> r) & 1u) {
       const float* Wr = S.ph.sub.W[r];
       float a = Jb[0] * Wr[0] + Jb[1] * Wr[1] + Jb[2] * Wr[2] + Jb[3] * Wr[3] + Jb[4] * Wr[4] + Jb[5] * Wr[5];
       a += jl[0] * Wr[6 + 3 * leg] + jl[1] * Wr[6 + 3 * leg + 1] + jl[2] * Wr[6 + 3 * leg + 2];
       Ac[r] = a;
-      const float l0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lam), r));
+      SCHED_FENCE();
+      const float l0 = bcast_row(lam, r, sub);
       w += a * l0;  // warm-start contribution
       if (r >= 16 && r < 20 && nrm_slot == r) lam_n = l0;
     }
@@ -592,14 +615,14 @@ __device__ static int physics_substep(const KParams& P, Shared& S, int lane, boo
   for (int it = 0; it < cfg.solver_iters; it++) {
 #pragma unroll
     for (int r = 0; r < kMaxRows; r++) {
-      if ((mask >> r) & 1ull) {
+      if ((mask >> r) & 1u) {
         float dl = rhs - w * jdi;
         const float hi_e = isfric ? mu * lam_n : hi;
         const float lo_e = isfric ? -hi_e : lo;
         float sum = lam + dl;
         sum = sum < lo_e ? lo_e : (sum > hi_e ? hi_e : sum);
         dl = sum - lam;
-        const float d_r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dl), r));
+        const float d_r = bcast_row(dl, r, sub);
         if (lane == r) lam = sum;
         w += Ac[r] * d_r;
         if (r >= 16 && r < 20 && nrm_slot == r) lam_n += d_r;
@@ -615,8 +638,8 @@ __device__ static int physics_substep(const KParams& P, Shared& S, int lane, boo
     const int kk = lane < 18 ? lane : 0;
 #pragma unroll
     for (int r = 0; r < kMaxRows; r++) {
-      if ((mask >> r) & 1ull) {
-        const float lr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lam), r));
+      if ((mask >> r) & 1u) {
+        const float lr = bcast_row(lam, r, sub);
         du += S.ph.sub.W[r][kk] * lr;
       }
     }
@@ -710,13 +733,14 @@ __device__ static void sample_poses(const KParams& P, Shared& S, int lane, int n
   const DevClip& c = P.tab->clip[geti(S, O(CLIP_ID))];
   const bool warm_ep = geti(S, O(WARMUP)) != 0;
   Sample sm = clip_index(c, lane < nt ? t_lane : 0.0f);
+  if (lane < nt) { S.red[2 * lane] = __int_as_float(sm.f0); S.red[2 * lane + 1] = __int_as_float(sm.f1); }
+  WSYNC();
   for (int e = 0; e < 2 * nt; e++) {
-    const int src = e >> 1;
-    const int f = (e & 1) ? __shfl(sm.f1, src) : __shfl(sm.f0, src);
+    const int f = __float_as_int(S.red[e]);
     if (lane < 19) S.ph.end.frames[e][lane] = c.frames[f * 19 + lane];
   }
   if (with_vel) {
-    const int f0 = __shfl(sm.f0, 0), f1 = __shfl(sm.f1, 0);
+    const int f0 = __float_as_int(S.red[0]), f1 = __float_as_int(S.red[1]);
     if (lane < 18) { S.ph.end.fvel[0][lane] = c.vels[f0 * 18 + lane]; S.ph.end.fvel[1][lane] = c.vels[f1 * 18 + lane]; }
   }
   if (lane < 19) S.ph.end.frames[10][lane] = c.frames[lane];  // frame 0 (warm-up heading)
@@ -956,7 +980,7 @@ __device__ static void sensors_push(Shared& S, int lane, bool fill_all) {
 // reset of one robot (wrapper_env.py:87-107 -> quadruped_gym_env.py:63-104 -> minitaur.py:232-278 ->
 // imitation_task.py:166-199); SURVEY.md Appendix A.2.  Writes the 160-d observation into obs (LDS).
 // ================================================================================================
-__device__ static void reset_robot(const KParams& P, float* rec, Shared& S, int lane, long long total_step_count, float* obs) {
+__device__ static void reset_robot(const KParams& P, float* rec, Shared& S, int lane, bool valid, long long total_step_count, float* obs) {
   const orr_config& c = P.cfg;
   const uint32_t robot = (uint32_t)geti(S, O(ROBOT_INDEX)), ep = (uint32_t)geti(S, O(EPISODE_IDX));
   // 1-2. default pose at the grid slot, counters, ring, filter (minitaur.py:246-268, 465-483)
@@ -979,7 +1003,7 @@ __device__ static void reset_robot(const KParams& P, float* rec, Shared& S, int 
     S.s[O(EP_RETURN)] = 0.0f;
   }
   WSYNC();
-  receive_obs(rec, S, lane);  // ring entry #1
+  receive_obs(rec, S, lane, valid);  // ring entry #1
   // 3. sensor histories <- 3 copies of the current readings (minitaur.py:270-271; sensor_wrappers.py:122-129)
   ctrl_obs(P, rec, S, lane);
   sensors_push(S, lane, true);
@@ -1043,54 +1067,63 @@ __device__ static void reset_robot(const KParams& P, float* rec, Shared& S, int 
   if (lane < 4) S.s[O(QUAT) + lane] = S.ph.end.pose[0][3 + lane];
   if (lane < 12) { S.s[O(Q) + lane] = S.ph.end.pose[0][7 + lane]; S.s[O(QD) + lane] = S.ph.end.vel[6 + lane]; }
   WSYNC();
-  receive_obs(rec, S, lane);  // ring entry #2 (imitation_task.py:792)
+  receive_obs(rec, S, lane, valid);  // ring entry #2 (imitation_task.py:792)
   // 7. observation = histories from step 3 + target observation (quadruped_gym_env.py:100-102; wrapper_env.py:101-105)
   if (lane == 0) seti(S, O(MAX_EP_STEPS), time_limit(c, total_step_count));
   if (lane < 12) obs[lane] = S.s[O(IMU_HIST) + lane];
-  if (lane < 36) { obs[12 + lane] = S.s[O(LASTACT_HIST) + lane]; obs[48 + lane] = S.s[O(MOTORANG_HIST) + lane]; }
+  for (int i = lane; i < 36; i += kLanes) { obs[12 + i] = S.s[O(LASTACT_HIST) + i]; obs[48 + i] = S.s[O(MOTORANG_HIST) + i]; }
   target_obs(P, rec, S, lane, obs + ORR_PROPRIO_DIM);
 }
 
 // ================================================================================================
 // kernels
 // ================================================================================================
+// lane group bookkeeping shared by the kernels: `sub` = which robot of this wave, `lane` = lane within the robot
+#define ORR_PROLOGUE()                                                                   \
+  __shared__ Shared Sarr[kRPW];                                                          \
+  const int sub = threadIdx.x / kLanes, lane = threadIdx.x % kLanes;                     \
+  Shared& S = Sarr[sub];                                                                 \
+  float* obs = S.ph.end.obs;                                                             \
+  const int robot_raw = blockIdx.x * kRPW + sub;                                         \
+  const bool in_range = robot_raw < P.cfg.num_robots;                                    \
+  const int robot = in_range ? robot_raw : 0; /* a padding lane group shadows robot 0 and never stores */ \
+  float* rec = P.state + (size_t)robot * ORR_STATE_STRIDE
+
 __global__ __launch_bounds__(64) void orr_reset_kernel(KParams P, const uint8_t* mask, float* obs_out) {
-  __shared__ Shared S;
-  float* obs = S.ph.end.obs;
-  const int robot = blockIdx.x, lane = threadIdx.x;
-  if (mask && !mask[robot]) return;
-  float* rec = P.state + (size_t)robot * ORR_STATE_STRIDE;
+  ORR_PROLOGUE();
+  const bool valid = in_range && !(mask && !mask[robot]);
   load_robot(P, rec, S, lane);
   const long long total = P.counters ? P.counters[ORR_CNT_TOTAL_STEP_COUNT] : 0;
-  reset_robot(P, rec, S, lane, total, obs);
+  reset_robot(P, rec, S, lane, valid, total, obs);
   WSYNC();
-  store_robot(rec, S, lane);
-  if (obs_out)
-    for (int i = lane; i < ORR_OBS_DIM; i += 64) obs_out[(size_t)robot * ORR_OBS_DIM + i] = obs[i];
+  store_robot(rec, S, lane, valid);
+  if (obs_out && valid)
+    for (int i = lane; i < ORR_OBS_DIM; i += kLanes) obs_out[(size_t)robot * ORR_OBS_DIM + i] = obs[i];
 }
 
 // mode 0: full env step.  mode 1 (debug / parity of row C): nsub physics sub-steps with the given
 // motor torques (actions = torques), no robot or task logic.
 #ifndef ORR_WAVES_PER_EU
-#define ORR_WAVES_PER_EU 4  // 4096 robots = 4 waves on each of the 1024 SIMDs: the whole batch is resident at once
+#define ORR_WAVES_PER_EU 2  // 4096 robots, two per wave = 2 waves on each of the 1024 SIMDs: the whole batch is resident at once
 #endif
 template <int MODE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PER_EU, 8))) void orr_step_kernel(KParams P, const float* actions, float* obs_out, float* reward_out,
                                                       uint8_t* done_out, int nsub) {
-  __shared__ Shared S;
-  float* obs = S.ph.end.obs;
-  const int robot = blockIdx.x, lane = threadIdx.x;
-  float* rec = P.state + (size_t)robot * ORR_STATE_STRIDE;
+  ORR_PROLOGUE();
+  const bool valid = in_range;
   const orr_config& c = P.cfg;
   load_robot(P, rec, S, lane);
+  // impulse-response table: stale rows are multiplied by zero impulses, so they only have to be finite
+  for (int i = lane; i < kMaxRows * 18; i += kLanes) (&S.ph.sub.W[0][0])[i] = 0.0f;
+  WSYNC();
 
   if (MODE == 1) {
     if (lane < 12) { const int j = S.m.joint_of_motor[lane]; S.tau[j] = S.m.tau_sign[j] * actions[(size_t)robot * 12 + lane]; }
     WSYNC();
     int fall = 0;
-    for (int s = 0; s < nsub; s++) fall = physics_substep(P, S, lane, true);
-    if (lane == 0 && done_out) done_out[robot] = (uint8_t)fall;
-    store_robot(rec, S, lane);
+    for (int s = 0; s < nsub; s++) fall = physics_substep(P, S, lane, sub, true);
+    if (valid && lane == 0 && done_out) done_out[robot] = (uint8_t)fall;
+    store_robot(rec, S, lane, valid);
     return;
   }
 
@@ -1111,10 +1144,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
   }
   WSYNC();
   int fall = 0;
-  for (int sub = 0; sub < c.action_repeat; sub++) {
-    if (sub > 0) ctrl_obs(P, rec, S, lane);
+  for (int sstep = 0; sstep < c.action_repeat; sstep++) {
+    if (sstep > 0) ctrl_obs(P, rec, S, lane);
     if (lane < 12) {
-      const float lerp = (float)(sub + 1) / (float)c.action_repeat;  // process_action (minitaur.py:438-460)
+      const float lerp = (float)(sstep + 1) / (float)c.action_repeat;  // process_action (minitaur.py:438-460)
       const float cur = map_pi(S.co[lane]);
       const float prev = geti(S, O(FILTER_VALID)) ? S.s[O(FILTER_ACTION) + lane] : cur;
       float cmd = prev + lerp * (S.s[O(ACTION) + lane] - prev);
@@ -1128,11 +1161,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
     WSYNC();
     if (lane == 0) {  // robot_step bookkeeping (minitaur.py:287-293)
       seti(S, O(STATE_ACTION_COUNTER), geti(S, O(STATE_ACTION_COUNTER)) + 1);
-      if (sub == c.action_repeat - 1) { seti(S, O(FILTER_VALID), 1); seti(S, O(STEP_COUNTER), geti(S, O(STEP_COUNTER)) + 1); }
+      if (sstep == c.action_repeat - 1) { seti(S, O(FILTER_VALID), 1); seti(S, O(STEP_COUNTER), geti(S, O(STEP_COUNTER)) + 1); }
     }
-    if (sub == c.action_repeat - 1 && lane < 12) S.s[O(FILTER_ACTION) + lane] = S.s[O(ACTION) + lane];
-    fall = physics_substep(P, S, lane, sub == c.action_repeat - 1);
-    receive_obs(rec, S, lane);
+    if (sstep == c.action_repeat - 1 && lane < 12) S.s[O(FILTER_ACTION) + lane] = S.s[O(ACTION) + lane];
+    fall = physics_substep(P, S, lane, sub, sstep == c.action_repeat - 1);
+    receive_obs(rec, S, lane, valid);
   }
   // ---- get_obs: sensors on_step (minitaur.py:295-299) ----
   ctrl_obs(P, rec, S, lane);
@@ -1181,8 +1214,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
     if (pe > c.dist_fail_threshold * c.dist_fail_threshold) reason |= ORR_DONE_ROOT_POS;
     if (fabsf(ang) > c.rot_fail_threshold) reason |= ORR_DONE_ROOT_ROT;
     bool bad = false;
-    if (lane < 37) bad = !(fabsf(S.s[O(POS) + lane]) < 1e30f);
-    if (__ballot(bad) != 0ull) reason |= ORR_DONE_NAN;
+    for (int i = lane; i < 37; i += kLanes) bad = bad || !(fabsf(S.s[O(POS) + i]) < 1e30f);
+    if (((__ballot(bad) >> (sub * kLanes)) & ((1ull << (kLanes - 1)) * 2ull - 1ull)) != 0ull) reason |= ORR_DONE_NAN;
     if (!(fabsf(rew) < 1e30f)) { reason |= ORR_DONE_NAN; rew = 0.0f; }
     const int ep_step = geti(S, O(EP_STEP)) + 1;  // quadruped_gym_env.py:237
     if (ep_step >= geti(S, O(MAX_EP_STEPS))) reason |= ORR_DONE_TIME_LIMIT;
@@ -1195,9 +1228,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
   }
   // observation (wrapper_env.py:109-125)
   if (lane < 12) obs[lane] = S.s[O(IMU_HIST) + lane];
-  if (lane < 36) { obs[12 + lane] = S.s[O(LASTACT_HIST) + lane]; obs[48 + lane] = S.s[O(MOTORANG_HIST) + lane]; }
+  for (int i = lane; i < 36; i += kLanes) { obs[12 + i] = S.s[O(LASTACT_HIST) + i]; obs[48 + i] = S.s[O(MOTORANG_HIST) + i]; }
   target_obs(P, rec, S, lane, obs + ORR_PROPRIO_DIM);
-  if (lane == 0) {
+  if (valid && lane == 0) {
     reward_out[robot] = rew;
     done_out[robot] = reason != 0;
   }
@@ -1206,7 +1239,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
     if (lane == 0) {
       S.s[O(LAST_EP_RETURN)] = S.s[O(EP_RETURN)];
       seti(S, O(LAST_EP_LEN), geti(S, O(EP_STEP)));
-      if (P.counters) {
+      if (P.counters && valid) {
         atomicAdd((unsigned long long*)&P.counters[ORR_CNT_DONE_ACCUM], 1ull);
         const unsigned long long slot = atomicAdd((unsigned long long*)&P.counters[ORR_CNT_EPISODES], 1ull);
         if (P.ep_log && slot < (unsigned long long)P.ep_log_cap) {
@@ -1221,19 +1254,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
     if (c.flags & ORR_FLAG_AUTO_RESET) {
       if (lane == 0) seti(S, O(EPISODE_IDX), geti(S, O(EPISODE_IDX)) + 1);
       WSYNC();
-      reset_robot(P, rec, S, lane, total_snapshot, obs);
+      reset_robot(P, rec, S, lane, valid, total_snapshot, obs);
     }
   }
   WSYNC();
-  store_robot(rec, S, lane);
-  for (int i = lane; i < ORR_OBS_DIM; i += 64) obs_out[(size_t)robot * ORR_OBS_DIM + i] = obs[i];
+  store_robot(rec, S, lane, valid);
+  if (valid)
+    for (int i = lane; i < ORR_OBS_DIM; i += kLanes) obs_out[(size_t)robot * ORR_OBS_DIM + i] = obs[i];
   // the last wave to finish folds this launch's done count into the curriculum counter (wrapper_env.py:82-83)
-  if (P.counters && lane == 0) {
+  if (P.counters && valid && lane == 0) {
     const unsigned long long ticket = atomicAdd((unsigned long long*)&P.counters[ORR_CNT_TICKET], 1ull);
-    if (ticket == (unsigned long long)gridDim.x - 1ull) {
+    if (ticket == (unsigned long long)P.cfg.num_robots - 1ull) {
       const unsigned long long nd = atomicExch((unsigned long long*)&P.counters[ORR_CNT_DONE_ACCUM], 0ull);
       atomicAdd((unsigned long long*)&P.counters[ORR_CNT_TOTAL_STEP_COUNT], nd);
-      atomicAdd((unsigned long long*)&P.counters[ORR_CNT_TOTAL_TIMESTEPS], (unsigned long long)gridDim.x);
+      atomicAdd((unsigned long long*)&P.counters[ORR_CNT_TOTAL_TIMESTEPS], (unsigned long long)P.cfg.num_robots);
       atomicExch((unsigned long long*)&P.counters[ORR_CNT_TICKET], 0ull);
     }
   }
@@ -1430,7 +1464,7 @@ static KParams make_params(const orr_handle* h) {
 
 int32_t orr_reset(orr_handle* h, const uint8_t* mask_dev, float* obs_dev, void* stream) {
   if (!h || !h->state) return fail(-1, "orr_reset: handle not bound");
-  hipLaunchKernelGGL(orr_reset_kernel, dim3(h->cfg.num_robots), dim3(64), 0, (hipStream_t)stream, make_params(h), mask_dev, obs_dev);
+  hipLaunchKernelGGL(orr_reset_kernel, dim3((h->cfg.num_robots + kRPW - 1) / kRPW), dim3(64), 0, (hipStream_t)stream, make_params(h), mask_dev, obs_dev);
   HIPCHK(hipGetLastError(), "orr_reset: launch");
   return 0;
 }
@@ -1438,7 +1472,7 @@ int32_t orr_reset(orr_handle* h, const uint8_t* mask_dev, float* obs_dev, void* 
 int32_t orr_step(orr_handle* h, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev, void* stream) {
   if (!h || !h->state) return fail(-1, "orr_step: handle not bound");
   if (!actions_dev || !obs_dev || !reward_dev || !done_dev) return fail(-1, "orr_step: null buffer");
-  hipLaunchKernelGGL(orr_step_kernel<0>, dim3(h->cfg.num_robots), dim3(64), 0, (hipStream_t)stream, make_params(h), actions_dev,
+  hipLaunchKernelGGL(orr_step_kernel<0>, dim3((h->cfg.num_robots + kRPW - 1) / kRPW), dim3(64), 0, (hipStream_t)stream, make_params(h), actions_dev,
                      obs_dev, reward_dev, done_dev, 0);
   HIPCHK(hipGetLastError(), "orr_step: launch");
   return 0;
@@ -1447,7 +1481,7 @@ int32_t orr_step(orr_handle* h, const float* actions_dev, float* obs_dev, float*
 // parity / debug entry point (not part of the drop-in surface): nsub physics sub-steps with fixed motor torques
 int32_t orr_debug_physics(orr_handle* h, const float* torques_dev, uint8_t* fall_dev, int32_t nsub, void* stream) {
   if (!h || !h->state || !torques_dev) return fail(-1, "orr_debug_physics: bad argument");
-  hipLaunchKernelGGL(orr_step_kernel<1>, dim3(h->cfg.num_robots), dim3(64), 0, (hipStream_t)stream, make_params(h), torques_dev,
+  hipLaunchKernelGGL(orr_step_kernel<1>, dim3((h->cfg.num_robots + kRPW - 1) / kRPW), dim3(64), 0, (hipStream_t)stream, make_params(h), torques_dev,
                      nullptr, nullptr, fall_dev, nsub);
   HIPCHK(hipGetLastError(), "orr_debug_physics: launch");
   return 0;
