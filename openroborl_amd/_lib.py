@@ -38,8 +38,9 @@ def build(force=False, verbose=False):
         return LIB_PATH
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-Wno-unused-value",
            "-o", LIB_PATH, SRC]
-    if os.environ.get("ORR_WAVES_PER_EU"):
-        cmd.insert(-3, "-DORR_WAVES_PER_EU=%d" % int(os.environ["ORR_WAVES_PER_EU"]))
+    for var in ("ORR_WAVES_PER_EU", "ORR_LANES_PER_ROBOT"):      # tuning experiments only
+        if os.environ.get(var):
+            cmd.insert(-3, "-D%s=%d" % (var, int(os.environ[var])))
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

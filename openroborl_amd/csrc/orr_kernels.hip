@@ -216,7 +216,7 @@ __device__ __forceinline__ void pass2_link(Shared& S, int j, bool wr, float Iacc
   float Ut[3], Ub[3];
   if (AX == 0) { Ut[0] = I[0]; Ut[1] = I[3]; Ut[2] = I[4]; Ub[0] = H[0]; Ub[1] = H[1]; Ub[2] = H[2]; }
   else { Ut[0] = I[3]; Ut[1] = I[1]; Ut[2] = I[5]; Ub[0] = H[3]; Ub[1] = H[4]; Ub[2] = H[5]; }
-  const float invD = 1.0f / Ut[AX];
+  const float invD = __builtin_amdgcn_rcpf(Ut[AX]);
   const float u = S.tau[j] - pA[AX];
   const float uD = u * invD;
   if (wr) {
@@ -448,7 +448,7 @@ __device__ __forceinline__ float delta_out(const Shared& S, int j, float ud, flo
 // One physics sub-step.  Returns the fall-proxy flag (wave-uniform) when want_fall.
 __device__ static int physics_substep(const KParams& P, Shared& S, int lane, int sub, bool want_fall) {
   const orr_config& cfg = P.cfg;
-  const float dt = cfg.sim_dt;
+  const float dt = cfg.sim_dt, inv_dt = 1.0f / cfg.sim_dt, erp_dt = cfg.contact_erp / cfg.sim_dt;
   aba_legs(P, S, lane);
   WSYNC();
   if (lane < 18) {
@@ -497,7 +497,7 @@ __device__ static int physics_substep(const KParams& P, Shared& S, int lane, int
     jl[0] = kk == 0 ? sgn : 0.0f; jl[1] = kk == 1 ? sgn : 0.0f; jl[2] = kk == 2 ? sgn : 0.0f;
     const float rel = sgn * S.ustar[6 + j];
     lo = 0.0f; hi = 1e30f;
-    rhs = pen > 0.0f ? -rel - pen / dt : -rel - pen * cfg.contact_erp / dt;
+    rhs = pen > 0.0f ? -rel - pen * inv_dt : -rel - pen * erp_dt;
   } else if (lane < 28) {
     int d;
     if (lane < 20) { leg = lane - 16; d = 0; }
@@ -528,7 +528,7 @@ __device__ static int physics_substep(const KParams& P, Shared& S, int lane, int
     warm = 3 * leg + d;
     if (d == 0) {
       lo = 0.0f; hi = 1e30f;
-      rhs = dist > 0.0f ? -rel - dist / dt : -rel - dist * cfg.contact_erp / dt;
+      rhs = dist > 0.0f ? -rel - dist * inv_dt : -rel - dist * erp_dt;
     } else {
       nrm_slot = 16 + leg;
       mu = S.s[O(FOOT_MU)] * cfg.plane_friction;  // combined friction = product of the two coefficients
@@ -587,7 +587,7 @@ __device__ static int physics_substep(const KParams& P, Shared& S, int lane, int
       for (int i = 0; i < 12; i++) S.ph.sub.W[lane][6 + i] = mq[i];
     }
   }
-  const float jdi = active ? 1.0f / diag : 0.0f;
+  const float jdi = active ? __builtin_amdgcn_rcpf(diag) : 0.0f;
   float lam = (active && warm >= 0) ? cfg.warmstart_factor * S.s[O(LAMBDA) + warm] : 0.0f;
   rhs = active ? rhs * jdi : 0.0f;
   if (!active) { lo = 0.0f; hi = 0.0f; mu = 0.0f; }
@@ -611,17 +611,16 @@ __device__ static int physics_substep(const KParams& P, Shared& S, int lane, int
   }
   // projected Gauss-Seidel (btMultiBodyConstraintSolver::solveSingleIteration), Delassus form:
   // lane i keeps lambda_i and w_i = (A lambda)_i; one readlane per row update
-  const bool isfric = nrm_slot >= 0;
+  // bounds as (constant part) + mu * lambda_normal: friction rows have zero constant part, the others mu = 0
+  const float mu_e = nrm_slot >= 0 ? mu : 0.0f;
+  const float hi_c = nrm_slot >= 0 ? 0.0f : hi, lo_c = nrm_slot >= 0 ? 0.0f : lo;
   for (int it = 0; it < cfg.solver_iters; it++) {
 #pragma unroll
     for (int r = 0; r < kMaxRows; r++) {
       if ((mask >> r) & 1u) {
-        float dl = rhs - w * jdi;
-        const float hi_e = isfric ? mu * lam_n : hi;
-        const float lo_e = isfric ? -hi_e : lo;
-        float sum = lam + dl;
-        sum = sum < lo_e ? lo_e : (sum > hi_e ? hi_e : sum);
-        dl = sum - lam;
+        const float hi_e = fmaf(mu_e, lam_n, hi_c), lo_e = fmaf(-mu_e, lam_n, lo_c);
+        const float sum = __builtin_amdgcn_fmed3f(lam + (rhs - w * jdi), lo_e, hi_e);
+        const float dl = sum - lam;
         const float d_r = bcast_row(dl, r, sub);
         if (lane == r) lam = sum;
         w += Ac[r] * d_r;
