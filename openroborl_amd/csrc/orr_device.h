@@ -300,12 +300,28 @@ __device__ __forceinline__ float bcast_row(float x, int r, int sub) {
   return __int_as_float(sub ? b : a);
 }
 
-// sine / cosine of a joint angle
-__device__ __forceinline__ void joint_sincos(float a, float* s, float* c) {
-#ifdef ORR_FAST_TRIG
-  *s = __sinf(a); *c = __cosf(a);  // v_sin_f32 / v_cos_f32: ~1e-6 absolute error
+// sine / cosine of a joint angle (|a| is a few radians at most).  Cody-Waite reduction to [-pi/4, pi/4] with a
+// two-part pi/2 and minimax polynomials (~25 instructions, error < 1e-7); optional, see below.
+__device__ __forceinline__ void joint_sincos(float a, float* sn, float* cs) {
+#ifndef ORR_POLY_TRIG  // measured: no speed difference at kernel level, and libm keeps the sub-step parity at 2e-5
+  sincosf(a, sn, cs);
 #else
-  sincosf(a, s, c);
+  const float k = rintf(a * 0.63661977236758134f);       // a * 2/pi
+  float r = fmaf(-k, 1.57079625129699707031f, a);         // pi/2 high part (exact in float)
+  r = fmaf(-k, 7.54978941586159635335e-08f, r);           // pi/2 low part
+  const float r2 = r * r;
+  // sin(r), |r| <= pi/4
+  float ps = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+  ps = fmaf(ps, r2, -1.6666654611e-1f);
+  const float s = fmaf(ps * r2, r, r);
+  // cos(r)
+  float pc = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+  pc = fmaf(pc, r2, 4.166664568298827e-2f);
+  const float c = fmaf(pc * r2, r2, fmaf(r2, -0.5f, 1.0f));
+  const int q = (int)k & 3;
+  const float ss = (q & 1) ? c : s, cc = (q & 1) ? s : c;
+  *sn = (q & 2) ? -ss : ss;
+  *cs = ((q + 1) & 2) ? -cc : cc;
 #endif
 }
 

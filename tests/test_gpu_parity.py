@@ -249,3 +249,24 @@ def test_masked_reset_and_legacy_protocol():
     assert torch.equal(before[1], after[1]) and torch.equal(before[4], after[4])
     assert not torch.equal(before[0], after[0])
     env.close()
+
+
+def test_odd_robot_count_padding_lane_group():
+    """Two robots share a wavefront; with an odd N the last wave carries a padding lane group that must not
+    write anything (it shadows robot 0)."""
+    import torch
+    for n in (1, 5):
+        env, orc = make_pair("laikago", n=n, seed=4)
+        og = env.reset().cpu().numpy()
+        oo = orc.reset()
+        np.testing.assert_allclose(og, oo, atol=2e-6)
+        orc.state[:] = gpu_state64(env)
+        a = np.random.RandomState(n).uniform(-0.2, 0.2, (n, 12)).astype(np.float32)
+        for _ in range(3):
+            og, rg, dg, _ = env.step(torch.from_numpy(a).to(env.device))
+            oo, ro, do = orc.step(a.astype(np.float64))
+        np.testing.assert_allclose(rg.cpu().numpy(), ro, atol=5e-3)
+        np.testing.assert_allclose(og.cpu().numpy()[:, 84:], oo[:, 84:], atol=1e-3)
+        torch.cuda.synchronize()
+        assert env.counters.cpu().numpy()[_abi.CNT_TOTAL_TIMESTEPS] == 3 * n
+        env.close(); orc.close()
