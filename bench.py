@@ -37,7 +37,12 @@ def cpu_baseline(env, seconds_target=12.0):
     """Time the CPU oracle (kind "port") on the host cores on a bounded sample of the same workload."""
     import numpy as np
     from tests import oracle_lib as ol
-    cores = os.cpu_count() or 1
+    # a one-GPU box owns a 16-core share of the host (more threads only oversubscribe it)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, int(os.environ.get("ORR_CPU_BASELINE_THREADS", "16"))))
     n = 32 * cores
     orc = ol.OracleEnv(env.cfg, env.models, env.clips, n, robot_type=0, clip_id=0, threads=cores)
     obs = orc.reset()

@@ -85,6 +85,10 @@ class VecQuadrupedEnv(object):
             raise RuntimeError("VecQuadrupedEnv needs a ROCm GPU (the HIP path has no CPU fallback)")
         self.L = _lib.load()
         self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise ValueError("device must be a cuda (ROCm) device")
+        if self.device.index is not None:
+            torch.cuda.set_device(self.device)   # the C-ABI library allocates / launches on the current HIP device
         params = {}
         if task_name is not None:
             params = cfgmod.load_training_params(task_name, training_yaml)

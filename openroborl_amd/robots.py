@@ -176,7 +176,9 @@ def mini_cheetah():
         lo_m=0.064, lo_com=[0.0, 0.0, -0.061], lo_I=[0.000245, 0.000248, 0.000006],
         toe_m=0.03, toe_r=0.0175,
         limits=[(-1e9, 1e9)] * 3,                                            # continuous joints
-        chassis_half=[0.19, 0.049, 0.05], hip_r=0.04, knee_r=0.02, foot_friction=1.0)
+        # knee proxy radius 0: with a finite knee sphere the shipped minicheetah_trot policy is stopped by knee
+        # "contacts" within ~10 steps while still upright; the thigh/shank of this robot are thin plates
+        chassis_half=[0.19, 0.049, 0.05], hip_r=0.04, knee_r=0.0, foot_friction=1.0)
 
 
 ROBOTS = {"laikago": laikago, "mini_cheetah": mini_cheetah}

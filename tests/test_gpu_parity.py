@@ -270,3 +270,37 @@ def test_odd_robot_count_padding_lane_group():
         torch.cuda.synchronize()
         assert env.counters.cpu().numpy()[_abi.CNT_TOTAL_TIMESTEPS] == 3 * n
         env.close(); orc.close()
+
+
+def test_rollout_across_cycle_wrap_tracks_oracle():
+    """25 env steps (> one pace cycle of 19.2 steps) so every robot passes the cycle-sync re-anchoring of
+    ImitationTask._sync_ref_origin (imitation_task.py:751-754,1047-1053) at least once."""
+    import torch
+    n = 32
+    env, orc = make_pair("laikago", n=n, seed=13)
+    env.reset(); orc.reset()
+    orc.state[:] = gpu_state64(env)
+    W = np.load(os.path.join(ol.GOLDEN, "policy_laikago_pace.npz"))
+
+    def policy(o):
+        h = np.maximum(o @ W["model__pi_fc0__w_0"] + W["model__pi_fc0__b_0"], 0)
+        h = np.maximum(h @ W["model__pi_fc1__w_0"] + W["model__pi_fc1__b_0"], 0)
+        return np.clip(h @ W["model__pi__w_0"] + W["model__pi__b_0"], -2 * np.pi, 2 * np.pi)
+    og = env.obs.cpu().numpy().astype(np.float64)
+    origin0 = orc.field("ORIGIN_POS").copy()
+    for k in range(25):
+        a = policy(og).astype(np.float32)         # same actions on both sides (driven by the GPU observation)
+        o_t, rg, dg, _ = env.step(torch.from_numpy(a).to(env.device))
+        oo, ro, do = orc.step(a.astype(np.float64))
+        og = o_t.cpu().numpy().astype(np.float64)
+    moved = np.abs(orc.field("ORIGIN_POS") - origin0).max(axis=1) > 1e-6
+    warm = orc.field("WARMUP")[:, 0] > 0
+    assert moved[~warm].all()                      # the wrap happened for every non-warm-up robot
+    g = gpu_state64(env)
+    for name, tol in (("ORIGIN_POS", 2e-2), ("POS", 2e-2), ("REF_POSE", 2e-2)):
+        sl = env.layout.sl(name)
+        assert np.median(np.abs(g[:, sl] - orc.state[:, sl])) < tol / 10, name
+        assert np.abs(g[:, sl] - orc.state[:, sl]).max() < tol * 5, name
+    np.testing.assert_allclose(rg.cpu().numpy(), ro, atol=0.1)
+    assert (dg.cpu().numpy().astype(bool) == do).all()
+    env.close(); orc.close()
