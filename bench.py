@@ -138,13 +138,20 @@ def main():
     achieved = B_ALG * n / (kern_ms * 1e-3) / 1e9
 
     if rank == 0:
-        traffic = None
+        # PMC numbers come from a separate rocprofv3 --pmc run of this same command (tools/profile_gpu.sh), committed
+        # under profiles/; FETCH_SIZE is taken as reported (4-byte-per-lane rows, the x2 wide-read correction does not apply)
+        traffic, valu = None, {}
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                d = json.load(open(pmc))
+                traffic = d.get("hbm_bytes_per_launch")
+                waves = d["SQ_WAVES"]["mean_per_launch"]
+                valu = {"valu_insts_per_robot_step": d["SQ_INSTS_VALU"]["mean_per_launch"] / n,
+                        "valu_active_frac_of_wave_cycles": d["SQ_ACTIVE_INST_VALU"]["mean_per_launch"] / d["SQ_WAVE_CYCLES"]["mean_per_launch"],
+                        "waves_per_simd": waves / 1024.0}
             except Exception:
-                traffic = None
+                traffic, valu = None, {}
         out = {
             "metric": "env steps/sec at N parallel robots", "value": world * n * args.steps / elapsed, "unit": "env steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -158,6 +165,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "orr_step_kernel<0>", "kernel_ms": kern_ms, "alg_bytes_per_robot_step": B_ALG,
+                         "pmc": valu,
                          "note": "VALU/latency-bound serial chain (33 x (ABA + 9 PGS sweeps)); HBM fraction is reported "
                                  "because the north star asks for it, see DESIGN.md section 6"},
         }
