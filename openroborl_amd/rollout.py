@@ -1,0 +1,64 @@
+"""Device-resident rollout buffers + per-robot GAE.
+
+Replaces the host-side trajectory generator (agents/imitation_runners.py:22-208) and
+`add_vtarg_and_adv` (agents/ppo_imitation.py:68-93) plus the per-robot advantage normalisation
+(ppo_imitation.py:329-338) with [T, N] tensors that never leave the GPU:
+
+  obs [T,N,160], actions [T,N,12], rewards [T,N], dones [T,N], vpred [T,N], next_vpred [T,N]
+
+Semantics kept from the reference: gamma = lam = 0.95 (run.py:113,120); the value after a finished episode is
+0 and -- the reference's quirk -- so is the bootstrap value at the end of a segment
+(imitation_runners.py:98-100 `last_vpred = 0.0`); advantages are standardised per robot over the segment.
+Deliberate divergences: robots reset individually (auto-reset inside env.step) instead of the whole env
+resetting when any robot is done, and the GAE recursion uses each robot's own done flags (the reference
+indexes `episode_starts[(step*num_robot+i) + (1+i)]`, ppo_imitation.py:88, which reads a neighbouring
+robot's flag).
+"""
+
+
+def collect_rollout(env, policy, horizon, obs=None, deterministic=False, generator=None):
+    """Run `horizon` env steps of all robots.  Returns a dict of [T, N, ...] tensors + the final observation."""
+    t = env.torch
+    n = env.num_robot
+    dev = env.device
+    if obs is None:
+        obs = env.reset()
+    buf = {
+        "obs": t.empty((horizon, n, obs.shape[1]), device=dev), "actions": t.empty((horizon, n, 12), device=dev),
+        "rewards": t.empty((horizon, n), device=dev), "dones": t.empty((horizon, n), dtype=t.bool, device=dev),
+        "vpred": t.empty((horizon, n), device=dev),
+    }
+    for k in range(horizon):
+        clipped, raw, v = policy.act(obs, deterministic=deterministic, generator=generator)
+        buf["obs"][k].copy_(obs)
+        buf["actions"][k].copy_(raw)
+        buf["vpred"][k].copy_(v)
+        obs, rew, done, _ = env.step(clipped.contiguous())
+        buf["rewards"][k].copy_(rew)
+        buf["dones"][k].copy_(done.bool())
+    buf["last_obs"] = obs
+    return buf
+
+
+def gae(rewards, vpred, dones, gamma=0.95, lam=0.95, bootstrap=None):
+    """Per-robot GAE(lambda) on [T, N] tensors.  next value = vpred[t+1] unless the episode ended at t (then 0);
+    at the end of the segment `bootstrap` ([N], default 0 like the reference)."""
+    import torch
+    T, n = rewards.shape
+    nonterminal = (~dones).to(rewards.dtype)
+    nxt = torch.empty_like(vpred)
+    nxt[:-1] = vpred[1:]
+    nxt[-1] = 0.0 if bootstrap is None else bootstrap
+    nxt = nxt * nonterminal
+    delta = rewards + gamma * nxt - vpred
+    adv = torch.empty_like(rewards)
+    last = torch.zeros(n, dtype=rewards.dtype, device=rewards.device)
+    for k in range(T - 1, -1, -1):
+        last = delta[k] + gamma * lam * nonterminal[k] * last
+        adv[k] = last
+    return adv, adv + vpred
+
+
+def normalize_per_robot(adv, eps=0.0):
+    """ppo_imitation.py:329-338: (a - mean) / std over each robot's own samples (population std, like numpy)."""
+    return (adv - adv.mean(dim=0, keepdim=True)) / (adv.std(dim=0, unbiased=False, keepdim=True) + eps)

@@ -1,0 +1,71 @@
+"""CPU tests of the "next" rows: batched policy MLP and device-side GAE."""
+import os
+
+import numpy as np
+import torch
+
+from openroborl_amd import policy as pol, rollout
+from tests import oracle_lib as ol
+
+
+def test_policy_matches_numpy_mlp_on_shipped_weights():
+    path = os.path.join(ol.GOLDEN, "policy_laikago_pace.npz")
+    p = pol.MLPPolicy.from_file(path, "cpu")
+    W = np.load(path)
+    obs = np.random.RandomState(0).randn(17, 160).astype(np.float32)
+    h = np.maximum(obs @ W["model__pi_fc0__w_0"] + W["model__pi_fc0__b_0"], 0)
+    h = np.maximum(h @ W["model__pi_fc1__w_0"] + W["model__pi_fc1__b_0"], 0)
+    mu = h @ W["model__pi__w_0"] + W["model__pi__b_0"]
+    a, raw, v = p.act(torch.from_numpy(obs), deterministic=True)
+    np.testing.assert_allclose(raw.numpy(), mu, atol=2e-4, rtol=1e-4)
+    assert a.abs().max() <= 2 * np.pi + 1e-6 and v.shape == (17,)
+    g = torch.Generator().manual_seed(0)
+    a2, raw2, _ = p.act(torch.from_numpy(obs), generator=g)
+    assert abs((raw2 - raw).std().item() - pol.PI_STD) < 0.02          # fixed std 0.125 (imitation_policies.py:106)
+    lp = p.log_prob(torch.from_numpy(obs), raw)
+    np.testing.assert_allclose(lp.numpy(), 12 * (-0.5 * np.log(2 * np.pi * pol.PI_STD ** 2)), rtol=1e-5)
+
+
+def test_gae_matches_reference_loop():
+    rng = np.random.RandomState(1)
+    T, n, gamma, lam = 40, 5, 0.95, 0.95
+    rew = rng.rand(T, n).astype(np.float32)
+    vp = rng.randn(T, n).astype(np.float32)
+    done = rng.rand(T, n) < 0.1
+    adv, ret = rollout.gae(torch.from_numpy(rew), torch.from_numpy(vp), torch.from_numpy(done), gamma, lam)
+    exp = np.zeros((T, n), dtype=np.float64)
+    for i in range(n):
+        last = 0.0
+        for k in reversed(range(T)):
+            nonterm = 0.0 if done[k, i] else 1.0
+            nxt = (vp[k + 1, i] if k + 1 < T else 0.0) * nonterm      # 0 after an episode end and at the segment end
+            delta = rew[k, i] + gamma * nxt - vp[k, i]
+            last = delta + gamma * lam * nonterm * last
+            exp[k, i] = last
+    np.testing.assert_allclose(adv.numpy(), exp, atol=1e-4)
+    np.testing.assert_allclose(ret.numpy(), exp + vp, atol=1e-4)
+    nrm = rollout.normalize_per_robot(adv)
+    np.testing.assert_allclose(nrm.mean(dim=0).numpy(), 0, atol=1e-5)
+    np.testing.assert_allclose(nrm.std(dim=0, unbiased=False).numpy(), 1, atol=1e-4)
+
+
+def test_collect_rollout_with_a_fake_env():
+    class FakeEnv(object):
+        torch = torch
+        num_robot = 3
+        device = torch.device("cpu")
+
+        def __init__(self):
+            self.k = 0
+
+        def reset(self):
+            return torch.zeros(3, 160)
+
+        def step(self, a):
+            self.k += 1
+            return torch.full((3, 160), float(self.k)), torch.full((3,), 0.5), torch.tensor([0, 1, 0], dtype=torch.uint8), {}
+    p = pol.MLPPolicy.from_file(os.path.join(ol.GOLDEN, "policy_laikago_pace.npz"), "cpu")
+    buf = rollout.collect_rollout(FakeEnv(), p, horizon=4, deterministic=True)
+    assert buf["obs"].shape == (4, 3, 160) and buf["actions"].shape == (4, 3, 12)
+    assert torch.equal(buf["obs"][2], torch.full((3, 160), 2.0)) and buf["dones"][:, 1].all() and not buf["dones"][:, 0].any()
+    assert torch.equal(buf["last_obs"], torch.full((3, 160), 4.0))
