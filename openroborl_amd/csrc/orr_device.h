@@ -38,11 +38,11 @@
 namespace orr {
 
 #ifndef ORR_LANES_PER_ROBOT
-#define ORR_LANES_PER_ROBOT 32
+#define ORR_LANES_PER_ROBOT 16
 #endif
-constexpr int kLanes = ORR_LANES_PER_ROBOT;  // lanes of a wavefront that serve one robot (32 -> two robots per wave)
+constexpr int kLanes = ORR_LANES_PER_ROBOT;  // lanes of a wavefront that serve one robot (16 -> four robots per wave)
 constexpr int kRPW = 64 / kLanes;            // robots per wavefront
-static_assert(kLanes == 32 || kLanes == 64, "rows need 28 lanes per robot");
+static_assert(kLanes == 16 || kLanes == 32 || kLanes == 64, "a robot needs 16 row lanes");
 constexpr int kMaxRows = 28;  // 4 knee-friction + <=12 joint-limit + 12 contact rows
 constexpr int kHead = 320;    // words of the state record staged in LDS (everything before the ring)
 
@@ -292,12 +292,18 @@ __device__ __forceinline__ void symv(const float S[6], const float v[3], float o
   o[0] = a; o[1] = b; o[2] = c;
 }
 
-// value of x in lane r of the robot's lane group (r is a compile-time constant at every call site)
+// value of x in lane r (< 16, compile-time constant at every call site) of this robot's lane group
 __device__ __forceinline__ float bcast_row(float x, int r, int sub) {
   const int v = __float_as_int(x);
   if (kRPW == 1) return __int_as_float(__builtin_amdgcn_readlane(v, r));
-  const int a = __builtin_amdgcn_readlane(v, r), b = __builtin_amdgcn_readlane(v, r + 32);
-  return __int_as_float(sub ? b : a);
+  if (kRPW == 2) {
+    const int a = __builtin_amdgcn_readlane(v, r), b = __builtin_amdgcn_readlane(v, r + 32);
+    return __int_as_float(sub ? b : a);
+  }
+  const int a0 = __builtin_amdgcn_readlane(v, r), a1 = __builtin_amdgcn_readlane(v, r + 16);
+  const int a2 = __builtin_amdgcn_readlane(v, r + 32), a3 = __builtin_amdgcn_readlane(v, r + 48);
+  const int lo = (sub & 1) ? a1 : a0, hi = (sub & 1) ? a3 : a2;
+  return __int_as_float((sub & 2) ? hi : lo);
 }
 
 // sine / cosine of a joint angle (|a| is a few radians at most).  Cody-Waite reduction to [-pi/4, pi/4] with a

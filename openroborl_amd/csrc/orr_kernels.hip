@@ -59,10 +59,10 @@ __device__ static void ctrl_obs(const KParams& P, const float* rec, Shared& S, i
     if (n + 1 >= len) { k0 = k1 = len - 1; }
     else { k0 = n; k1 = n + 1; al = (lat - n * dt) / dt; }
   }
-  if (lane < 19) {
-    int i0 = (head - k0 + 2 * ORR_RING_DEPTH) % ORR_RING_DEPTH, i1 = (head - k1 + 2 * ORR_RING_DEPTH) % ORR_RING_DEPTH;
-    float e0 = rec[O(RING) + i0 * ORR_RING_ENTRY + lane], e1 = rec[O(RING) + i1 * ORR_RING_ENTRY + lane];
-    S.co[lane] = (k0 == k1) ? e0 : (1.0f - al) * e0 + al * e1;
+  const int i0 = (head - k0 + 2 * ORR_RING_DEPTH) % ORR_RING_DEPTH, i1 = (head - k1 + 2 * ORR_RING_DEPTH) % ORR_RING_DEPTH;
+  for (int i = lane; i < 19; i += kLanes) {
+    float e0 = rec[O(RING) + i0 * ORR_RING_ENTRY + i], e1 = rec[O(RING) + i1 * ORR_RING_ENTRY + i];
+    S.co[i] = (k0 == k1) ? e0 : (1.0f - al) * e0 + al * e1;
   }
   WSYNC();
 }
@@ -76,16 +76,18 @@ __device__ static void receive_obs(float* rec, Shared& S, int lane, bool valid) 
   qinv(rel, ri);
   q_to_mat(ri, Rm);
   mv3(Rm, &S.s[O(ANGVEL)], rate);  // get_true_base_rpy_rate (minitaur.py:640-672)
-  float val = 0.0f;
-  if (lane < 12) {
-    int j = S.m.joint_of_motor[lane];
-    val = (S.s[O(Q) + j] - S.m.motor_offset[lane]) * S.m.motor_dir[lane];  // get_true_motor_angles (:543-553)
-  } else if (lane < 16) {
-    val = lane == 12 ? rel[0] : (lane == 13 ? rel[1] : (lane == 14 ? rel[2] : rel[3]));
-  } else if (lane < 19) {
-    val = lane == 16 ? rate[0] : (lane == 17 ? rate[1] : rate[2]);
+  for (int i = lane; i < ORR_RING_ENTRY; i += kLanes) {
+    float val = 0.0f;
+    if (i < 12) {
+      int j = S.m.joint_of_motor[i];
+      val = (S.s[O(Q) + j] - S.m.motor_offset[i]) * S.m.motor_dir[i];  // get_true_motor_angles (:543-553)
+    } else if (i < 16) {
+      val = i == 12 ? rel[0] : (i == 13 ? rel[1] : (i == 14 ? rel[2] : rel[3]));
+    } else if (i < 19) {
+      val = i == 16 ? rate[0] : (i == 17 ? rate[1] : rate[2]);
+    }
+    if (valid) rec[O(RING) + head * ORR_RING_ENTRY + i] = val;
   }
-  if (valid && lane < ORR_RING_ENTRY) rec[O(RING) + head * ORR_RING_ENTRY + lane] = val;
   WSYNC();
   if (lane == 0) {
     seti(S, O(RING_HEAD), head);
@@ -445,15 +447,152 @@ __device__ __forceinline__ float delta_out(const Shared& S, int j, float ud, flo
   return qdd;
 }
 
+// One constraint row (state of a row lane for one of its two banks)
+struct Row {
+  bool active;
+  int leg, nrm_slot, warm;
+  float Jb[6], jl[3];          // Jacobian: base part (world angular, linear) and the 3 joints of `leg`
+  float rhs, jdi, lam, w, lam_n;
+  float lo_c, hi_c, mu_e;      // bounds = constant part -/+ mu_e * lambda_normal
+};
+
+__device__ __forceinline__ float row_dot(const Row& R, const float* Wr) {
+  float a = R.Jb[0] * Wr[0] + R.Jb[1] * Wr[1] + R.Jb[2] * Wr[2] + R.Jb[3] * Wr[3] + R.Jb[4] * Wr[4] + R.Jb[5] * Wr[5];
+  a += R.jl[0] * Wr[6 + 3 * R.leg] + R.jl[1] * Wr[6 + 3 * R.leg + 1] + R.jl[2] * Wr[6 + 3 * R.leg + 2];
+  return a;
+}
+
+// Jacobian, right-hand side (not yet scaled by 1/diag) and bounds of row slot `slot`
+__device__ __forceinline__ void row_setup(const Shared& S, const orr_config& cfg, int slot, bool enable, float dt, float inv_dt,
+                                          float erp_dt, Row& R) {
+  R.active = false; R.leg = 0; R.nrm_slot = -1; R.warm = -1;
+#pragma unroll
+  for (int i = 0; i < 6; i++) R.Jb[i] = 0.0f;
+  R.jl[0] = R.jl[1] = R.jl[2] = 0.0f;
+  R.rhs = 0.0f; R.jdi = 0.0f; R.lam = 0.0f; R.w = 0.0f; R.lam_n = 0.0f;
+  float lo = 0.0f, hi = 0.0f, mu = 0.0f;
+  if (slot < 4) {
+    R.leg = slot;
+    const float fr = S.s[O(KNEE_FRICTION) + R.leg];
+    R.active = fr > 0.0f;
+    R.jl[2] = 1.0f;
+    lo = -fr * dt; hi = fr * dt;
+    R.rhs = -S.ustar[6 + 3 * R.leg + 2];
+  } else if (slot < 16) {
+    const int j = slot - 4;
+    R.leg = j / 3;
+    const int kk = j - 3 * R.leg;
+    const float a = S.m.jdir[j] * (S.s[O(Q) + j] - S.m.joff[j]);
+    const float pen_lo = a - S.m.joint_lo[j], pen_hi = S.m.joint_hi[j] - a;
+    const bool use_lo = pen_lo < cfg.limit_activation;
+    const bool use_hi = (!use_lo) && pen_hi < cfg.limit_activation;
+    R.active = use_lo || use_hi;
+    const float sgn = use_lo ? 1.0f : -1.0f, pen = use_lo ? pen_lo : pen_hi;
+    R.jl[0] = kk == 0 ? sgn : 0.0f; R.jl[1] = kk == 1 ? sgn : 0.0f; R.jl[2] = kk == 2 ? sgn : 0.0f;
+    const float rel = sgn * S.ustar[6 + j];
+    lo = 0.0f; hi = 1e30f;
+    R.rhs = pen > 0.0f ? -rel - pen * inv_dt : -rel - pen * erp_dt;
+  } else {
+    int d;
+    if (slot < 20) { R.leg = slot - 16; d = 0; }
+    else { R.leg = (slot - 20) >> 1; d = 1 + ((slot - 20) & 1); }
+    const int leg = R.leg;
+    const LinkCache& Lb = S.lc[3 * leg + 2];
+    float cw[3];
+    mv3(Lb.Rw, S.m.toe_pos[leg], cw);
+    cw[0] += Lb.ow[0]; cw[1] += Lb.ow[1]; cw[2] += Lb.ow[2];
+    const float dist = cw[2] - S.m.toe_radius;
+    R.active = dist < cfg.contact_margin;
+    const float Pw[3] = {cw[0], cw[1], cw[2] - S.m.toe_radius};
+    const float dir[3] = {d == 1 ? 1.0f : 0.0f, d == 2 ? 1.0f : 0.0f, d == 0 ? 1.0f : 0.0f};
+    float rr[3] = {Pw[0] - S.s[O(POS)], Pw[1] - S.s[O(POS) + 1], Pw[2] - S.s[O(POS) + 2]};
+    cross3(rr, dir, &R.Jb[0]);
+    R.Jb[3] = dir[0]; R.Jb[4] = dir[1]; R.Jb[5] = dir[2];
+    float rel = R.Jb[0] * S.ustar[0] + R.Jb[1] * S.ustar[1] + R.Jb[2] * S.ustar[2] + R.Jb[3] * S.ustar[3] + R.Jb[4] * S.ustar[4] + R.Jb[5] * S.ustar[5];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const LinkCache& L = S.lc[3 * leg + k];
+      const int ax = k == 0 ? 0 : 1;  // world joint axis = column ax of Rw
+      const float axw[3] = {L.Rw[ax], L.Rw[3 + ax], L.Rw[6 + ax]};
+      float cr[3];
+      rr[0] = Pw[0] - L.ow[0]; rr[1] = Pw[1] - L.ow[1]; rr[2] = Pw[2] - L.ow[2];
+      cross3(axw, rr, cr);
+      R.jl[k] = dot3(dir, cr);
+      rel += R.jl[k] * S.ustar[6 + 3 * leg + k];
+    }
+    R.warm = 3 * leg + d;
+    if (d == 0) {
+      lo = 0.0f; hi = 1e30f;
+      R.rhs = dist > 0.0f ? -rel - dist * inv_dt : -rel - dist * erp_dt;
+    } else {
+      R.nrm_slot = 16 + leg;
+      mu = S.s[O(FOOT_MU)] * cfg.plane_friction;  // combined friction = product of the two coefficients
+      R.rhs = -rel;
+    }
+  }
+  if (!enable) R.active = false;
+  // bounds as (constant part) + mu * lambda_normal: friction rows have a zero constant part, the others mu = 0;
+  // an inactive row is pinned to zero
+  R.mu_e = (R.active && R.nrm_slot >= 0) ? mu : 0.0f;
+  R.hi_c = (R.active && R.nrm_slot < 0) ? hi : 0.0f;
+  R.lo_c = (R.active && R.nrm_slot < 0) ? lo : 0.0f;
+  if (!R.active) R.rhs = 0.0f;
+}
+
+// impulse response M^-1 J^T of the row (btMultiBody::calcAccelerationDeltasMultiDof) -> W[slot]; 1/diag; warm start
+__device__ __forceinline__ void row_response(Shared& S, const orr_config& cfg, Row& R, int slot) {
+  float diag = 0.0f;
+  float mj[6], mq[12];
+  float pA[6] = {0, 0, 0, 0, 0, 0}, ud0, ud1, ud2;
+  const int leg = R.leg;
+  delta_in<1>(S, 3 * leg + 2, R.jl[2], pA, ud2);
+  delta_in<1>(S, 3 * leg + 1, R.jl[1], pA, ud1);
+  delta_in<0>(S, 3 * leg, R.jl[0], pA, ud0);
+  float fb[6], a0[6];
+  mtv3(S.Rb, &R.Jb[0], &fb[0]);
+  mtv3(S.Rb, &R.Jb[3], &fb[3]);
+#pragma unroll
+  for (int i = 0; i < 6; i++) fb[i] -= pA[i];
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    float sacc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 6; k++) sacc += S.IA0inv[i * 6 + k] * fb[k];
+    a0[i] = sacc;
+  }
+#pragma unroll
+  for (int L4 = 0; L4 < 4; L4++) {
+    float ap[6] = {a0[0], a0[1], a0[2], a0[3], a0[4], a0[5]};
+    const bool mine = (L4 == leg);
+    mq[3 * L4] = delta_out<0>(S, 3 * L4, mine ? ud0 : 0.0f, ap);
+    mq[3 * L4 + 1] = delta_out<1>(S, 3 * L4 + 1, mine ? ud1 : 0.0f, ap);
+    mq[3 * L4 + 2] = delta_out<1>(S, 3 * L4 + 2, mine ? ud2 : 0.0f, ap);
+    diag += mine ? (R.jl[0] * mq[3 * L4] + R.jl[1] * mq[3 * L4 + 1] + R.jl[2] * mq[3 * L4 + 2]) : 0.0f;
+  }
+  mv3(S.Rb, &a0[0], &mj[0]);
+  mv3(S.Rb, &a0[3], &mj[3]);
+#pragma unroll
+  for (int i = 0; i < 6; i++) diag += R.Jb[i] * mj[i];
+  if (R.active) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) S.ph.sub.W[slot][i] = mj[i];
+#pragma unroll
+    for (int i = 0; i < 12; i++) S.ph.sub.W[slot][6 + i] = mq[i];
+  }
+  R.jdi = R.active ? __builtin_amdgcn_rcpf(diag) : 0.0f;
+  R.rhs *= R.jdi;
+  R.lam = (R.active && R.warm >= 0) ? cfg.warmstart_factor * S.s[O(LAMBDA) + R.warm] : 0.0f;
+}
+
 // One physics sub-step.  Returns the fall-proxy flag (wave-uniform) when want_fall.
 __device__ static int physics_substep(const KParams& P, Shared& S, int lane, int sub, bool want_fall) {
   const orr_config& cfg = P.cfg;
   const float dt = cfg.sim_dt, inv_dt = 1.0f / cfg.sim_dt, erp_dt = cfg.contact_erp / cfg.sim_dt;
   aba_legs(P, S, lane);
   WSYNC();
-  if (lane < 18) {
-    float u = lane < 3 ? S.s[O(ANGVEL) + lane] : (lane < 6 ? S.s[O(LINVEL) + lane - 3] : S.m.jdir[lane - 6] * S.s[O(QD) + lane - 6]);
-    S.ustar[lane] = u + dt * S.acc[lane];
+  for (int i = lane; i < 18; i += kLanes) {
+    float u = i < 3 ? S.s[O(ANGVEL) + i] : (i < 6 ? S.s[O(LINVEL) + i - 3] : S.m.jdir[i - 6] * S.s[O(QD) + i - 6]);
+    S.ustar[i] = u + dt * S.acc[i];
   }
   int fall = 0;
   if (want_fall) {  // termination-only collision proxies (imitation_task.py:536-546)
@@ -469,184 +608,86 @@ __device__ static int physics_substep(const KParams& P, Shared& S, int lane, int
   }
   WSYNC();
 
-  // ---------------- constraint rows: one per lane; lane index = row slot = solve order ----------------
-  //  0..3   knee joint-friction motors (minitaur.py:1063-1070)
-  //  4..15  joint limits (joint j = lane-4; at most one side can be within limit_activation)
-  //  16..19 toe contact normals, 20..27 pyramid friction (leg = (lane-20)/2, t1 = +x, t2 = +y)
-  bool active = false;
-  int leg = 0, nrm_slot = -1, warm = -1;
-  float Jb[6] = {0, 0, 0, 0, 0, 0}, jl[3] = {0, 0, 0};
-  float rhs = 0.0f, lo = 0.0f, hi = 0.0f, mu = 0.0f;
-  if (lane < 4) {
-    leg = lane;
-    const float fr = S.s[O(KNEE_FRICTION) + leg];
-    active = fr > 0.0f;
-    jl[2] = 1.0f;
-    lo = -fr * dt; hi = fr * dt;
-    rhs = -S.ustar[6 + 3 * leg + 2];
-  } else if (lane < 16) {
-    const int j = lane - 4;
-    leg = j / 3;
-    const int kk = j - 3 * leg;
-    const float a = S.m.jdir[j] * (S.s[O(Q) + j] - S.m.joff[j]);
-    const float pen_lo = a - S.m.joint_lo[j], pen_hi = S.m.joint_hi[j] - a;
-    const bool use_lo = pen_lo < cfg.limit_activation;
-    const bool use_hi = (!use_lo) && pen_hi < cfg.limit_activation;
-    active = use_lo || use_hi;
-    const float sgn = use_lo ? 1.0f : -1.0f, pen = use_lo ? pen_lo : pen_hi;
-    jl[0] = kk == 0 ? sgn : 0.0f; jl[1] = kk == 1 ? sgn : 0.0f; jl[2] = kk == 2 ? sgn : 0.0f;
-    const float rel = sgn * S.ustar[6 + j];
-    lo = 0.0f; hi = 1e30f;
-    rhs = pen > 0.0f ? -rel - pen * inv_dt : -rel - pen * erp_dt;
-  } else if (lane < 28) {
-    int d;
-    if (lane < 20) { leg = lane - 16; d = 0; }
-    else { leg = (lane - 20) >> 1; d = 1 + ((lane - 20) & 1); }
-    const LinkCache& Lb = S.lc[3 * leg + 2];
-    float cw[3];
-    mv3(Lb.Rw, S.m.toe_pos[leg], cw);
-    cw[0] += Lb.ow[0]; cw[1] += Lb.ow[1]; cw[2] += Lb.ow[2];
-    const float dist = cw[2] - S.m.toe_radius;
-    active = dist < cfg.contact_margin;
-    const float Pw[3] = {cw[0], cw[1], cw[2] - S.m.toe_radius};
-    const float dir[3] = {d == 1 ? 1.0f : 0.0f, d == 2 ? 1.0f : 0.0f, d == 0 ? 1.0f : 0.0f};
-    float rr[3] = {Pw[0] - S.s[O(POS)], Pw[1] - S.s[O(POS) + 1], Pw[2] - S.s[O(POS) + 2]};
-    cross3(rr, dir, &Jb[0]);
-    Jb[3] = dir[0]; Jb[4] = dir[1]; Jb[5] = dir[2];
-    float rel = Jb[0] * S.ustar[0] + Jb[1] * S.ustar[1] + Jb[2] * S.ustar[2] + Jb[3] * S.ustar[3] + Jb[4] * S.ustar[4] + Jb[5] * S.ustar[5];
+  // ---------------- constraint rows ----------------
+  // 28 row slots, slot index = solve order:
+  //    0..3   knee joint-friction motors (minitaur.py:1063-1070)
+  //    4..15  joint limits (joint j = slot-4; at most one side can be within limit_activation)
+  //   16..19  toe contact normals, 20..27 pyramid friction (leg = (slot-20)/2, t1 = +x, t2 = +y)
+  // A robot has 16 row lanes holding two banks: bank A = slots 0..3 and 16..27 (lane l -> slot l < 4 ? l : l+12),
+  // bank B = the joint-limit slots 4..15 (lane l -> slot l).  Bank B is skipped unless some robot of the wave has
+  // a joint near its limit.
+  Row A, B;
+  const bool rowlane = lane < 16;
+  row_setup(S, cfg, rowlane ? (lane < 4 ? lane : lane + 12) : 0, rowlane, dt, inv_dt, erp_dt, A);
+  row_setup(S, cfg, (rowlane && lane >= 4) ? lane : 4, rowlane && lane >= 4, dt, inv_dt, erp_dt, B);
+  const unsigned long long balA = __ballot(A.active), balB = __ballot(B.active);
+  const bool anyB = balB != 0ull;  // wave-uniform
+  // union over the robots of this wave of the active slots (a slot visited for a robot where it is inactive is a no-op)
+  unsigned int mask = 0;
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-      const LinkCache& L = S.lc[3 * leg + k];
-      const int ax = k == 0 ? 0 : 1;  // world joint axis = column ax of Rw
-      const float axw[3] = {L.Rw[ax], L.Rw[3 + ax], L.Rw[6 + ax]};
-      float cr[3];
-      rr[0] = Pw[0] - L.ow[0]; rr[1] = Pw[1] - L.ow[1]; rr[2] = Pw[2] - L.ow[2];
-      cross3(axw, rr, cr);
-      jl[k] = dot3(dir, cr);
-      rel += jl[k] * S.ustar[6 + 3 * leg + k];
-    }
-    warm = 3 * leg + d;
-    if (d == 0) {
-      lo = 0.0f; hi = 1e30f;
-      rhs = dist > 0.0f ? -rel - dist * inv_dt : -rel - dist * erp_dt;
-    } else {
-      nrm_slot = 16 + leg;
-      mu = S.s[O(FOOT_MU)] * cfg.plane_friction;  // combined friction = product of the two coefficients
-      rhs = -rel;
-    }
+  for (int g = 0; g < kRPW; g++) {
+    const unsigned int a = (unsigned int)(balA >> (g * kLanes)) & 0xFFFFu, b2 = (unsigned int)(balB >> (g * kLanes)) & 0xFFF0u;
+    mask |= (a & 0xFu) | ((a >> 4) << 16) | b2;
   }
-  const unsigned long long bal = __ballot(active);
-  // rows of the robots sharing this wave are solved side by side: a row slot is visited when it is active for any
-  // of them; a robot whose slot is inactive carries lambda = rhs = 0 there, so the visit is a no-op for it
-  const unsigned int mask = kRPW == 1 ? (unsigned int)(bal | (bal >> 32)) : ((unsigned int)bal | (unsigned int)(bal >> 32));
-
-  // ---------------- impulse response M^-1 J^T ----------------
-  float diag = 0.0f;
-  {
-    float mj[6], mq[12];
-    float pA[6] = {0, 0, 0, 0, 0, 0}, ud0, ud1, ud2;
-    SCHED_FENCE();
-    delta_in<1>(S, 3 * leg + 2, jl[2], pA, ud2);
-    SCHED_FENCE();
-    delta_in<1>(S, 3 * leg + 1, jl[1], pA, ud1);
-    SCHED_FENCE();
-    delta_in<0>(S, 3 * leg, jl[0], pA, ud0);
-    SCHED_FENCE();
-    float fb[6], a0[6];
-    mtv3(S.Rb, &Jb[0], &fb[0]);
-    mtv3(S.Rb, &Jb[3], &fb[3]);
-#pragma unroll
-    for (int i = 0; i < 6; i++) fb[i] -= pA[i];
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-      float sacc = 0.0f;
-#pragma unroll
-      for (int k = 0; k < 6; k++) sacc += S.IA0inv[i * 6 + k] * fb[k];
-      a0[i] = sacc;
-    }
-#pragma unroll
-    for (int L4 = 0; L4 < 4; L4++) {
-      float ap[6] = {a0[0], a0[1], a0[2], a0[3], a0[4], a0[5]};
-      const bool mine = (L4 == leg);
-      SCHED_FENCE();
-      mq[3 * L4] = delta_out<0>(S, 3 * L4, mine ? ud0 : 0.0f, ap);
-      SCHED_FENCE();
-      mq[3 * L4 + 1] = delta_out<1>(S, 3 * L4 + 1, mine ? ud1 : 0.0f, ap);
-      SCHED_FENCE();
-      mq[3 * L4 + 2] = delta_out<1>(S, 3 * L4 + 2, mine ? ud2 : 0.0f, ap);
-      diag += mine ? (jl[0] * mq[3 * L4] + jl[1] * mq[3 * L4 + 1] + jl[2] * mq[3 * L4 + 2]) : 0.0f;
-    }
-    mv3(S.Rb, &a0[0], &mj[0]);
-    mv3(S.Rb, &a0[3], &mj[3]);
-#pragma unroll
-    for (int i = 0; i < 6; i++) diag += Jb[i] * mj[i];
-    if (active) {
-#pragma unroll
-      for (int i = 0; i < 6; i++) S.ph.sub.W[lane][i] = mj[i];
-#pragma unroll
-      for (int i = 0; i < 12; i++) S.ph.sub.W[lane][6 + i] = mq[i];
-    }
-  }
-  const float jdi = active ? __builtin_amdgcn_rcpf(diag) : 0.0f;
-  float lam = (active && warm >= 0) ? cfg.warmstart_factor * S.s[O(LAMBDA) + warm] : 0.0f;
-  rhs = active ? rhs * jdi : 0.0f;
-  if (!active) { lo = 0.0f; hi = 0.0f; mu = 0.0f; }
+  // ---------------- impulse responses M^-1 J^T, diagonal, warm start ----------------
+  row_response(S, cfg, A, rowlane ? (lane < 4 ? lane : lane + 12) : 0);
+  if (anyB) row_response(S, cfg, B, (rowlane && lane >= 4) ? lane : 4);
   WSYNC();
-  // Delassus column for this lane: Ac[r] = J_lane . W[r] (= A[lane][r] = A[r][lane]), kept in registers
-  float Ac[kMaxRows];
-  float w = 0.0f, lam_n = 0.0f;
+  // Delassus columns Ac[r] = J . W[r] (= A[row][r]) kept in registers; w = (A lambda) for the warm start
+  float AcA[kMaxRows], AcB[kMaxRows];
 #pragma unroll
   for (int r = 0; r < kMaxRows; r++) {
-    Ac[r] = 0.0f;
+    AcA[r] = 0.0f; AcB[r] = 0.0f;
     if ((mask >> r) & 1u) {
       const float* Wr = S.ph.sub.W[r];
-      float a = Jb[0] * Wr[0] + Jb[1] * Wr[1] + Jb[2] * Wr[2] + Jb[3] * Wr[3] + Jb[4] * Wr[4] + Jb[5] * Wr[5];
-      a += jl[0] * Wr[6 + 3 * leg] + jl[1] * Wr[6 + 3 * leg + 1] + jl[2] * Wr[6 + 3 * leg + 2];
-      Ac[r] = a;
-      SCHED_FENCE();
-      const float l0 = bcast_row(lam, r, sub);
-      w += a * l0;  // warm-start contribution
-      if (r >= 16 && r < 20 && nrm_slot == r) lam_n = l0;
+      const float l0 = (r >= 4 && r < 16) ? bcast_row(B.lam, r, sub) : bcast_row(A.lam, r < 4 ? r : r - 12, sub);
+      AcA[r] = row_dot(A, Wr);
+      A.w += AcA[r] * l0;
+      if (r >= 16 && r < 20 && A.nrm_slot == r) A.lam_n = l0;
+      if (anyB) { AcB[r] = row_dot(B, Wr); B.w += AcB[r] * l0; }
     }
   }
-  // projected Gauss-Seidel (btMultiBodyConstraintSolver::solveSingleIteration), Delassus form:
-  // lane i keeps lambda_i and w_i = (A lambda)_i; one readlane per row update
-  // bounds as (constant part) + mu * lambda_normal: friction rows have zero constant part, the others mu = 0
-  const float mu_e = nrm_slot >= 0 ? mu : 0.0f;
-  const float hi_c = nrm_slot >= 0 ? 0.0f : hi, lo_c = nrm_slot >= 0 ? 0.0f : lo;
+  // projected Gauss-Seidel (btMultiBodyConstraintSolver::solveSingleIteration), Delassus form: every row lane keeps
+  // lambda and w = (A lambda) of its row(s); one broadcast per row update
   for (int it = 0; it < cfg.solver_iters; it++) {
 #pragma unroll
     for (int r = 0; r < kMaxRows; r++) {
       if ((mask >> r) & 1u) {
-        const float hi_e = fmaf(mu_e, lam_n, hi_c), lo_e = fmaf(-mu_e, lam_n, lo_c);
-        const float sum = __builtin_amdgcn_fmed3f(lam + (rhs - w * jdi), lo_e, hi_e);
-        const float dl = sum - lam;
-        const float d_r = bcast_row(dl, r, sub);
-        if (lane == r) lam = sum;
-        w += Ac[r] * d_r;
-        if (r >= 16 && r < 20 && nrm_slot == r) lam_n += d_r;
+        float d_r;
+        if (r >= 4 && r < 16) {
+          const float sum = __builtin_amdgcn_fmed3f(B.lam + (B.rhs - B.w * B.jdi), B.lo_c, B.hi_c);
+          d_r = bcast_row(sum - B.lam, r, sub);
+          if (lane == r) B.lam = sum;
+        } else {
+          const int src = r < 4 ? r : r - 12;
+          const float hi_e = fmaf(A.mu_e, A.lam_n, A.hi_c), lo_e = fmaf(-A.mu_e, A.lam_n, A.lo_c);
+          const float sum = __builtin_amdgcn_fmed3f(A.lam + (A.rhs - A.w * A.jdi), lo_e, hi_e);
+          d_r = bcast_row(sum - A.lam, src, sub);
+          if (lane == src) A.lam = sum;
+          if (r >= 16 && r < 20 && A.nrm_slot == r) A.lam_n += d_r;
+        }
+        A.w += AcA[r] * d_r;
+        if (anyB) B.w += AcB[r] * d_r;
       }
     }
   }
   // contact impulses are remembered for the next sub-step's warm start (0 for open contacts)
-  if (lane >= 16 && lane < 28) S.s[O(LAMBDA) + warm] = active ? lam : 0.0f;
+  if (rowlane && lane >= 4) S.s[O(LAMBDA) + A.warm] = A.active ? A.lam : 0.0f;
   // ---------------- velocity update, Bullet coordinate-velocity clamp, semi-implicit Euler ----------------
-  float unew = 0.0f;
   {
-    float du = 0.0f;
-    const int kk = lane < 18 ? lane : 0;
+    float du0 = 0.0f, du1 = 0.0f;  // DOF lane and DOF lane+16
+    const int k1 = lane + 16 < 18 ? lane + 16 : 0;
+    const int k0 = lane < 18 ? lane : 0;
 #pragma unroll
     for (int r = 0; r < kMaxRows; r++) {
       if ((mask >> r) & 1u) {
-        const float lr = bcast_row(lam, r, sub);
-        du += S.ph.sub.W[r][kk] * lr;
+        const float lr = (r >= 4 && r < 16) ? bcast_row(B.lam, r, sub) : bcast_row(A.lam, r < 4 ? r : r - 12, sub);
+        du0 += S.ph.sub.W[r][k0] * lr;
+        if (kLanes < 18) du1 += S.ph.sub.W[r][k1] * lr;
       }
     }
-    if (lane < 18) {
-      unew = S.ustar[lane] + du;
-      unew = fminf(fmaxf(unew, -cfg.max_coord_velocity), cfg.max_coord_velocity);
-      S.du[lane] = unew;
-    }
+    if (lane < 18) S.du[lane] = fminf(fmaxf(S.ustar[lane] + du0, -cfg.max_coord_velocity), cfg.max_coord_velocity);
+    if (kLanes < 18 && lane + 16 < 18) S.du[lane + 16] = fminf(fmaxf(S.ustar[lane + 16] + du1, -cfg.max_coord_velocity), cfg.max_coord_velocity);
   }
   WSYNC();
   {
@@ -660,16 +701,18 @@ __device__ static int physics_substep(const KParams& P, Shared& S, int lane, int
     qmul(dq, &S.s[O(QUAT)], qn);
     const float nn = rsqrtf(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
     WSYNC();
-    if (lane < 3) S.s[O(ANGVEL) + lane] = unew;
-    else if (lane < 6) { S.s[O(LINVEL) + lane - 3] = unew; S.s[O(POS) + lane - 3] += dt * unew; }
-    else if (lane < 18) {
-      const int j = lane - 6;
-      const float a = S.m.jdir[j] * (S.s[O(Q) + j] - S.m.joff[j]) + dt * unew;
-      S.s[O(Q) + j] = a * S.m.jdir[j] + S.m.joff[j];
-      S.s[O(QD) + j] = unew * S.m.jdir[j];
-    } else if (lane < 22) {
-      const int i = lane - 18;
-      S.s[O(QUAT) + i] = (i == 0 ? qn[0] : (i == 1 ? qn[1] : (i == 2 ? qn[2] : qn[3]))) * nn;
+    for (int i = lane; i < 22; i += kLanes) {
+      if (i < 3) S.s[O(ANGVEL) + i] = S.du[i];
+      else if (i < 6) { S.s[O(LINVEL) + i - 3] = S.du[i]; S.s[O(POS) + i - 3] += dt * S.du[i]; }
+      else if (i < 18) {
+        const int j = i - 6;
+        const float a = S.m.jdir[j] * (S.s[O(Q) + j] - S.m.joff[j]) + dt * S.du[i];
+        S.s[O(Q) + j] = a * S.m.jdir[j] + S.m.joff[j];
+        S.s[O(QD) + j] = S.du[i] * S.m.jdir[j];
+      } else {
+        const int q = i - 18;
+        S.s[O(QUAT) + q] = (q == 0 ? qn[0] : (q == 1 ? qn[1] : (q == 2 ? qn[2] : qn[3]))) * nn;
+      }
     }
   }
   WSYNC();
@@ -736,13 +779,13 @@ __device__ static void sample_poses(const KParams& P, Shared& S, int lane, int n
   WSYNC();
   for (int e = 0; e < 2 * nt; e++) {
     const int f = __float_as_int(S.red[e]);
-    if (lane < 19) S.ph.end.frames[e][lane] = c.frames[f * 19 + lane];
+    for (int i = lane; i < 19; i += kLanes) S.ph.end.frames[e][i] = c.frames[f * 19 + i];
   }
   if (with_vel) {
     const int f0 = __float_as_int(S.red[0]), f1 = __float_as_int(S.red[1]);
-    if (lane < 18) { S.ph.end.fvel[0][lane] = c.vels[f0 * 18 + lane]; S.ph.end.fvel[1][lane] = c.vels[f1 * 18 + lane]; }
+    for (int i = lane; i < 18; i += kLanes) { S.ph.end.fvel[0][i] = c.vels[f0 * 18 + i]; S.ph.end.fvel[1][i] = c.vels[f1 * 18 + i]; }
   }
-  if (lane < 19) S.ph.end.frames[10][lane] = c.frames[lane];  // frame 0 (warm-up heading)
+  for (int i = lane; i < 19; i += kLanes) S.ph.end.frames[10][i] = c.frames[i];  // frame 0 (warm-up heading)
   WSYNC();
   if (lane < nt) {
     const bool warm_pose = warm_ep && t_lane >= -P.cfg.warmup_time && t_lane < 0.0f;
@@ -959,18 +1002,27 @@ __device__ __forceinline__ int time_limit(const orr_config& c, long long total) 
 __device__ static void sensors_push(Shared& S, int lane, bool fill_all) {
   float rpy[3];
   euler_from_quat(&S.co[12], rpy);
-  // lanes 0..11 motor angle k, lanes 12..15 IMU channel, lanes 16..27 last action
-  float newest = 0.0f, h0 = 0.0f, h1 = 0.0f;
-  int base = 0, w = 0, k = 0;
-  if (lane < 12) { base = O(MOTORANG_HIST); w = 12; k = lane; newest = map_pi(S.co[lane]); }
-  else if (lane < 16) { base = O(IMU_HIST); w = 4; k = lane - 12; newest = k == 0 ? rpy[0] : (k == 1 ? rpy[1] : (k == 2 ? S.co[16] : S.co[17])); }
-  else if (lane < 28) { base = O(LASTACT_HIST); w = 12; k = lane - 16; newest = S.s[O(LAST_ACTION) + k]; }
-  if (lane < 28) { h0 = S.s[base + k]; h1 = S.s[base + w + k]; }
+  // 28 history columns: 0..11 motor angle k, 12..15 IMU channel, 16..27 last action; a lane owns columns lane, lane+kLanes
+  constexpr int kCols = (28 + kLanes - 1) / kLanes;
+  float newest[kCols], h0[kCols], h1[kCols];
+  int base[kCols], w[kCols], kk[kCols];
+#pragma unroll
+  for (int c = 0; c < kCols; c++) {
+    const int col = lane + c * kLanes;
+    base[c] = 0; w[c] = 0; kk[c] = 0; newest[c] = 0.0f; h0[c] = 0.0f; h1[c] = 0.0f;
+    if (col < 12) { base[c] = O(MOTORANG_HIST); w[c] = 12; kk[c] = col; newest[c] = map_pi(S.co[col]); }
+    else if (col < 16) { base[c] = O(IMU_HIST); w[c] = 4; kk[c] = col - 12; newest[c] = kk[c] == 0 ? rpy[0] : (kk[c] == 1 ? rpy[1] : (kk[c] == 2 ? S.co[16] : S.co[17])); }
+    else if (col < 28) { base[c] = O(LASTACT_HIST); w[c] = 12; kk[c] = col - 16; newest[c] = S.s[O(LAST_ACTION) + kk[c]]; }
+    if (col < 28) { h0[c] = S.s[base[c] + kk[c]]; h1[c] = S.s[base[c] + w[c] + kk[c]]; }
+  }
   WSYNC();
-  if (lane < 28) {
-    S.s[base + k] = newest;
-    S.s[base + w + k] = fill_all ? newest : h0;
-    S.s[base + 2 * w + k] = fill_all ? newest : h1;
+#pragma unroll
+  for (int c = 0; c < kCols; c++) {
+    if (lane + c * kLanes < 28) {
+      S.s[base[c] + kk[c]] = newest[c];
+      S.s[base[c] + w[c] + kk[c]] = fill_all ? newest[c] : h0[c];
+      S.s[base[c] + 2 * w[c] + kk[c]] = fill_all ? newest[c] : h1[c];
+    }
   }
   WSYNC();
 }
@@ -1009,14 +1061,14 @@ __device__ static void reset_robot(const KParams& P, float* rec, Shared& S, int 
   // 4. randomiser (controllable_env_randomizer_from_config.py:92-122), sorted-name draw order:
   //    inertia 2 | joint friction 8 | latency 1 | lateral friction 1 | mass 2 | motor strength 12
   if (c.flags & ORR_FLAG_RANDOMIZER) {
-    if (lane < 26) {
-      const float u = philox_uniform(c.seed, robot, ep, (uint32_t)lane);
-      if (lane < 2) S.s[O(INERTIA_RATIO) + lane] = 0.5f + u * 1.0f;
-      else if (lane < 10) { if (((lane - 2) & 1) == 0) S.s[O(KNEE_FRICTION) + ((lane - 2) >> 1)] = u * 0.05f; }
-      else if (lane == 10) S.s[O(LATENCY)] = u * 0.04f;
-      else if (lane == 11) S.s[O(FOOT_MU)] = 0.5f + u * 0.75f;
-      else if (lane < 14) S.s[O(MASS_RATIO) + lane - 12] = 0.8f + u * 0.4f;
-      else S.s[O(STRENGTH) + lane - 14] = 0.8f + u * 0.4f;
+    for (int i = lane; i < 26; i += kLanes) {
+      const float u = philox_uniform(c.seed, robot, ep, (uint32_t)i);
+      if (i < 2) S.s[O(INERTIA_RATIO) + i] = 0.5f + u * 1.0f;
+      else if (i < 10) { if (((i - 2) & 1) == 0) S.s[O(KNEE_FRICTION) + ((i - 2) >> 1)] = u * 0.05f; }
+      else if (i == 10) S.s[O(LATENCY)] = u * 0.04f;
+      else if (i == 11) S.s[O(FOOT_MU)] = 0.5f + u * 0.75f;
+      else if (i < 14) S.s[O(MASS_RATIO) + i - 12] = 0.8f + u * 0.4f;
+      else S.s[O(STRENGTH) + i - 14] = 0.8f + u * 0.4f;
     }
     WSYNC();
     refresh_mass(P.tab->model[geti(S, O(ROBOT_TYPE))], S, lane);
@@ -1053,14 +1105,14 @@ __device__ static void reset_robot(const KParams& P, float* rec, Shared& S, int 
   }
   WSYNC();
   apply_origin(S, lane, 5);
-  if (lane < 19) S.s[O(REF_POSE) + lane] = S.ph.end.pose[0][lane];
+  for (int i = lane; i < 19; i += kLanes) S.s[O(REF_POSE) + i] = S.ph.end.pose[0][i];
   if (lane == 0) {
     float v[3];
     qrot(&S.ph.end.vel[0], &S.s[O(ORIGIN_ROT)], v); S.ph.end.vel[0] = v[0]; S.ph.end.vel[1] = v[1]; S.ph.end.vel[2] = v[2];
     qrot(&S.ph.end.vel[3], &S.s[O(ORIGIN_ROT)], v); S.ph.end.vel[3] = v[0]; S.ph.end.vel[4] = v[1]; S.ph.end.vel[5] = v[2];
   }
   WSYNC();
-  if (lane < 18) S.s[O(REF_VEL) + lane] = S.ph.end.vel[lane];
+  for (int i = lane; i < 18; i += kLanes) S.s[O(REF_VEL) + i] = S.ph.end.vel[i];
   // 6. _sync_sim_model / _set_state (:778-829): teleport the sim robot onto the reference
   if (lane < 3) { S.s[O(POS) + lane] = S.ph.end.pose[0][lane]; S.s[O(LINVEL) + lane] = S.ph.end.vel[lane]; S.s[O(ANGVEL) + lane] = S.ph.end.vel[3 + lane]; }
   if (lane < 4) S.s[O(QUAT) + lane] = S.ph.end.pose[0][3 + lane];
@@ -1103,7 +1155,7 @@ __global__ __launch_bounds__(64) void orr_reset_kernel(KParams P, const uint8_t*
 // mode 0: full env step.  mode 1 (debug / parity of row C): nsub physics sub-steps with the given
 // motor torques (actions = torques), no robot or task logic.
 #ifndef ORR_WAVES_PER_EU
-#define ORR_WAVES_PER_EU 2  // 4096 robots, two per wave = 2 waves on each of the 1024 SIMDs: the whole batch is resident at once
+#define ORR_WAVES_PER_EU 1  // 4096 robots, four per wave = one wave on each of the 1024 SIMDs: the whole batch is resident at once
 #endif
 template <int MODE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PER_EU, 8))) void orr_step_kernel(KParams P, const float* actions, float* obs_out, float* reward_out,
@@ -1195,8 +1247,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
     }
     WSYNC();
     apply_origin(S, lane, 5);
-    if (lane < 19) S.s[O(REF_POSE) + lane] = S.ph.end.pose[0][lane];
-    if (lane < 18) S.s[O(REF_VEL) + lane] = S.ph.end.vel[lane];
+    for (int i = lane; i < 19; i += kLanes) S.s[O(REF_POSE) + i] = S.ph.end.pose[0][i];
+    for (int i = lane; i < 18; i += kLanes) S.s[O(REF_VEL) + i] = S.ph.end.vel[i];
     WSYNC();
   }
   // _terminal_condition (imitation_task.py:518-572) + time limit (wrapper_env.py:79) + non-finite guard
