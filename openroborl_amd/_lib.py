@@ -41,6 +41,8 @@ def build(force=False, verbose=False):
     for var in ("ORR_WAVES_PER_EU", "ORR_LANES_PER_ROBOT"):      # tuning experiments only
         if os.environ.get(var):
             cmd.insert(-3, "-D%s=%d" % (var, int(os.environ[var])))
+    for d in os.environ.get("ORR_EXTRA_DEFS", "").split():
+        cmd.insert(-3, "-D" + d)
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -54,13 +56,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if needs_build():
+    if needs_build() and not os.environ.get("ORR_LIB_PATH"):
         try:
             build()
         except Exception as e:  # stale library on a box without hipcc is still usable
             if not os.path.exists(LIB_PATH):
                 raise RuntimeError("libopenroborl_hip.so is missing and could not be built: %r" % (e,))
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(os.environ.get("ORR_LIB_PATH", LIB_PATH))   # override = tuning experiments (A/B of two builds)
     vp = C.c_void_p
     L.orr_last_error.restype = C.c_char_p
     L.orr_abi_version.restype = C.c_int32

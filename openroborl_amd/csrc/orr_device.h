@@ -16,23 +16,29 @@
 #include "../../include/openroborl_hip.h"
 
 #define ORR_PI_F 3.14159265358979323846f
-// A workgroup is exactly one wavefront, so LDS hand-offs between lanes only need the LDS operations to be
-// complete and ordered (workgroup-scope fence -> s_waitcnt) and the compiler not to move code across:
-// no s_barrier, and safe inside divergent (per-robot) control flow.
+// A workgroup is exactly one wavefront.  A wave's LDS instructions execute in issue order, so a ds_write followed
+// by another lane's ds_read of the same word needs no s_waitcnt and no s_barrier -- only the COMPILER must not move
+// memory operations across the hand-off.  (A workgroup-scope release/acquire fence also works but makes the wave
+// drain vmcnt, i.e. wait for the latency-ring store to reach memory, ten times per sub-step.)
+#ifdef ORR_FENCE_SYNC
 #define WSYNC()                                           \
   do {                                                    \
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); \
     __builtin_amdgcn_wave_barrier();                      \
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); \
   } while (0)
-#ifdef ORR_NO_SCHED_FENCE
-#define SCHED_FENCE()
 #else
+#define WSYNC()                             \
+  do {                                      \
+    asm volatile("" ::: "memory");          \
+    __builtin_amdgcn_wave_barrier();        \
+    asm volatile("" ::: "memory");          \
+  } while (0)
+#endif
 #ifdef ORR_SCHED_FENCE
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
 #define SCHED_FENCE()  // measured: fencing the scheduler RAISES spills (104 vs 0 at 256 VGPRs); kept for experiments
-#endif
 #endif
 
 namespace orr {

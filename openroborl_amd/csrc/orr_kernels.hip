@@ -137,12 +137,36 @@ __device__ __forceinline__ void chol6_solve(const float L[21], const float invdi
   }
 }
 
+// Per-lane constants of the leg this lane works on, loaded once per launch and kept in registers over the 33
+// sub-steps (a lone wave per SIMD cannot hide the LDS round trips of re-reading them every sub-step).
+struct LegConst {
+  float r[3][3], com[3][3], m[3], Ic[3][6], jdir[3], joff[3];
+};
+__device__ static void load_leg_const(const Shared& S, int leg, LegConst& K) {
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const int j = 3 * leg + k;
+#pragma unroll
+    for (int i = 0; i < 3; i++) { K.r[k][i] = S.m.joint_pos[j][i]; K.com[k][i] = S.m.link_com[j][i]; }
+#pragma unroll
+    for (int i = 0; i < 6; i++) K.Ic[k][i] = S.Ic[j + 1][i];
+    K.m[k] = S.mass[j + 1];
+    K.jdir[k] = S.m.jdir[j];
+    K.joff[k] = S.m.joff[j];
+  }
+}
+// what pass 1 hands to passes 2 / 3 of the same lane (registers; the row lanes get their copy through LDS)
+struct LinkRegs {
+  float c, s, cv[6], pA[6];
+};
+
 // ---- pass 1 for one link: velocities, velocity-product terms, bias force, world pose ----
 template <int AX>
-__device__ __forceinline__ void pass1_link(Shared& S, int j, bool wr, float wp[3], float vp[3], float Rwp[9], float owp[3]) {
-  const float r[3] = {S.m.joint_pos[j][0], S.m.joint_pos[j][1], S.m.joint_pos[j][2]};
-  const float a = S.m.jdir[j] * (S.s[O(Q) + j] - S.m.joff[j]);
-  const float ad = S.m.jdir[j] * S.s[O(QD) + j];
+__device__ __forceinline__ void pass1_link(Shared& S, const LegConst& K, int k, LinkRegs& G, int j, bool wr, float wp[3], float vp[3],
+                                           float Rwp[9], float owp[3]) {
+  const float r[3] = {K.r[k][0], K.r[k][1], K.r[k][2]};
+  const float a = K.jdir[k] * (S.s[O(Q) + j] - K.joff[k]);
+  const float ad = K.jdir[k] * S.s[O(QD) + j];
   float sn, cs;
   joint_sincos(a, &sn, &cs);
   float t[3], w[3], v[3];
@@ -154,12 +178,12 @@ __device__ __forceinline__ void pass1_link(Shared& S, int j, bool wr, float wp[3
   float cv[6];  // c = [w x (e ad); v x (e ad)]
   if (AX == 0) { cv[0] = 0.0f; cv[1] = w[2] * ad; cv[2] = -w[1] * ad; cv[3] = 0.0f; cv[4] = v[2] * ad; cv[5] = -v[1] * ad; }
   else { cv[0] = -w[2] * ad; cv[1] = 0.0f; cv[2] = w[0] * ad; cv[3] = -v[2] * ad; cv[4] = 0.0f; cv[5] = v[0] * ad; }
-  const float m = S.mass[j + 1];
-  const float com[3] = {S.m.link_com[j][0], S.m.link_com[j][1], S.m.link_com[j][2]};
+  const float m = K.m[k];
+  const float com[3] = {K.com[k][0], K.com[k][1], K.com[k][2]};
   float wxc[3], f[3], n[3], cxf[3], t1[3], t2[3], pA[6];
   cross3(w, com, wxc);
   f[0] = m * (v[0] + wxc[0]); f[1] = m * (v[1] + wxc[1]); f[2] = m * (v[2] + wxc[2]);
-  symv(S.Ic[j + 1], w, n);
+  symv(K.Ic[k], w, n);
   cross3(com, f, cxf);
   n[0] += cxf[0]; n[1] += cxf[1]; n[2] += cxf[2];
   cross3(w, n, t1);
@@ -176,6 +200,9 @@ __device__ __forceinline__ void pass1_link(Shared& S, int j, bool wr, float wp[3
   }
   mv3(Rwp, r, ow);
   ow[0] += owp[0]; ow[1] += owp[1]; ow[2] += owp[2];
+  G.c = cs; G.s = sn;
+#pragma unroll
+  for (int i = 0; i < 6; i++) { G.cv[i] = cv[i]; G.pA[i] = pA[i]; }
   if (wr) {
     LinkCache& L = S.lc[j];
     L.c = cs; L.s = sn;
@@ -183,8 +210,6 @@ __device__ __forceinline__ void pass1_link(Shared& S, int j, bool wr, float wp[3
     for (int i = 0; i < 9; i++) L.Rw[i] = Rw[i];
 #pragma unroll
     for (int i = 0; i < 3; i++) L.ow[i] = ow[i];
-#pragma unroll
-    for (int i = 0; i < 6; i++) { L.cv[i] = cv[i]; L.pA[i] = pA[i]; }
   }
 #pragma unroll
   for (int i = 0; i < 3; i++) { wp[i] = w[i]; vp[i] = v[i]; owp[i] = ow[i]; }
@@ -196,24 +221,25 @@ __device__ __forceinline__ void pass1_link(Shared& S, int j, bool wr, float wp[3
 // (Iacc, Hacc, Macc, pacc): contribution of the child subtree on entry, of this subtree (parent coords) on exit.
 // I and M symmetric (xx yy zz xy xz yz), H general row-major; 6x6 = [[I, H], [H^T, M]].
 template <int AX>
-__device__ __forceinline__ void pass2_link(Shared& S, int j, bool wr, float Iacc[6], float Hacc[9], float Macc[6], float pacc[6]) {
+__device__ __forceinline__ void pass2_link(Shared& S, const LegConst& K, int k, LinkRegs& G, int j, bool wr, float Iacc[6], float Hacc[9],
+                                           float Macc[6], float pacc[6], float Uo[6], float& invDo, float& uo) {
   LinkCache& L = S.lc[j];
-  const float m = S.mass[j + 1];
-  const float c0 = S.m.link_com[j][0], c1 = S.m.link_com[j][1], c2 = S.m.link_com[j][2];
+  const float m = K.m[k];
+  const float c0 = K.com[k][0], c1 = K.com[k][1], c2 = K.com[k][2];
   const float cc = c0 * c0 + c1 * c1 + c2 * c2;
   float I[6], H[9], M[6], pA[6];
-  I[0] = S.Ic[j + 1][0] + m * (cc - c0 * c0) + Iacc[0];
-  I[1] = S.Ic[j + 1][1] + m * (cc - c1 * c1) + Iacc[1];
-  I[2] = S.Ic[j + 1][2] + m * (cc - c2 * c2) + Iacc[2];
-  I[3] = S.Ic[j + 1][3] - m * c0 * c1 + Iacc[3];
-  I[4] = S.Ic[j + 1][4] - m * c0 * c2 + Iacc[4];
-  I[5] = S.Ic[j + 1][5] - m * c1 * c2 + Iacc[5];
+  I[0] = K.Ic[k][0] + m * (cc - c0 * c0) + Iacc[0];
+  I[1] = K.Ic[k][1] + m * (cc - c1 * c1) + Iacc[1];
+  I[2] = K.Ic[k][2] + m * (cc - c2 * c2) + Iacc[2];
+  I[3] = K.Ic[k][3] - m * c0 * c1 + Iacc[3];
+  I[4] = K.Ic[k][4] - m * c0 * c2 + Iacc[4];
+  I[5] = K.Ic[k][5] - m * c1 * c2 + Iacc[5];
   M[0] = m + Macc[0]; M[1] = m + Macc[1]; M[2] = m + Macc[2]; M[3] = Macc[3]; M[4] = Macc[4]; M[5] = Macc[5];
   H[0] = Hacc[0]; H[1] = -m * c2 + Hacc[1]; H[2] = m * c1 + Hacc[2];
   H[3] = m * c2 + Hacc[3]; H[4] = Hacc[4]; H[5] = -m * c0 + Hacc[5];
   H[6] = -m * c1 + Hacc[6]; H[7] = m * c0 + Hacc[7]; H[8] = Hacc[8];
 #pragma unroll
-  for (int i = 0; i < 6; i++) pA[i] = L.pA[i] + pacc[i];
+  for (int i = 0; i < 6; i++) pA[i] = G.pA[i] + pacc[i];
   // U = IA S with S = e_AX: column AX of I on top, row AX of H below
   float Ut[3], Ub[3];
   if (AX == 0) { Ut[0] = I[0]; Ut[1] = I[3]; Ut[2] = I[4]; Ub[0] = H[0]; Ub[1] = H[1]; Ub[2] = H[2]; }
@@ -221,9 +247,11 @@ __device__ __forceinline__ void pass2_link(Shared& S, int j, bool wr, float Iacc
   const float invD = __builtin_amdgcn_rcpf(Ut[AX]);
   const float u = S.tau[j] - pA[AX];
   const float uD = u * invD;
+  Uo[0] = Ut[0]; Uo[1] = Ut[1]; Uo[2] = Ut[2]; Uo[3] = Ub[0]; Uo[4] = Ub[1]; Uo[5] = Ub[2];
+  invDo = invD; uo = u;
   if (wr) {
     L.U[0] = Ut[0]; L.U[1] = Ut[1]; L.U[2] = Ut[2]; L.U[3] = Ub[0]; L.U[4] = Ub[1]; L.U[5] = Ub[2];
-    L.invD = invD; L.u = u;
+    L.invD = invD;
   }
   // Ia = IA - U U^T / D  (row / column AX of I and row AX of H vanish identically)
   {
@@ -239,34 +267,34 @@ __device__ __forceinline__ void pass2_link(Shared& S, int j, bool wr, float Iacc
   }
   // pa = pA + Ia c + U u / D
   float pat[3], pab[3], t1[3], t2[3], t3[3];
-  symv(I, &L.cv[0], t1);
-  mv3(H, &L.cv[3], t2);
+  symv(I, &G.cv[0], t1);
+  mv3(H, &G.cv[3], t2);
 #pragma unroll
   for (int i = 0; i < 3; i++) pat[i] = pA[i] + t1[i] + t2[i] + Ut[i] * uD;
-  mtv3(H, &L.cv[0], t1);
-  symv(M, &L.cv[3], t3);
+  mtv3(H, &G.cv[0], t1);
+  symv(M, &G.cv[3], t3);
 #pragma unroll
   for (int i = 0; i < 3; i++) pab[i] = pA[3 + i] + t1[i] + t3[i] + Ub[i] * uD;
   // rotate into the parent orientation, then shift by r
-  const float cs = L.c, sn = L.s;
-  const float r[3] = {S.m.joint_pos[j][0], S.m.joint_pos[j][1], S.m.joint_pos[j][2]};
+  const float cs = G.c, sn = G.s;
+  const float r[3] = {K.r[k][0], K.r[k][1], K.r[k][2]};
   float Ip[6], Hp[9], Mp[6];
   rot_sym<AX>(cs, sn, I, Ip);
   rot_gen<AX>(cs, sn, H, Hp);
   rot_sym<AX>(cs, sn, M, Mp);
-  // K = Hp + rx Mp
-  float Mm[9], K[9];
+  // Km = Hp + rx Mp
+  float Mm[9], Km[9];
   sym_to_m3(Mp, Mm);
-  skewmul(r, Mm, K);
+  skewmul(r, Mm, Km);
 #pragma unroll
-  for (int i = 0; i < 9; i++) K[i] += Hp[i];
-  // Ipar = Ip + rx Hp^T - K rx   (symmetric: only the 6 unique entries)
+  for (int i = 0; i < 9; i++) Km[i] += Hp[i];
+  // Ipar = Ip + rx Hp^T - Km rx   (symmetric: only the 6 unique entries)
   {
     // (rx Hp^T)[a][b] = sum_k rx[a][k] Hp[b][k];  (K rx)[a][b] = sum_k K[a][k] rx[k][b]
     const float r0 = r[0], r1 = r[1], r2 = r[2];
     // rows of rx: [0,-r2,r1], [r2,0,-r0], [-r1,r0,0]
 #define RXHT(a, b) ((a) == 0 ? (-r2 * Hp[3 * (b) + 1] + r1 * Hp[3 * (b) + 2]) : ((a) == 1 ? (r2 * Hp[3 * (b)] - r0 * Hp[3 * (b) + 2]) : (-r1 * Hp[3 * (b)] + r0 * Hp[3 * (b) + 1])))
-#define KRX(a, b) ((b) == 0 ? (K[3 * (a) + 1] * r2 - K[3 * (a) + 2] * r1) : ((b) == 1 ? (-K[3 * (a)] * r2 + K[3 * (a) + 2] * r0) : (K[3 * (a)] * r1 - K[3 * (a) + 1] * r0)))
+#define KRX(a, b) ((b) == 0 ? (Km[3 * (a) + 1] * r2 - Km[3 * (a) + 2] * r1) : ((b) == 1 ? (-Km[3 * (a)] * r2 + Km[3 * (a) + 2] * r0) : (Km[3 * (a)] * r1 - Km[3 * (a) + 1] * r0)))
     Iacc[0] = Ip[0] + RXHT(0, 0) - KRX(0, 0);
     Iacc[1] = Ip[1] + RXHT(1, 1) - KRX(1, 1);
     Iacc[2] = Ip[2] + RXHT(2, 2) - KRX(2, 2);
@@ -277,7 +305,7 @@ __device__ __forceinline__ void pass2_link(Shared& S, int j, bool wr, float Iacc
 #undef KRX
   }
 #pragma unroll
-  for (int i = 0; i < 9; i++) Hacc[i] = K[i];
+  for (int i = 0; i < 9; i++) Hacc[i] = Km[i];
 #pragma unroll
   for (int i = 0; i < 6; i++) Macc[i] = Mp[i];
   float fp[3], np_[3], rxf[3];
@@ -290,18 +318,18 @@ __device__ __forceinline__ void pass2_link(Shared& S, int j, bool wr, float Iacc
 
 // ---- pass 3 for one link: joint acceleration ----
 template <int AX>
-__device__ __forceinline__ void pass3_link(Shared& S, int j, bool wr, float ap[6]) {
-  const LinkCache& L = S.lc[j];
-  const float r[3] = {S.m.joint_pos[j][0], S.m.joint_pos[j][1], S.m.joint_pos[j][2]};
+__device__ __forceinline__ void pass3_link(Shared& S, const LegConst& K, int k, const LinkRegs& G, const float U[6], float invD, float u,
+                                           int j, bool wr, float ap[6]) {
+  const float r[3] = {K.r[k][0], K.r[k][1], K.r[k][2]};
   float t[3], at[3], ab[3];
   cross3(&ap[0], r, t);
   t[0] += ap[3]; t[1] += ap[4]; t[2] += ap[5];
-  rot_inv<AX>(L.c, L.s, &ap[0], at);
-  rot_inv<AX>(L.c, L.s, t, ab);
+  rot_inv<AX>(G.c, G.s, &ap[0], at);
+  rot_inv<AX>(G.c, G.s, t, ab);
 #pragma unroll
-  for (int i = 0; i < 3; i++) { at[i] += L.cv[i]; ab[i] += L.cv[3 + i]; }
-  const float Ud = L.U[0] * at[0] + L.U[1] * at[1] + L.U[2] * at[2] + L.U[3] * ab[0] + L.U[4] * ab[1] + L.U[5] * ab[2];
-  const float qdd = (L.u - Ud) * L.invD;
+  for (int i = 0; i < 3; i++) { at[i] += G.cv[i]; ab[i] += G.cv[3 + i]; }
+  const float Ud = U[0] * at[0] + U[1] * at[1] + U[2] * at[2] + U[3] * ab[0] + U[4] * ab[1] + U[5] * ab[2];
+  const float qdd = (u - Ud) * invD;
   at[AX] += qdd;
   if (wr) S.acc[6 + j] = qdd;
 #pragma unroll
@@ -309,7 +337,7 @@ __device__ __forceinline__ void pass3_link(Shared& S, int j, bool wr, float ap[6
 }
 
 // Articulated-body algorithm.  Lanes with the same (lane & 3) do the same leg; results are written by lanes 0..3.
-__device__ static void aba_legs(const KParams& P, Shared& S, int lane) {
+__device__ static void aba_legs(const KParams& P, Shared& S, const LegConst& K, int lane) {
   const int leg = lane & 3;
   const bool wr = lane < 4;
   float Rb[9], wb[3], vb[3];
@@ -325,26 +353,23 @@ __device__ static void aba_legs(const KParams& P, Shared& S, int lane) {
 #pragma unroll
     for (int i = 0; i < 9; i++) S.Rb[i] = Rb[i];
   }
+  LinkRegs G0, G1, G2;
+  float U0[6], U1[6], U2[6], iD0, iD1, iD2, u0, u1, u2;
   {
     float wp[3] = {wb[0], wb[1], wb[2]}, vp[3] = {vb[0], vb[1], vb[2]};
     float Rwp[9], owp[3] = {S.s[O(POS)], S.s[O(POS) + 1], S.s[O(POS) + 2]};
 #pragma unroll
     for (int i = 0; i < 9; i++) Rwp[i] = Rb[i];
-    pass1_link<0>(S, 3 * leg, wr, wp, vp, Rwp, owp);
-    SCHED_FENCE();
-    pass1_link<1>(S, 3 * leg + 1, wr, wp, vp, Rwp, owp);
-    SCHED_FENCE();
-    pass1_link<1>(S, 3 * leg + 2, wr, wp, vp, Rwp, owp);
+    pass1_link<0>(S, K, 0, G0, 3 * leg, wr, wp, vp, Rwp, owp);
+    pass1_link<1>(S, K, 1, G1, 3 * leg + 1, wr, wp, vp, Rwp, owp);
+    pass1_link<1>(S, K, 2, G2, 3 * leg + 2, wr, wp, vp, Rwp, owp);
   }
   SCHED_FENCE();
   float Iacc[6] = {0, 0, 0, 0, 0, 0}, Hacc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Macc[6] = {0, 0, 0, 0, 0, 0};
   float pacc[6] = {0, 0, 0, 0, 0, 0};
-  pass2_link<1>(S, 3 * leg + 2, wr, Iacc, Hacc, Macc, pacc);
-  SCHED_FENCE();
-  pass2_link<1>(S, 3 * leg + 1, wr, Iacc, Hacc, Macc, pacc);
-  SCHED_FENCE();
-  pass2_link<0>(S, 3 * leg, wr, Iacc, Hacc, Macc, pacc);
-  SCHED_FENCE();
+  pass2_link<1>(S, K, 2, G2, 3 * leg + 2, wr, Iacc, Hacc, Macc, pacc, U2, iD2, u2);
+  pass2_link<1>(S, K, 1, G1, 3 * leg + 1, wr, Iacc, Hacc, Macc, pacc, U1, iD1, u1);
+  pass2_link<0>(S, K, 0, G0, 3 * leg, wr, Iacc, Hacc, Macc, pacc, U0, iD0, u0);
   // base: sum the four leg contributions (butterfly over lane bits 0, 1)
 #pragma unroll
   for (int i = 0; i < 6; i++) {
@@ -397,13 +422,9 @@ __device__ static void aba_legs(const KParams& P, Shared& S, int lane) {
   }
   {
     float ap[6] = {a0[0], a0[1], a0[2], a0[3], a0[4], a0[5]};
-    SCHED_FENCE();
-    pass3_link<0>(S, 3 * leg, wr, ap);
-    SCHED_FENCE();
-    pass3_link<1>(S, 3 * leg + 1, wr, ap);
-    SCHED_FENCE();
-    pass3_link<1>(S, 3 * leg + 2, wr, ap);
-    SCHED_FENCE();
+    pass3_link<0>(S, K, 0, G0, U0, iD0, u0, 3 * leg, wr, ap);
+    pass3_link<1>(S, K, 1, G1, U1, iD1, u1, 3 * leg + 1, wr, ap);
+    pass3_link<1>(S, K, 2, G2, U2, iD2, u2, 3 * leg + 2, wr, ap);
   }
   if (lane == 0) {
     // world-frame base accelerations (Bullet: vdot = R (a_lin + w x v)); gravity = uniform-field offset
@@ -585,10 +606,10 @@ __device__ __forceinline__ void row_response(Shared& S, const orr_config& cfg, R
 }
 
 // One physics sub-step.  Returns the fall-proxy flag (wave-uniform) when want_fall.
-__device__ static int physics_substep(const KParams& P, Shared& S, int lane, int sub, bool want_fall) {
+__device__ static int physics_substep(const KParams& P, Shared& S, const LegConst& K, int lane, int sub, bool want_fall) {
   const orr_config& cfg = P.cfg;
   const float dt = cfg.sim_dt, inv_dt = 1.0f / cfg.sim_dt, erp_dt = cfg.contact_erp / cfg.sim_dt;
-  aba_legs(P, S, lane);
+  aba_legs(P, S, K, lane);
   WSYNC();
   for (int i = lane; i < 18; i += kLanes) {
     float u = i < 3 ? S.s[O(ANGVEL) + i] : (i < 6 ? S.s[O(LINVEL) + i - 3] : S.m.jdir[i - 6] * S.s[O(QD) + i - 6]);
@@ -1167,12 +1188,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
   // impulse-response table: stale rows are multiplied by zero impulses, so they only have to be finite
   for (int i = lane; i < kMaxRows * 18; i += kLanes) (&S.ph.sub.W[0][0])[i] = 0.0f;
   WSYNC();
+  LegConst K;
+  load_leg_const(S, lane & 3, K);
 
   if (MODE == 1) {
     if (lane < 12) { const int j = S.m.joint_of_motor[lane]; S.tau[j] = S.m.tau_sign[j] * actions[(size_t)robot * 12 + lane]; }
     WSYNC();
     int fall = 0;
-    for (int s = 0; s < nsub; s++) fall = physics_substep(P, S, lane, sub, true);
+    for (int s = 0; s < nsub; s++) fall = physics_substep(P, S, K, lane, sub, true);
     if (valid && lane == 0 && done_out) done_out[robot] = (uint8_t)fall;
     store_robot(rec, S, lane, valid);
     return;
@@ -1215,7 +1238,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
       if (sstep == c.action_repeat - 1) { seti(S, O(FILTER_VALID), 1); seti(S, O(STEP_COUNTER), geti(S, O(STEP_COUNTER)) + 1); }
     }
     if (sstep == c.action_repeat - 1 && lane < 12) S.s[O(FILTER_ACTION) + lane] = S.s[O(ACTION) + lane];
-    fall = physics_substep(P, S, lane, sub, sstep == c.action_repeat - 1);
+    fall = physics_substep(P, S, K, lane, sub, sstep == c.action_repeat - 1);
     receive_obs(rec, S, lane, valid);
   }
   // ---- get_obs: sensors on_step (minitaur.py:295-299) ----

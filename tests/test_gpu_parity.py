@@ -304,3 +304,42 @@ def test_rollout_across_cycle_wrap_tracks_oracle():
     np.testing.assert_allclose(rg.cpu().numpy(), ro, atol=0.1)
     assert (dg.cpu().numpy().astype(bool) == do).all()
     env.close(); orc.close()
+
+
+def test_device_policy_rollout_and_gae():
+    """SURVEY 8f items 1-2 on the device: batched MLP + rollout buffers + per-robot GAE without leaving the GPU."""
+    import torch
+    from openroborl_amd import policy as pol, rollout
+    from openroborl_amd.env import VecQuadrupedEnv
+    env = VecQuadrupedEnv(num_robot=256, seed=3, robot="laikago", motion_file="laikago_pace", mode="test", auto_reset=True)
+    p = pol.MLPPolicy.from_file(os.path.join(ol.GOLDEN, "policy_laikago_pace.npz"), env.device)
+    buf = rollout.collect_rollout(env, p, horizon=64, deterministic=True)
+    assert buf["obs"].shape == (64, 256, 160) and buf["rewards"].is_cuda
+    assert torch.isfinite(buf["rewards"]).all() and buf["rewards"].mean().item() > 0.5     # the policy tracks the clip
+    assert buf["dones"].float().mean().item() < 0.01
+    adv, ret = rollout.gae(buf["rewards"], buf["vpred"], buf["dones"])
+    nrm = rollout.normalize_per_robot(adv)
+    assert torch.isfinite(nrm).all() and abs(nrm.mean().item()) < 1e-3
+    env.close()
+
+
+def test_legacy_host_buffer_rate_is_reported():
+    """Not a parity test: measures the PCIe-inclusive rate of the list-of-numpy protocol for DESIGN.md."""
+    import time
+    import torch
+    from openroborl_amd.env import VecQuadrupedEnv, LegacyListEnv
+    n = 1024
+    env = VecQuadrupedEnv(num_robot=n, seed=1, robot="laikago", motion_file="laikago_pace", mode="test", auto_reset=False)
+    leg = LegacyListEnv(env, mutate_actions=False)
+    leg.reset()
+    acts = [np.zeros(12, dtype=np.float32) for _ in range(n)]
+    for _ in range(3):
+        leg.step(acts)
+    t0 = time.perf_counter()
+    k = 20
+    for _ in range(k):
+        leg.step(acts)
+    dt = time.perf_counter() - t0
+    print("LEGACY_HOST_RATE robots=%d steps_per_s=%.0f ms_per_step=%.3f" % (n, n * k / dt, 1e3 * dt / k))
+    assert n * k / dt > 1e4
+    env.close()
