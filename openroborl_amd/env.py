@@ -303,6 +303,11 @@ class LegacyListEnv(object):
         obs = obs.detach().cpu().numpy().astype(np.float64)
         rew = rew.detach().cpu().numpy().astype(np.float64)
         done = done.detach().cpu().numpy().astype(bool)
+        ndone = int(done.sum())
+        if ndone > 0:
+            # wrapper_env.py:82-83: the curriculum counter advances by num_robot per step in which ANY robot finished
+            # (the kernel already added one per finished robot)
+            self._env.counters[_abi.CNT_TOTAL_STEP_COUNT] += self.num_robot - ndone
         done_list = [bool(d) for d in done]
         info = [{"terminated": done_list} for _ in range(self.num_robot)]
         return [obs[i] for i in range(self.num_robot)], [float(r) for r in rew], done_list, info

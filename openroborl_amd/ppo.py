@@ -1,0 +1,127 @@
+"""PPO learner in PyTorch-ROCm -- the consumer of rollout.py's [T, N] buffers.
+
+Restates the update of agents/ppo_imitation.py:156-258,352-382 (stable-baselines PPO1 graph) without TF1/MPI:
+  * actor 160 -> 512 -> 256 -> 12 and critic 160 -> 512 -> 256 -> 1, ReLU (run.py:101-105), fixed-variance diagonal
+    Gaussian, std 0.125 (agents/imitation_policies.py:44-51,96-107);
+  * clipped surrogate with clip_param 0.2, value loss mean((v - tdlamret)^2), Adam lr 1e-5, eps 1e-5, one epoch over
+    the segment (run.py:111-125; ppo1/pposgd_simple.py loss terms);
+  * data-parallel: one process per GPU, gradients averaged with ONE all-reduce of a flat 1.7 MB buffer per minibatch
+    (RCCL over xGMI; replaces MpiAdam's Allreduce, stable_baselines/common/mpi_adam.py:40-62).
+The env never leaves the device, so a full iteration is: collect_rollout -> gae -> normalize_per_robot -> update.
+"""
+import math
+
+import numpy as np
+
+from . import policy as pol
+
+
+class ActorCritic(object):
+    """Trainable twin of policy.MLPPolicy (same parameter names as the stable-baselines zips)."""
+
+    def __init__(self, device, obs_dim=160, act_dim=12, hidden=(512, 256), std=pol.PI_STD, params=None, seed=0):
+        import torch
+        self.torch = torch
+        self.device = torch.device(device)
+        self.std = float(std)
+        g = torch.Generator().manual_seed(seed)
+        self.p = {}
+        dims = [obs_dim] + list(hidden)
+        for net, out in (("pi", act_dim), ("vf", 1)):
+            for i in range(len(hidden)):
+                self._init("model/%s_fc%d" % (net, i), dims[i], dims[i + 1], g, math.sqrt(2.0))
+            self._init("model/%s" % net, dims[-1], out, g, 0.01 if net == "pi" else 1.0)
+        if params is not None:
+            for k, v in params.items():
+                if k in self.p:
+                    self.p[k].data.copy_(torch.as_tensor(np.asarray(v), dtype=torch.float32))
+        for v in self.p.values():
+            v.requires_grad_(True)
+
+    def _init(self, name, fan_in, fan_out, g, gain):
+        t = self.torch
+        w = t.randn(fan_in, fan_out, generator=g) * (gain / math.sqrt(fan_in))
+        self.p[name + "/w:0"] = w.to(self.device)
+        self.p[name + "/b:0"] = t.zeros(fan_out, device=self.device)
+
+    def parameters(self):
+        return [self.p[k] for k in sorted(self.p)]
+
+    def _mlp(self, net, x):
+        t = self.torch
+        h = t.relu(x @ self.p["model/%s_fc0/w:0" % net] + self.p["model/%s_fc0/b:0" % net])
+        h = t.relu(h @ self.p["model/%s_fc1/w:0" % net] + self.p["model/%s_fc1/b:0" % net])
+        return h @ self.p["model/%s/w:0" % net] + self.p["model/%s/b:0" % net]
+
+    def mean(self, obs):
+        return self._mlp("pi", obs)
+
+    def value(self, obs):
+        return self._mlp("vf", obs)[:, 0]
+
+    def act(self, obs, deterministic=False, generator=None):
+        t = self.torch
+        with t.no_grad():
+            mu = self.mean(obs)
+            a = mu if deterministic else mu + self.std * t.randn(mu.shape, device=mu.device, generator=generator)
+            return t.clamp(a, -2.0 * math.pi, 2.0 * math.pi), a, self.value(obs)
+
+    def log_prob(self, obs, actions):
+        mu = self.mean(obs)
+        var = self.std * self.std
+        return (-0.5 * ((actions - mu) ** 2) / var - 0.5 * math.log(2.0 * math.pi * var)).sum(dim=1)
+
+    def state_dict(self):
+        return {k: v.detach().cpu().numpy() for k, v in self.p.items()}
+
+
+class PPO(object):
+    def __init__(self, model, clip_param=0.2, lr=1e-5, adam_eps=1e-5, minibatch=4096, vf_coef=1.0, group=None):
+        import torch
+        self.torch = torch
+        self.model = model
+        self.clip = clip_param
+        self.minibatch = int(minibatch)
+        self.vf_coef = vf_coef
+        self.group = group
+        self.opt = torch.optim.Adam(model.parameters(), lr=lr, eps=adam_eps)
+
+    def _allreduce_grads(self):
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+            return
+        t = self.torch
+        params = [p for p in self.model.parameters() if p.grad is not None]
+        flat = t.cat([p.grad.reshape(-1) for p in params])
+        dist.all_reduce(flat, group=self.group)
+        flat /= dist.get_world_size(self.group)
+        off = 0
+        for p in params:
+            n = p.grad.numel()
+            p.grad.copy_(flat[off:off + n].view_as(p.grad))
+            off += n
+
+    def update(self, obs, actions, adv, ret, old_logp=None, epochs=1, generator=None):
+        """obs [B,160], actions [B,12] (unclipped samples), adv [B] (already normalised), ret [B] (TD(lambda) targets)."""
+        t = self.torch
+        B = obs.shape[0]
+        if old_logp is None:
+            with t.no_grad():
+                old_logp = self.model.log_prob(obs, actions)
+        stats = []
+        for _ in range(epochs):
+            perm = t.randperm(B, device=obs.device, generator=generator)
+            for s in range(0, B, self.minibatch):
+                idx = perm[s:s + self.minibatch]
+                logp = self.model.log_prob(obs[idx], actions[idx])
+                ratio = t.exp(logp - old_logp[idx])
+                a = adv[idx]
+                surr = -t.min(ratio * a, t.clamp(ratio, 1.0 - self.clip, 1.0 + self.clip) * a).mean()
+                vf = ((self.model.value(obs[idx]) - ret[idx]) ** 2).mean()
+                loss = surr + self.vf_coef * vf
+                self.opt.zero_grad(set_to_none=True)
+                loss.backward()
+                self._allreduce_grads()
+                self.opt.step()
+                stats.append((float(surr.detach()), float(vf.detach())))
+        return np.mean(stats, axis=0)

@@ -240,6 +240,14 @@ def test_masked_reset_and_legacy_protocol():
     assert isinstance(r[0], float) and isinstance(d[0], bool) and info[0]["terminated"] is d or info[0]["terminated"] == d
     np.testing.assert_allclose(acts[0], env.models[0]["init_motor_angles"], atol=1e-6)   # in-place += INIT (minitaur.py:281)
     assert leg.env_step_counter == 1 and leg.num_robot == 6
+    # curriculum counter: += num_robot in a step where any robot is done (wrapper_env.py:82-83)
+    env.field_int("MAX_EP_STEPS")[:] = 2
+    o, r, d, info = leg.step([np.zeros(12, dtype=np.float32) for _ in range(6)])
+    assert all(d) and info[0]["terminated"] is d
+    torch.cuda.synchronize()
+    assert int(env.counters[_abi.CNT_TOTAL_STEP_COUNT].item()) == 6
+    o = leg.reset()                                   # the runner resets the whole env (imitation_runners.py:185-205)
+    assert leg.env_step_counter == 0
     assert leg.observation_space.shape == (160,) and leg.action_space.shape == (12,)
     # masked reset leaves the other robots untouched
     before = env.state.clone()

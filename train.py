@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""End-to-end motion-imitation training on the device: env (HIP kernels) + batched policy + GAE + PPO, nothing
+leaves the GPU.  Counterpart of `python3 OpenRoboRL/run.py --task imitation_learning_laikago` in train mode
+(run.py:186-237), restricted to what SURVEY.md section 8f lists as "next" rows.
+
+  python train.py --task imitation_learning_laikago --iters 200
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 train.py ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--task", default="imitation_learning_laikago")
+    ap.add_argument("--num-robot", type=int, default=4096)
+    ap.add_argument("--horizon", type=int, default=32)
+    ap.add_argument("--iters", type=int, default=100)
+    ap.add_argument("--lr", type=float, default=1e-4)
+    ap.add_argument("--minibatch", type=int, default=16384)
+    ap.add_argument("--epochs", type=int, default=2)
+    ap.add_argument("--model-file", default="")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--log", default="")
+    args = ap.parse_args()
+
+    import torch
+    from openroborl_amd import dist as odist, policy as pol, ppo, rollout
+    from openroborl_amd.env import VecQuadrupedEnv
+
+    rank, world, local = odist.init_from_env()
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    env = VecQuadrupedEnv(task_name=args.task, num_robot=args.num_robot, mode="train", auto_reset=True, seed=args.seed,
+                          device=dev, num_procs=world, robot_index_offset=rank * args.num_robot)
+    params = pol.load_parameters(args.model_file) if args.model_file else None     # run.py:220-221
+    model = ppo.ActorCritic(dev, params=params, seed=args.seed)                     # same seed -> identical replicas
+    learner = ppo.PPO(model, lr=args.lr, minibatch=args.minibatch)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(args.seed * 1000 + rank)
+    obs = env.reset()
+    t0 = time.time()
+    samples = 0
+    log = []
+    for it in range(args.iters):
+        buf = rollout.collect_rollout(env, model, args.horizon, obs=obs, generator=gen)
+        obs = buf["last_obs"]
+        with torch.no_grad():
+            boot = model.value(obs)
+        # bootstrap with the critic at the segment end (the reference uses 0 there, imitation_runners.py:98-100;
+        # with 32-step segments that bias would dominate)
+        adv, ret = rollout.gae(buf["rewards"], buf["vpred"], buf["dones"], 0.95, 0.95, bootstrap=boot)
+        adv = rollout.normalize_per_robot(adv, eps=1e-8)
+        T, n = buf["rewards"].shape
+        surr, vf = learner.update(buf["obs"].reshape(T * n, -1), buf["actions"].reshape(T * n, -1), adv.reshape(-1),
+                                  ret.reshape(-1), epochs=args.epochs, generator=gen)
+        samples += T * n * world
+        rets, lens, ts, dropped = odist.gather_env_episodes(env, args.horizon)
+        if rank == 0 and (it % 10 == 0 or it == args.iters - 1):
+            rec = {"iter": it, "samples": samples, "sec": round(time.time() - t0, 2),
+                   "mean_step_reward": round(float(buf["rewards"].mean()), 4),
+                   "ep_len_mean": round(float(lens.mean()) if lens.numel() else 0.0, 1),
+                   "ep_ret_mean": round(float(rets.mean()) if rets.numel() else 0.0, 2),
+                   "max_ep_steps": int(env.field_int("MAX_EP_STEPS").max()), "surr": round(float(surr), 4), "vf": round(float(vf), 4)}
+            log.append(rec)
+            print(json.dumps(rec), flush=True)
+    if rank == 0 and args.log:
+        with open(args.log, "w") as f:
+            json.dump(log, f, indent=1)
+    env.close()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
