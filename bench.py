@@ -85,7 +85,8 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus > 1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
-    dev = torch.device("cuda", local)
+    # ORR_BENCH_SINGLE_DEVICE=1 (+ ORR_DIST_BACKEND=gloo): multi-rank rehearsal on a one-GPU box, never a measurement
+    dev = torch.device("cuda", 0 if os.environ.get("ORR_BENCH_SINGLE_DEVICE") else local)
     torch.cuda.set_device(dev)
     n = args.robots_per_gpu
     env = VecQuadrupedEnv(task_name="imitation_learning_laikago", num_robot=n, mode="train", enable_randomizer=True,
@@ -126,7 +127,8 @@ def main():
             since = 0
     sync_all()
     elapsed = time.perf_counter() - t0
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    gloo = world > 1 and torch.distributed.get_backend() == "gloo"
+    el = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if gloo else dev)
     if world > 1:
         torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(el.item())

@@ -1,10 +1,11 @@
 // orr_device.h -- device-side building blocks of the quadruped env kernels (gfx950, wave64).
 //
-// One wavefront owns one robot.  Lane roles change phase by phase:
+// A wavefront serves kRPW = 4 robots, 16 lanes each (ORR_LANES_PER_ROBOT; 32 / 64 are kept for experiments).
+// Lane roles inside a robot's lane group change phase by phase:
 //   motors      lanes 0..11   action filter / interpolation / clip / PD torque (minitaur.py:280-293,438-460,706-769)
 //   legs        lanes 0..3    articulated-body passes over the 3-link leg chains (pybullet stepSimulation)
-//   rows        lanes 0..27   one constraint row each: impulse response, Delassus row, PGS state
-//   dofs        lanes 0..17   generalised velocity u = [omega_w, v_w, joint rates]
+//   rows        lanes 0..15   constraint rows in two banks: impulse response, Delassus column, PGS state
+//   dofs        18 generalised velocities u = [omega_w, v_w, joint rates], strided over the lanes
 // Cross-lane data goes through LDS (register arrays are never indexed dynamically).
 //
 // Arithmetic: float32.  Reference citations are relative to /root/reference/OpenRoboRL/.

@@ -25,7 +25,7 @@ def init_from_env(backend=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("ORR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
@@ -75,9 +75,12 @@ def allgather_episode_stats(returns, lengths, total_timesteps, dropped=0, capaci
     buf = pack_episode_stats(returns, lengths, total_timesteps, dropped, capacity)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return unpack_episode_stats([buf], capacity)
+    dev = buf.device
+    if dist.get_backend(group) == "gloo" and buf.is_cuda:   # rehearsal on a one-GPU box: stage through the host
+        buf = buf.cpu()
     out = [torch.empty_like(buf) for _ in range(dist.get_world_size(group))]
     dist.all_gather(out, buf, group=group)
-    return unpack_episode_stats(out, capacity)
+    return unpack_episode_stats([o.to(dev) for o in out], capacity)
 
 
 def gather_env_episodes(env, steps_since_last, capacity=4096, group=None):
