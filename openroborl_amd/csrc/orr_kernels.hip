@@ -1054,7 +1054,10 @@ __device__ static void sensors_push(Shared& S, int lane, bool fill_all) {
 // ================================================================================================
 __device__ static void reset_robot(const KParams& P, float* rec, Shared& S, int lane, bool valid, long long total_step_count, float* obs) {
   const orr_config& c = P.cfg;
-  const uint32_t robot = (uint32_t)geti(S, O(ROBOT_INDEX)), ep = (uint32_t)geti(S, O(EPISODE_IDX));
+  // every reset starts a new episode = a new RNG stream (robot, episode)
+  const uint32_t robot = (uint32_t)geti(S, O(ROBOT_INDEX)), ep = (uint32_t)geti(S, O(EPISODE_IDX)) + 1u;
+  WSYNC();
+  if (lane == 0) seti(S, O(EPISODE_IDX), (int)ep);
   // 1-2. default pose at the grid slot, counters, ring, filter (minitaur.py:246-268, 465-483)
   if (lane < 3) {
     S.s[O(POS) + lane] = S.m.init_pos[lane] + (lane < 2 ? S.s[O(GRID_OFFSET) + lane] : 0.0f);
@@ -1326,8 +1329,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
     }
     WSYNC();
     if (c.flags & ORR_FLAG_AUTO_RESET) {
-      if (lane == 0) seti(S, O(EPISODE_IDX), geti(S, O(EPISODE_IDX)) + 1);
-      WSYNC();
       reset_robot(P, rec, S, lane, valid, total_snapshot, obs);
     }
   }

@@ -104,6 +104,16 @@ def test_reset_semantics(robot):
     env.close()
 
 
+def test_every_reset_draws_a_new_episode():
+    env, _, _ = make(n=8, seed=3)
+    o1 = env.reset()
+    t1 = env.field("TIME_OFFSET").copy()
+    o2 = env.reset()
+    assert np.all(env.field("EPISODE_IDX") == 2)
+    assert np.abs(env.field("TIME_OFFSET") - t1).max() > 1e-3 and np.abs(o1 - o2).max() > 1e-3
+    env.close()
+
+
 def test_reset_is_deterministic_and_seeded():
     a, _, _ = make(seed=11)
     b, _, _ = make(seed=11)
