@@ -33,6 +33,20 @@ def load_parameters(path):
     return {_norm_key(k): params[k].astype(np.float32) for k in params.files}
 
 
+def save_parameters_zip(path, params, data=None):
+    """Write weights in the stable-baselines zip layout (`data` JSON, `parameter_list` JSON, `parameters` npz;
+    stable_baselines/common/base_class.py:552-590) so that the reference's `agent.load_parameters(model_file)`
+    (run.py:220-221) can read a policy trained here.  `data` carries no pickled objects (load_parameters ignores it)."""
+    import json
+    names = sorted(params)
+    buf = io.BytesIO()
+    np.savez(buf, **{k: np.asarray(params[k], dtype=np.float32) for k in names})
+    with zipfile.ZipFile(path, "w") as z:
+        z.writestr("data", json.dumps(data or {}))
+        z.writestr("parameter_list", json.dumps(names))
+        z.writestr("parameters", buf.getvalue())
+
+
 class MLPPolicy(object):
     def __init__(self, params, device, std=PI_STD):
         import torch

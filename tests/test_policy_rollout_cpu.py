@@ -69,3 +69,21 @@ def test_collect_rollout_with_a_fake_env():
     assert buf["obs"].shape == (4, 3, 160) and buf["actions"].shape == (4, 3, 12)
     assert torch.equal(buf["obs"][2], torch.full((3, 160), 2.0)) and buf["dones"][:, 1].all() and not buf["dones"][:, 0].any()
     assert torch.equal(buf["last_obs"], torch.full((3, 160), 4.0))
+
+
+def test_stable_baselines_zip_round_trip(tmp_path):
+    from openroborl_amd import ppo
+    m = ppo.ActorCritic("cpu", seed=3)
+    path = str(tmp_path / "model.zip")
+    pol.save_parameters_zip(path, m.state_dict())
+    import json, zipfile
+    with zipfile.ZipFile(path) as z:
+        assert set(z.namelist()) == {"data", "parameter_list", "parameters"}
+        assert json.loads(z.read("parameter_list"))[0].startswith("model/")
+    w = pol.load_parameters(path)
+    for k, v in m.state_dict().items():
+        np.testing.assert_array_equal(w[k], v)
+    p = pol.MLPPolicy.from_file(path, "cpu")
+    obs = torch.randn(4, 160)
+    np.testing.assert_allclose(p.mean(obs).numpy(), m.mean(obs).detach().numpy(), atol=1e-6)
+    np.testing.assert_allclose(p.value(obs).numpy(), m.value(obs).detach().numpy(), atol=1e-6)

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--model-file", default="")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--log", default="")
+    ap.add_argument("--save", default="", help="write the trained weights as a stable-baselines style zip")
     args = ap.parse_args()
 
     import torch
@@ -70,6 +71,8 @@ def main():
                    "max_ep_steps": int(env.field_int("MAX_EP_STEPS").max()), "surr": round(float(surr), 4), "vf": round(float(vf), 4)}
             log.append(rec)
             print(json.dumps(rec), flush=True)
+    if rank == 0 and args.save:
+        pol.save_parameters_zip(args.save, model.state_dict())
     if rank == 0 and args.log:
         with open(args.log, "w") as f:
             json.dump(log, f, indent=1)
