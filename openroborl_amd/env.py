@@ -252,6 +252,17 @@ class VecQuadrupedEnv(object):
         self.counters.copy_(d["counters"])
         self._env_step_counter = int(d["env_step_counter"])
 
+    def stats(self):
+        """Diagnostic counters (metrics): totals + histogram of the last done reasons.  Syncs."""
+        c = self.counters.cpu().numpy()
+        reasons = self.field_int("DONE_REASON")[:, 0].cpu().numpy()
+        names = (("contact_fall", _abi.DONE_CONTACT_FALL), ("root_pos", _abi.DONE_ROOT_POS), ("root_rot", _abi.DONE_ROOT_ROT),
+                 ("time_limit", _abi.DONE_TIME_LIMIT), ("non_finite", _abi.DONE_NAN))
+        return {"total_timesteps": int(c[_abi.CNT_TOTAL_TIMESTEPS]), "curriculum_counter": int(c[_abi.CNT_TOTAL_STEP_COUNT]),
+                "episodes_logged": int(c[_abi.CNT_EPISODES]), "episodes_dropped": int(c[_abi.CNT_EPLOG_DROPPED]),
+                "last_done_reason": {k: int(((reasons & bit) != 0).sum()) for k, bit in names},
+                "max_episode_steps": int(self.field_int("MAX_EP_STEPS").max().item())}
+
     def episode_log(self):
         """(returns[K], lengths[K]) of the episodes finished since the last call; clears the log.  Syncs."""
         n = int(self.counters[_abi.CNT_EPISODES].item())

@@ -354,3 +354,28 @@ def test_legacy_host_buffer_rate_is_reported():
     print("LEGACY_HOST_RATE robots=%d steps_per_s=%.0f ms_per_step=%.3f" % (n, n * k / dt, 1e3 * dt / k))
     assert n * k / dt > 1e4
     env.close()
+
+
+def test_checkpoint_resume_is_bitwise():
+    """state_dict / load_state_dict (the env state is a handful of device tensors)."""
+    import torch
+    from openroborl_amd.env import VecQuadrupedEnv
+    env = VecQuadrupedEnv(num_robot=64, seed=9, robot="laikago", motion_file="laikago_pace", mode="train", auto_reset=True)
+    env.reset()
+    g = torch.Generator().manual_seed(0)
+    acts = [(torch.randn(64, 12, generator=g) * 0.2).to(env.device) for _ in range(30)]
+    for a in acts[:10]:
+        env.step(a)
+    ck = env.state_dict()
+    outs = []
+    for a in acts[10:]:
+        o, r, d, _ = env.step(a)
+        outs.append((o.clone(), r.clone(), d.clone()))
+    env.load_state_dict(ck)
+    for a, (o0, r0, d0) in zip(acts[10:], outs):
+        o, r, d, _ = env.step(a)
+        assert torch.equal(o, o0) and torch.equal(r, r0) and torch.equal(d, d0)
+    st = env.stats()
+    assert st["total_timesteps"] > 0
+    assert set(st["last_done_reason"]) == {"contact_fall", "root_pos", "root_rot", "time_limit", "non_finite"}
+    env.close()
