@@ -299,18 +299,35 @@ __device__ __forceinline__ void symv(const float S[6], const float v[3], float o
   o[0] = a; o[1] = b; o[2] = c;
 }
 
-// value of x in lane r (< 16, compile-time constant at every call site) of this robot's lane group
-__device__ __forceinline__ float bcast_row(float x, int r, int sub) {
+// value of x in lane R (< 16) of this robot's lane group.  With 16 lanes per robot a robot is one DPP row and the
+// broadcast is a single v_mov_b32_dpp row_newbcast:R (gfx90a+; every lane of the wave is active at the call sites).
+template <int R>
+__device__ __forceinline__ float bcast_lane(float x, int sub) {
   const int v = __float_as_int(x);
-  if (kRPW == 1) return __int_as_float(__builtin_amdgcn_readlane(v, r));
+  if (kRPW == 1) return __int_as_float(__builtin_amdgcn_readlane(v, R));
   if (kRPW == 2) {
-    const int a = __builtin_amdgcn_readlane(v, r), b = __builtin_amdgcn_readlane(v, r + 32);
+    const int a = __builtin_amdgcn_readlane(v, R), b = __builtin_amdgcn_readlane(v, R + 32);
     return __int_as_float(sub ? b : a);
   }
-  const int a0 = __builtin_amdgcn_readlane(v, r), a1 = __builtin_amdgcn_readlane(v, r + 16);
-  const int a2 = __builtin_amdgcn_readlane(v, r + 32), a3 = __builtin_amdgcn_readlane(v, r + 48);
+#ifndef ORR_READLANE_BCAST
+  return __int_as_float(__builtin_amdgcn_update_dpp(v, v, 0x150 + R, 0xF, 0xF, false));
+#else
+  const int a0 = __builtin_amdgcn_readlane(v, R), a1 = __builtin_amdgcn_readlane(v, R + 16);
+  const int a2 = __builtin_amdgcn_readlane(v, R + 32), a3 = __builtin_amdgcn_readlane(v, R + 48);
   const int lo = (sub & 1) ? a1 : a0, hi = (sub & 1) ? a3 : a2;
   return __int_as_float((sub & 2) ? hi : lo);
+#endif
+}
+// same with r a loop counter of an unrolled loop (the switch folds to one case)
+__device__ __forceinline__ float bcast_row(float x, int r, int sub) {
+  switch (r) {
+    case 0: return bcast_lane<0>(x, sub);   case 1: return bcast_lane<1>(x, sub);   case 2: return bcast_lane<2>(x, sub);
+    case 3: return bcast_lane<3>(x, sub);   case 4: return bcast_lane<4>(x, sub);   case 5: return bcast_lane<5>(x, sub);
+    case 6: return bcast_lane<6>(x, sub);   case 7: return bcast_lane<7>(x, sub);   case 8: return bcast_lane<8>(x, sub);
+    case 9: return bcast_lane<9>(x, sub);   case 10: return bcast_lane<10>(x, sub); case 11: return bcast_lane<11>(x, sub);
+    case 12: return bcast_lane<12>(x, sub); case 13: return bcast_lane<13>(x, sub); case 14: return bcast_lane<14>(x, sub);
+    default: return bcast_lane<15>(x, sub);
+  }
 }
 
 // sine / cosine of a joint angle (|a| is a few radians at most).  Cody-Waite reduction to [-pi/4, pi/4] with a

@@ -6,6 +6,7 @@
 // this device: 33 physics sub-steps, observation, reward, termination, optional auto-reset.
 // Specification of every stage: DESIGN.md section 4; CPU restatement: oracle/orr_oracle.c.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
@@ -605,6 +606,92 @@ __device__ __forceinline__ void row_response(Shared& S, const orr_config& cfg, R
   R.lam = (R.active && R.warm >= 0) ? cfg.warmstart_factor * S.s[O(LAMBDA) + R.warm] : 0.0f;
 }
 
+// compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+// Row update tail: d = (sum - lam) of lane SRC broadcast to the robot's lanes; lam = sum in lane SRC.
+// Written out for the 16-lane layout: (a) the lane compare is redone at each use - hoisted out of the sweep loop the 28
+// lane masks cost 28 SGPR pairs (spills + reloads); (b) the compare + select sit between the subtraction and the DPP
+// move that reads its result, which covers the two wait states that hazard needs.
+template <int SRC>
+__device__ __forceinline__ float row_commit(float& lam, float sum, int lane, int sub) {
+#if !defined(ORR_READLANE_BCAST)
+  if (kRPW == 4) {
+    float d;
+    asm("v_sub_f32_e32 %0, %3, %1\n\t"
+        "v_cmp_eq_u32_e32 vcc, %4, %2\n\t"
+        "v_cndmask_b32_e32 %1, %1, %3, vcc\n\t"
+        "v_mov_b32_dpp %0, %0 row_newbcast:%4 row_mask:0xf bank_mask:0xf"
+        : "=&v"(d), "+v"(lam) : "v"(lane), "v"(sum), "n"(SRC) : "vcc");
+    return d;
+  }
+#endif
+  const float d = bcast_lane<SRC>(sum - lam, sub);
+  lam = lane == SRC ? sum : lam;
+  return d;
+}
+
+// The Gauss-Seidel sweeps over the row slots in solve order (btMultiBodyConstraintSolver::solveSingleIteration),
+// Delassus form.  Every row lane keeps, for its row, lambda and z = (rhs - (A lambda)) / diag, so that a row update is
+//   sum = clamp(lambda + z);  d = broadcast(sum - lambda);  z += Ac[r] d   (Ac[r] = -A[row][r] / diag, every row lane)
+// = 7 vector instructions.  HAS_B: some robot of the wave has an active joint-limit row (bank B is swept too).
+// Knee rows are swept unconditionally, contact rows per leg when some robot of the wave has that toe in contact (a
+// row visited for a robot where it is inactive is a no-op: its bounds, 1/diag and lambda are zero).
+template <bool HAS_B>
+__device__ __forceinline__ void pgs_sweeps(int iters, unsigned int mask, int lane, int sub, Row& A, Row& B,
+                                           const float (&AcA)[kMaxRows], const float (&AcB)[kMaxRows]) {
+  float lamA = A.lam, lamN = A.lam_n, lamB = B.lam;
+  float zA = fmaf(-A.w, A.jdi, A.rhs), zB = fmaf(-B.w, B.jdi, B.rhs);
+  const float muA = A.mu_e, hiA = A.hi_c, loA = A.lo_c, hiB = B.hi_c, loB = B.lo_c;
+  float isn[4];
+#pragma unroll
+  for (int g = 0; g < 4; g++) isn[g] = A.nrm_slot == 16 + g ? 1.0f : 0.0f;
+  float hiE = fmaf(muA, lamN, hiA), loE = fmaf(-muA, lamN, loA);
+  const unsigned int cm = __builtin_amdgcn_readfirstlane((mask >> 16) & 0xFu);  // legs with a toe contact (wave-uniform)
+  for (int it = 0; it < iters; it++) {
+    auto rowA = [&](auto rc) __attribute__((always_inline)) {
+      constexpr int r = decltype(rc)::value, src = r < 4 ? r : r - 12;
+      const float sum = __builtin_amdgcn_fmed3f(lamA + zA, loE, hiE);
+      const float d = row_commit<src>(lamA, sum, lane, sub);
+      zA = fmaf(AcA[r], d, zA);
+      if (HAS_B) zB = fmaf(AcB[r], d, zB);
+      if (r >= 16 && r < 20) {  // a normal impulse moved: friction bounds of the rows of that toe follow
+        lamN = fmaf(isn[r >= 16 && r < 20 ? r - 16 : 0], d, lamN);
+        hiE = fmaf(muA, lamN, hiA); loE = fmaf(-muA, lamN, loA);
+      }
+    };
+    static_for<0, 4>(rowA);
+    if (HAS_B) {
+      static_for<4, 16>([&](auto rc) __attribute__((always_inline)) {
+        constexpr int r = decltype(rc)::value;
+        if ((mask >> r) & 1u) {
+          const float sum = __builtin_amdgcn_fmed3f(lamB + zB, loB, hiB);
+          const float d = row_commit<r>(lamB, sum, lane, sub);
+          zA = fmaf(AcA[r], d, zA);
+          zB = fmaf(AcB[r], d, zB);
+        }
+      });
+    }
+    static_for<0, 4>([&](auto gc) __attribute__((always_inline)) {
+      constexpr int g = decltype(gc)::value;
+      if ((cm >> g) & 1u) rowA(std::integral_constant<int, 16 + g>{});
+    });
+    static_for<0, 4>([&](auto gc) __attribute__((always_inline)) {
+      constexpr int g = decltype(gc)::value;
+      if ((cm >> g) & 1u) {
+        rowA(std::integral_constant<int, 20 + 2 * g>{});
+        rowA(std::integral_constant<int, 21 + 2 * g>{});
+      }
+    });
+  }
+  A.lam = lamA; A.lam_n = lamN; B.lam = lamB;
+}
+
 // One physics sub-step.  Returns the fall-proxy flag (wave-uniform) when want_fall.
 __device__ static int physics_substep(const KParams& P, Shared& S, const LegConst& K, int lane, int sub, bool want_fall) {
   const orr_config& cfg = P.cfg;
@@ -654,7 +741,8 @@ __device__ static int physics_substep(const KParams& P, Shared& S, const LegCons
   row_response(S, cfg, A, rowlane ? (lane < 4 ? lane : lane + 12) : 0);
   if (anyB) row_response(S, cfg, B, (rowlane && lane >= 4) ? lane : 4);
   WSYNC();
-  // Delassus columns Ac[r] = J . W[r] (= A[row][r]) kept in registers; w = (A lambda) for the warm start
+  // Delassus columns A[row][r] = J . W[r], kept in registers already scaled for the sweeps: Ac[r] = -A[row][r] / diag(row);
+  // w = (A lambda) of the warm start
   float AcA[kMaxRows], AcB[kMaxRows];
 #pragma unroll
   for (int r = 0; r < kMaxRows; r++) {
@@ -662,36 +750,19 @@ __device__ static int physics_substep(const KParams& P, Shared& S, const LegCons
     if ((mask >> r) & 1u) {
       const float* Wr = S.ph.sub.W[r];
       const float l0 = (r >= 4 && r < 16) ? bcast_row(B.lam, r, sub) : bcast_row(A.lam, r < 4 ? r : r - 12, sub);
-      AcA[r] = row_dot(A, Wr);
-      A.w += AcA[r] * l0;
+      const float a = row_dot(A, Wr);
+      A.w += a * l0;
+      AcA[r] = -a * A.jdi;
       if (r >= 16 && r < 20 && A.nrm_slot == r) A.lam_n = l0;
-      if (anyB) { AcB[r] = row_dot(B, Wr); B.w += AcB[r] * l0; }
+      if (anyB) { const float b = row_dot(B, Wr); B.w += b * l0; AcB[r] = -b * B.jdi; }
+      asm volatile("" : "+v"(AcA[r]), "+v"(AcB[r]));  // keep the scaled value (do not re-derive it inside the sweeps)
     }
   }
   // projected Gauss-Seidel (btMultiBodyConstraintSolver::solveSingleIteration), Delassus form: every row lane keeps
-  // lambda and w = (A lambda) of its row(s); one broadcast per row update
-  for (int it = 0; it < cfg.solver_iters; it++) {
-#pragma unroll
-    for (int r = 0; r < kMaxRows; r++) {
-      if ((mask >> r) & 1u) {
-        float d_r;
-        if (r >= 4 && r < 16) {
-          const float sum = __builtin_amdgcn_fmed3f(B.lam + (B.rhs - B.w * B.jdi), B.lo_c, B.hi_c);
-          d_r = bcast_row(sum - B.lam, r, sub);
-          if (lane == r) B.lam = sum;
-        } else {
-          const int src = r < 4 ? r : r - 12;
-          const float hi_e = fmaf(A.mu_e, A.lam_n, A.hi_c), lo_e = fmaf(-A.mu_e, A.lam_n, A.lo_c);
-          const float sum = __builtin_amdgcn_fmed3f(A.lam + (A.rhs - A.w * A.jdi), lo_e, hi_e);
-          d_r = bcast_row(sum - A.lam, src, sub);
-          if (lane == src) A.lam = sum;
-          if (r >= 16 && r < 20 && A.nrm_slot == r) A.lam_n += d_r;
-        }
-        A.w += AcA[r] * d_r;
-        if (anyB) B.w += AcB[r] * d_r;
-      }
-    }
-  }
+  // lambda and w = (A lambda) of its row(s); one broadcast per row update.  Two instantiations: with and without the
+  // joint-limit bank.
+  if (anyB) pgs_sweeps<true>(cfg.solver_iters, mask, lane, sub, A, B, AcA, AcB);
+  else pgs_sweeps<false>(cfg.solver_iters, mask, lane, sub, A, B, AcA, AcB);
   // contact impulses are remembered for the next sub-step's warm start (0 for open contacts)
   if (rowlane && lane >= 4) S.s[O(LAMBDA) + A.warm] = A.active ? A.lam : 0.0f;
   // ---------------- velocity update, Bullet coordinate-velocity clamp, semi-implicit Euler ----------------
