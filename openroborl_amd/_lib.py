@@ -36,8 +36,9 @@ def build(force=False, verbose=False):
     """Compile the HIP kernels + C-ABI for gfx950 into the in-tree shared library."""
     if not force and not needs_build():
         return LIB_PATH
+    # one wave per SIMD and up to 512 VGPRs: schedule for instruction-level parallelism, not for occupancy
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-Wno-unused-value",
-           "-o", LIB_PATH, SRC]
+           "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-o", LIB_PATH, SRC]
     for var in ("ORR_WAVES_PER_EU", "ORR_LANES_PER_ROBOT"):      # tuning experiments only
         if os.environ.get(var):
             cmd.insert(-3, "-D%s=%d" % (var, int(os.environ[var])))

@@ -154,10 +154,12 @@ struct Shared {
   float tau[12];              // joint torques (internal sign convention), joint order
   float acc[18];
   float ustar[18];
-  float du[18];
   float co[20];               // control (latency-delayed) observation
   float red[64];
   PhaseBuf ph;
+#ifdef ORR_PHASE_TIMERS
+  long long pt_acc[16], pt_last;  // development aid, see PT() in orr_kernels.hip
+#endif
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -299,6 +301,13 @@ __device__ __forceinline__ void symv(const float S[6], const float v[3], float o
   o[0] = a; o[1] = b; o[2] = c;
 }
 
+// sum of x over the 4 lanes of a quad (lanes 4q..4q+3), in every lane of the quad
+__device__ __forceinline__ float quad_sum(float x) {
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));  // quad_perm:[1,0,3,2]
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, true));  // quad_perm:[2,3,0,1]
+  return x;
+}
+
 // value of x in lane R (< 16) of this robot's lane group.  With 16 lanes per robot a robot is one DPP row and the
 // broadcast is a single v_mov_b32_dpp row_newbcast:R (gfx90a+; every lane of the wave is active at the call sites).
 template <int R>
@@ -365,7 +374,7 @@ __device__ __forceinline__ void qmul(const float a[4], const float b[4], float o
 }
 __device__ __forceinline__ void qconj(const float q[4], float o[4]) { o[0] = -q[0]; o[1] = -q[1]; o[2] = -q[2]; o[3] = q[3]; }
 __device__ __forceinline__ void qinv(const float q[4], float o[4]) {
-  float n = 1.0f / (q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  float n = __builtin_amdgcn_rcpf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
   o[0] = -q[0] * n; o[1] = -q[1] * n; o[2] = -q[2] * n; o[3] = q[3] * n;
 }
 // pose3d.QuaternionRotatePoint (pose3d.py:213-231): q [p,0] q^-1

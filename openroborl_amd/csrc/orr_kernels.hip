@@ -13,6 +13,19 @@
 
 #include "orr_device.h"
 
+// Development aid (tools/phase_cycles.py): -DORR_PHASE_TIMERS makes lane 0 of one wave accumulate shader-clock cycles
+// per phase (Shared::pt_acc) and add them to g_phase_cycles at the end of the launch.
+#ifdef ORR_PHASE_TIMERS
+__device__ long long g_phase_cycles[16];
+#define PT_INIT() do { if (threadIdx.x == 0) { for (int i_ = 0; i_ < 16; i_++) S.pt_acc[i_] = 0; S.pt_last = clock64(); } } while (0)
+#define PT(k) do { if (threadIdx.x == 0) { const long long t_ = clock64(); S.pt_acc[k] += t_ - S.pt_last; S.pt_last = clock64(); } } while (0)
+#define PT_FLUSH() do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) for (int i_ = 0; i_ < 16; i_++) atomicAdd((unsigned long long*)&g_phase_cycles[i_], (unsigned long long)S.pt_acc[i_]); } while (0)
+#else
+#define PT_INIT()
+#define PT(k)
+#define PT_FLUSH()
+#endif
+
 using namespace orr;
 
 #define O(name) ORR_OFF_##name
@@ -90,6 +103,77 @@ __device__ static void receive_obs(float* rec, Shared& S, int lane, bool valid) 
     if (valid) rec[O(RING) + head * ORR_RING_ENTRY + i] = val;
   }
   WSYNC();
+  if (lane == 0) {
+    seti(S, O(RING_HEAD), head);
+    seti(S, O(RING_LEN), len + 1 > ORR_RING_DEPTH ? ORR_RING_DEPTH : len + 1);
+  }
+  WSYNC();
+}
+
+// Sub-step fast path of (receive_obs; ctrl_obs): the ring entries that the control observation after the next push will
+// need are already in the ring before the physics sub-step (all but the pushed one), so their loads are issued early
+// (ring_prefetch) and consumed after the sub-step (ring_push_and_ctrl_obs); the global-memory latency is hidden.
+struct RingFetch {
+  float e0[2], e1[2];  // words lane and 16 + lane of the two entries being blended
+  float al;
+  bool new0, new1, same;  // entry k is the one about to be pushed
+};
+struct RingLatency {  // per-episode constants of Minitaur._get_delay_obs (minitaur.py:336-357)
+  int n;       // whole sub-steps of latency
+  float al;    // fraction towards entry n + 1
+  bool none;   // latency <= 0: newest entry
+};
+__device__ __forceinline__ RingLatency ring_latency(const KParams& P, const Shared& S) {
+  const float lat = S.s[O(LATENCY)], dt = P.cfg.sim_dt;
+  RingLatency L;
+  L.none = lat <= 0.0f;
+  L.n = (int)(lat / dt);
+  L.al = (lat - L.n * dt) / dt;
+  return L;
+}
+__device__ __forceinline__ void ring_prefetch(const RingLatency& L, const float* rec, const Shared& S, int lane, RingFetch& F) {
+  const int len0 = geti(S, O(RING_LEN)), head = (geti(S, O(RING_HEAD)) + 1) % ORR_RING_DEPTH;  // after the push
+  const int len = len0 + 1 > ORR_RING_DEPTH ? ORR_RING_DEPTH : len0 + 1;
+  int k0 = 0, k1 = 0;
+  F.al = 0.0f;
+  if (!(L.none || len == 1)) {
+    if (L.n + 1 >= len) { k0 = k1 = len - 1; }
+    else { k0 = L.n; k1 = L.n + 1; F.al = L.al; }
+  }
+  F.same = k0 == k1; F.new0 = k0 == 0; F.new1 = k1 == 0;
+  const int i0 = (head - k0 + 2 * ORR_RING_DEPTH) % ORR_RING_DEPTH, i1 = (head - k1 + 2 * ORR_RING_DEPTH) % ORR_RING_DEPTH;
+  const float* p0 = rec + O(RING) + i0 * ORR_RING_ENTRY;
+  const float* p1 = rec + O(RING) + i1 * ORR_RING_ENTRY;
+  const int hi = lane < 3 ? 16 + lane : lane;  // lanes >= 3: harmless duplicate of word `lane`
+  F.e0[0] = p0[lane]; F.e0[1] = p0[hi];
+  F.e1[0] = p1[lane]; F.e1[1] = p1[hi];
+}
+__device__ __forceinline__ void ring_push_and_ctrl_obs(float* rec, Shared& S, int lane, bool valid, const RingFetch& F) {
+  static_assert(ORR_RING_ENTRY == 20, "lane mapping below assumes 20-word entries");
+  const int head = (geti(S, O(RING_HEAD)) + 1) % ORR_RING_DEPTH, len = geti(S, O(RING_LEN));
+  float qi[4], rel[4], ri[4], Rm[9], rate[3];
+  qinv(S.m.init_quat, qi);
+  qmul(&S.s[O(QUAT)], qi, rel);  // orientation relative to the initial one (minitaur.py:325-331)
+  qinv(rel, ri);
+  q_to_mat(ri, Rm);
+  mv3(Rm, &S.s[O(ANGVEL)], rate);  // get_true_base_rpy_rate (minitaur.py:640-672)
+  // word `lane`: motor angles 0..11, relative quaternion 12..15; word 16 + lane (lanes 0..3): rate 16..18, pad 19
+  float va, vb;
+  {
+    const int m = lane < 12 ? lane : 0, j = S.m.joint_of_motor[m];
+    const float ang = (S.s[O(Q) + j] - S.m.motor_offset[m]) * S.m.motor_dir[m];  // get_true_motor_angles (:543-553)
+    va = lane < 12 ? ang : (lane == 12 ? rel[0] : (lane == 13 ? rel[1] : (lane == 14 ? rel[2] : rel[3])));
+    vb = lane == 0 ? rate[0] : (lane == 1 ? rate[1] : (lane == 2 ? rate[2] : 0.0f));
+  }
+  float* dst = rec + O(RING) + head * ORR_RING_ENTRY;
+  if (valid) {
+    dst[lane] = va;
+    if (lane < 4) dst[16 + lane] = vb;
+  }
+  const float a0 = F.new0 ? va : F.e0[0], a1 = F.new1 ? va : F.e1[0];
+  const float b0 = F.new0 ? vb : F.e0[1], b1 = F.new1 ? vb : F.e1[1];
+  S.co[lane] = F.same ? a0 : (1.0f - F.al) * a0 + F.al * a1;
+  if (lane < 3) S.co[16 + lane] = F.same ? b0 : (1.0f - F.al) * b0 + F.al * b1;
   if (lane == 0) {
     seti(S, O(RING_HEAD), head);
     seti(S, O(RING_LEN), len + 1 > ORR_RING_DEPTH ? ORR_RING_DEPTH : len + 1);
@@ -371,15 +455,11 @@ __device__ static void aba_legs(const KParams& P, Shared& S, const LegConst& K, 
   pass2_link<1>(S, K, 2, G2, 3 * leg + 2, wr, Iacc, Hacc, Macc, pacc, U2, iD2, u2);
   pass2_link<1>(S, K, 1, G1, 3 * leg + 1, wr, Iacc, Hacc, Macc, pacc, U1, iD1, u1);
   pass2_link<0>(S, K, 0, G0, 3 * leg, wr, Iacc, Hacc, Macc, pacc, U0, iD0, u0);
-  // base: sum the four leg contributions (butterfly over lane bits 0, 1)
+  // base: sum the four leg contributions (butterfly over lane bits 0, 1 = DPP quad permutes, fused into the adds)
 #pragma unroll
-  for (int i = 0; i < 6; i++) {
-    Iacc[i] += __shfl_xor(Iacc[i], 1); Iacc[i] += __shfl_xor(Iacc[i], 2);
-    Macc[i] += __shfl_xor(Macc[i], 1); Macc[i] += __shfl_xor(Macc[i], 2);
-    pacc[i] += __shfl_xor(pacc[i], 1); pacc[i] += __shfl_xor(pacc[i], 2);
-  }
+  for (int i = 0; i < 6; i++) { Iacc[i] = quad_sum(Iacc[i]); Macc[i] = quad_sum(Macc[i]); pacc[i] = quad_sum(pacc[i]); }
 #pragma unroll
-  for (int i = 0; i < 9; i++) { Hacc[i] += __shfl_xor(Hacc[i], 1); Hacc[i] += __shfl_xor(Hacc[i], 2); }
+  for (int i = 0; i < 9; i++) Hacc[i] = quad_sum(Hacc[i]);
   float a0[6];
   {
     float A6[36], pA0[6];
@@ -637,32 +717,34 @@ __device__ __forceinline__ float row_commit(float& lam, float sum, int lane, int
 }
 
 // The Gauss-Seidel sweeps over the row slots in solve order (btMultiBodyConstraintSolver::solveSingleIteration),
-// Delassus form.  Every row lane keeps, for its row, lambda and z = (rhs - (A lambda)) / diag, so that a row update is
-//   sum = clamp(lambda + z);  d = broadcast(sum - lambda);  z += Ac[r] d   (Ac[r] = -A[row][r] / diag, every row lane)
-// = 7 vector instructions.  HAS_B: some robot of the wave has an active joint-limit row (bank B is swept too).
+// Delassus form.  Every row lane keeps, for its row, lambda and y = lambda + (rhs - (A lambda)) / diag (the unclamped
+// Gauss-Seidel value), so that a row update is
+//   sum = clamp(y);  d = broadcast(sum - lambda);  lambda = sum (own lane);  y += Ac[r] d   (every row lane)
+// with Ac[r] = -A[row][r] / diag(row) off the diagonal and 0 on it (y of the updated row does not move)
+// = 6 vector instructions.  HAS_B: some robot of the wave has an active joint-limit row (bank B is swept too).
 // Knee rows are swept unconditionally, contact rows per leg when some robot of the wave has that toe in contact (a
 // row visited for a robot where it is inactive is a no-op: its bounds, 1/diag and lambda are zero).
 template <bool HAS_B>
 __device__ __forceinline__ void pgs_sweeps(int iters, unsigned int mask, int lane, int sub, Row& A, Row& B,
                                            const float (&AcA)[kMaxRows], const float (&AcB)[kMaxRows]) {
-  float lamA = A.lam, lamN = A.lam_n, lamB = B.lam;
-  float zA = fmaf(-A.w, A.jdi, A.rhs), zB = fmaf(-B.w, B.jdi, B.rhs);
-  const float muA = A.mu_e, hiA = A.hi_c, loA = A.lo_c, hiB = B.hi_c, loB = B.lo_c;
-  float isn[4];
+  float lamA = A.lam, lamB = B.lam;
+  float yA = lamA + fmaf(-A.w, A.jdi, A.rhs), yB = lamB + fmaf(-B.w, B.jdi, B.rhs);
+  const float hiB = B.hi_c, loB = B.lo_c;
+  float mun[4];  // friction rows: d(bound) / d(normal impulse of their toe)
 #pragma unroll
-  for (int g = 0; g < 4; g++) isn[g] = A.nrm_slot == 16 + g ? 1.0f : 0.0f;
-  float hiE = fmaf(muA, lamN, hiA), loE = fmaf(-muA, lamN, loA);
-  const unsigned int cm = __builtin_amdgcn_readfirstlane((mask >> 16) & 0xFu);  // legs with a toe contact (wave-uniform)
+  for (int g = 0; g < 4; g++) mun[g] = A.nrm_slot == 16 + g ? A.mu_e : 0.0f;
+  float hiE = fmaf(A.mu_e, A.lam_n, A.hi_c), loE = fmaf(-A.mu_e, A.lam_n, A.lo_c);
+  const unsigned int cm = (mask >> 16) & 0xFu;  // legs with a toe contact in some robot of the wave
   for (int it = 0; it < iters; it++) {
     auto rowA = [&](auto rc) __attribute__((always_inline)) {
       constexpr int r = decltype(rc)::value, src = r < 4 ? r : r - 12;
-      const float sum = __builtin_amdgcn_fmed3f(lamA + zA, loE, hiE);
+      const float sum = __builtin_amdgcn_fmed3f(yA, loE, hiE);
       const float d = row_commit<src>(lamA, sum, lane, sub);
-      zA = fmaf(AcA[r], d, zA);
-      if (HAS_B) zB = fmaf(AcB[r], d, zB);
+      yA = fmaf(AcA[r], d, yA);
+      if (HAS_B) yB = fmaf(AcB[r], d, yB);
       if (r >= 16 && r < 20) {  // a normal impulse moved: friction bounds of the rows of that toe follow
-        lamN = fmaf(isn[r >= 16 && r < 20 ? r - 16 : 0], d, lamN);
-        hiE = fmaf(muA, lamN, hiA); loE = fmaf(-muA, lamN, loA);
+        constexpr int g = r >= 16 && r < 20 ? r - 16 : 0;
+        hiE = fmaf(mun[g], d, hiE); loE = fmaf(-mun[g], d, loE);
       }
     };
     static_for<0, 4>(rowA);
@@ -670,10 +752,10 @@ __device__ __forceinline__ void pgs_sweeps(int iters, unsigned int mask, int lan
       static_for<4, 16>([&](auto rc) __attribute__((always_inline)) {
         constexpr int r = decltype(rc)::value;
         if ((mask >> r) & 1u) {
-          const float sum = __builtin_amdgcn_fmed3f(lamB + zB, loB, hiB);
+          const float sum = __builtin_amdgcn_fmed3f(yB, loB, hiB);
           const float d = row_commit<r>(lamB, sum, lane, sub);
-          zA = fmaf(AcA[r], d, zA);
-          zB = fmaf(AcB[r], d, zB);
+          yA = fmaf(AcA[r], d, yA);
+          yB = fmaf(AcB[r], d, yB);
         }
       });
     }
@@ -689,7 +771,7 @@ __device__ __forceinline__ void pgs_sweeps(int iters, unsigned int mask, int lan
       }
     });
   }
-  A.lam = lamA; A.lam_n = lamN; B.lam = lamB;
+  A.lam = lamA; B.lam = lamB;
 }
 
 // One physics sub-step.  Returns the fall-proxy flag (wave-uniform) when want_fall.
@@ -698,6 +780,7 @@ __device__ static int physics_substep(const KParams& P, Shared& S, const LegCons
   const float dt = cfg.sim_dt, inv_dt = 1.0f / cfg.sim_dt, erp_dt = cfg.contact_erp / cfg.sim_dt;
   aba_legs(P, S, K, lane);
   WSYNC();
+  PT(3);
   for (int i = lane; i < 18; i += kLanes) {
     float u = i < 3 ? S.s[O(ANGVEL) + i] : (i < 6 ? S.s[O(LINVEL) + i - 3] : S.m.jdir[i - 6] * S.s[O(QD) + i - 6]);
     S.ustar[i] = u + dt * S.acc[i];
@@ -715,6 +798,7 @@ __device__ static int physics_substep(const KParams& P, Shared& S, const LegCons
     fall = ((__ballot(hit) >> (sub * kLanes)) & ((1ull << (kLanes - 1)) * 2ull - 1ull)) != 0ull;
   }
   WSYNC();
+  PT(4);
 
   // ---------------- constraint rows ----------------
   // 28 row slots, slot index = solve order:
@@ -737,11 +821,13 @@ __device__ static int physics_substep(const KParams& P, Shared& S, const LegCons
     const unsigned int a = (unsigned int)(balA >> (g * kLanes)) & 0xFFFFu, b2 = (unsigned int)(balB >> (g * kLanes)) & 0xFFF0u;
     mask |= (a & 0xFu) | ((a >> 4) << 16) | b2;
   }
+  PT(5);
   // ---------------- impulse responses M^-1 J^T, diagonal, warm start ----------------
   row_response(S, cfg, A, rowlane ? (lane < 4 ? lane : lane + 12) : 0);
   if (anyB) row_response(S, cfg, B, (rowlane && lane >= 4) ? lane : 4);
   WSYNC();
-  // Delassus columns A[row][r] = J . W[r], kept in registers already scaled for the sweeps: Ac[r] = -A[row][r] / diag(row);
+  PT(6);
+  // Delassus columns A[row][r] = J . W[r], kept in registers already scaled for the sweeps: Ac[r] = -A[row][r] / diag(row), 0 on the diagonal;
   // w = (A lambda) of the warm start
   float AcA[kMaxRows], AcB[kMaxRows];
 #pragma unroll
@@ -752,22 +838,26 @@ __device__ static int physics_substep(const KParams& P, Shared& S, const LegCons
       const float l0 = (r >= 4 && r < 16) ? bcast_row(B.lam, r, sub) : bcast_row(A.lam, r < 4 ? r : r - 12, sub);
       const float a = row_dot(A, Wr);
       A.w += a * l0;
-      AcA[r] = -a * A.jdi;
+      AcA[r] = (!(r >= 4 && r < 16) && lane == (r < 4 ? r : r - 12)) ? 0.0f : -a * A.jdi;
       if (r >= 16 && r < 20 && A.nrm_slot == r) A.lam_n = l0;
-      if (anyB) { const float b = row_dot(B, Wr); B.w += b * l0; AcB[r] = -b * B.jdi; }
+      if (anyB) { const float b = row_dot(B, Wr); B.w += b * l0; AcB[r] = (r >= 4 && r < 16 && lane == r) ? 0.0f : -b * B.jdi; }
       asm volatile("" : "+v"(AcA[r]), "+v"(AcB[r]));  // keep the scaled value (do not re-derive it inside the sweeps)
     }
   }
   // projected Gauss-Seidel (btMultiBodyConstraintSolver::solveSingleIteration), Delassus form: every row lane keeps
   // lambda and w = (A lambda) of its row(s); one broadcast per row update.  Two instantiations: with and without the
   // joint-limit bank.
+  PT(7);
   if (anyB) pgs_sweeps<true>(cfg.solver_iters, mask, lane, sub, A, B, AcA, AcB);
   else pgs_sweeps<false>(cfg.solver_iters, mask, lane, sub, A, B, AcA, AcB);
+  PT(8);
   // contact impulses are remembered for the next sub-step's warm start (0 for open contacts)
   if (rowlane && lane >= 4) S.s[O(LAMBDA) + A.warm] = A.active ? A.lam : 0.0f;
   // ---------------- velocity update, Bullet coordinate-velocity clamp, semi-implicit Euler ----------------
+  // lane l owns DOF l (v0) and, for l < 2, DOF 16 + l (v1); the new coordinates are written by the owning lane
+  float v0, v1;
   {
-    float du0 = 0.0f, du1 = 0.0f;  // DOF lane and DOF lane+16
+    float du0 = 0.0f, du1 = 0.0f;
     const int k1 = lane + 16 < 18 ? lane + 16 : 0;
     const int k0 = lane < 18 ? lane : 0;
 #pragma unroll
@@ -778,13 +868,52 @@ __device__ static int physics_substep(const KParams& P, Shared& S, const LegCons
         if (kLanes < 18) du1 += S.ph.sub.W[r][k1] * lr;
       }
     }
-    if (lane < 18) S.du[lane] = fminf(fmaxf(S.ustar[lane] + du0, -cfg.max_coord_velocity), cfg.max_coord_velocity);
-    if (kLanes < 18 && lane + 16 < 18) S.du[lane + 16] = fminf(fmaxf(S.ustar[lane + 16] + du1, -cfg.max_coord_velocity), cfg.max_coord_velocity);
+    const float vmax = cfg.max_coord_velocity;
+    v0 = __builtin_amdgcn_fmed3f(S.ustar[k0] + du0, -vmax, vmax);
+    v1 = __builtin_amdgcn_fmed3f(S.ustar[k1] + du1, -vmax, vmax);
   }
-  WSYNC();
-  {
-    // quaternion: exponential map of the world angular velocity, then normalise
-    const float w0 = S.du[0], w1 = S.du[1], w2 = S.du[2];
+  if (kLanes == 16) {
+    // quaternion: exponential map of the world angular velocity (DOFs 0..2, broadcast from their lanes), then normalise
+    const float w0 = bcast_lane<0>(v0, sub), w1 = bcast_lane<1>(v0, sub), w2 = bcast_lane<2>(v0, sub);
+    const float ww = w0 * w0 + w1 * w1 + w2 * w2, h2 = 0.25f * dt * dt * ww;  // h = |w| dt / 2
+    float sc, ch;  // sin(h) / |w| and cos(h)
+    if (h2 < 0.04f) {  // always, unless max_coord_velocity is raised a lot: Taylor series exact to float precision
+      sc = 0.5f * dt * fmaf(h2, fmaf(h2, fmaf(h2, -1.0f / 5040.0f, 1.0f / 120.0f), -1.0f / 6.0f), 1.0f);
+      ch = fmaf(h2, fmaf(h2, fmaf(h2, fmaf(h2, 1.0f / 40320.0f, -1.0f / 720.0f), 1.0f / 24.0f), -0.5f), 1.0f);
+    } else {
+      const float wn = sqrtf(ww);
+      float sh;
+      sincosf(0.5f * wn * dt, &sh, &ch);
+      sc = sh / wn;
+    }
+    const float dq[4] = {w0 * sc, w1 * sc, w2 * sc, ch};
+    float qn[4];
+    qmul(dq, &S.s[O(QUAT)], qn);
+    const float nn = rsqrtf(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+    WSYNC();
+    if (lane < 3) {
+      S.s[O(ANGVEL) + lane] = v0;
+    } else if (lane < 6) {
+      S.s[O(LINVEL) + lane - 3] = v0;
+      S.s[O(POS) + lane - 3] += dt * v0;
+    } else {
+      const int j = lane - 6;
+      const float a = S.m.jdir[j] * (S.s[O(Q) + j] - S.m.joff[j]) + dt * v0;
+      S.s[O(Q) + j] = a * S.m.jdir[j] + S.m.joff[j];
+      S.s[O(QD) + j] = v0 * S.m.jdir[j];
+    }
+    if (lane < 2) {
+      const int j = 10 + lane;
+      const float a = S.m.jdir[j] * (S.s[O(Q) + j] - S.m.joff[j]) + dt * v1;
+      S.s[O(Q) + j] = a * S.m.jdir[j] + S.m.joff[j];
+      S.s[O(QD) + j] = v1 * S.m.jdir[j];
+    }
+    if (lane < 4) S.s[O(QUAT) + lane] = (lane == 0 ? qn[0] : (lane == 1 ? qn[1] : (lane == 2 ? qn[2] : qn[3]))) * nn;
+  } else {
+    // wider lane groups (tuning builds): through LDS
+    if (lane < 18) S.ustar[lane] = v0;
+    WSYNC();
+    const float w0 = S.ustar[0], w1 = S.ustar[1], w2 = S.ustar[2];
     const float wn = sqrtf(w0 * w0 + w1 * w1 + w2 * w2), half = 0.5f * wn * dt;
     float sc, ch;
     if (wn < 1e-12f) { sc = 0.5f * dt; ch = 1.0f; }
@@ -794,13 +923,13 @@ __device__ static int physics_substep(const KParams& P, Shared& S, const LegCons
     const float nn = rsqrtf(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
     WSYNC();
     for (int i = lane; i < 22; i += kLanes) {
-      if (i < 3) S.s[O(ANGVEL) + i] = S.du[i];
-      else if (i < 6) { S.s[O(LINVEL) + i - 3] = S.du[i]; S.s[O(POS) + i - 3] += dt * S.du[i]; }
+      if (i < 3) S.s[O(ANGVEL) + i] = S.ustar[i];
+      else if (i < 6) { S.s[O(LINVEL) + i - 3] = S.ustar[i]; S.s[O(POS) + i - 3] += dt * S.ustar[i]; }
       else if (i < 18) {
         const int j = i - 6;
-        const float a = S.m.jdir[j] * (S.s[O(Q) + j] - S.m.joff[j]) + dt * S.du[i];
+        const float a = S.m.jdir[j] * (S.s[O(Q) + j] - S.m.joff[j]) + dt * S.ustar[i];
         S.s[O(Q) + j] = a * S.m.jdir[j] + S.m.joff[j];
-        S.s[O(QD) + j] = S.du[i] * S.m.jdir[j];
+        S.s[O(QD) + j] = S.ustar[i] * S.m.jdir[j];
       } else {
         const int q = i - 18;
         S.s[O(QUAT) + q] = (q == 0 ? qn[0] : (q == 1 ? qn[1] : (q == 2 ? qn[2] : qn[3]))) * nn;
@@ -808,6 +937,7 @@ __device__ static int physics_substep(const KParams& P, Shared& S, const LegCons
     }
   }
   WSYNC();
+  PT(9);
   return fall;
 }
 
@@ -1258,12 +1388,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
   ORR_PROLOGUE();
   const bool valid = in_range;
   const orr_config& c = P.cfg;
+  PT_INIT();
   load_robot(P, rec, S, lane);
   // impulse-response table: stale rows are multiplied by zero impulses, so they only have to be finite
   for (int i = lane; i < kMaxRows * 18; i += kLanes) (&S.ph.sub.W[0][0])[i] = 0.0f;
   WSYNC();
   LegConst K;
   load_leg_const(S, lane & 3, K);
+  PT(0);
 
   if (MODE == 1) {
     if (lane < 12) { const int j = S.m.joint_of_motor[lane]; S.tau[j] = S.m.tau_sign[j] * actions[(size_t)robot * 12 + lane]; }
@@ -1291,11 +1423,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
     S.s[O(ACTION) + lane] = y;
   }
   WSYNC();
+  PT(1);
   int fall = 0;
+  const float inv_repeat = 1.0f / (float)c.action_repeat;
+  const RingLatency rlat = ring_latency(P, S);
   for (int sstep = 0; sstep < c.action_repeat; sstep++) {
-    if (sstep > 0) ctrl_obs(P, rec, S, lane);
+    if (kLanes != 16 && sstep > 0) ctrl_obs(P, rec, S, lane);
     if (lane < 12) {
-      const float lerp = (float)(sstep + 1) / (float)c.action_repeat;  // process_action (minitaur.py:438-460)
+      const float lerp = (float)(sstep + 1) * inv_repeat;  // process_action (minitaur.py:438-460)
       const float cur = map_pi(S.co[lane]);
       const float prev = geti(S, O(FILTER_VALID)) ? S.s[O(FILTER_ACTION) + lane] : cur;
       float cmd = prev + lerp * (S.s[O(ACTION) + lane] - prev);
@@ -1312,12 +1447,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
       if (sstep == c.action_repeat - 1) { seti(S, O(FILTER_VALID), 1); seti(S, O(STEP_COUNTER), geti(S, O(STEP_COUNTER)) + 1); }
     }
     if (sstep == c.action_repeat - 1 && lane < 12) S.s[O(FILTER_ACTION) + lane] = S.s[O(ACTION) + lane];
-    fall = physics_substep(P, S, K, lane, sub, sstep == c.action_repeat - 1);
-    receive_obs(rec, S, lane, valid);
+    PT(2);
+    if (kLanes == 16) {  // receive_obs, then the control observation of the next sub-step / of get_obs
+      RingFetch F;
+      ring_prefetch(rlat, rec, S, lane, F);
+      fall = physics_substep(P, S, K, lane, sub, sstep == c.action_repeat - 1);
+      ring_push_and_ctrl_obs(rec, S, lane, valid, F);
+    } else {
+      fall = physics_substep(P, S, K, lane, sub, sstep == c.action_repeat - 1);
+      receive_obs(rec, S, lane, valid);
+    }
+    PT(10);
   }
   // ---- get_obs: sensors on_step (minitaur.py:295-299) ----
-  ctrl_obs(P, rec, S, lane);
+  if (kLanes != 16) ctrl_obs(P, rec, S, lane);
   sensors_push(S, lane, false);
+  PT(11);
   // ---- reward -> update -> done (quadruped_gym_env.py:230-233) ----
   float rew = calc_reward(P, S, lane);
   const DevClip& clip = P.tab->clip[geti(S, O(CLIP_ID))];
@@ -1348,6 +1493,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
     for (int i = lane; i < 18; i += kLanes) S.s[O(REF_VEL) + i] = S.ph.end.vel[i];
     WSYNC();
   }
+  PT(12);
   // _terminal_condition (imitation_task.py:518-572) + time limit (wrapper_env.py:79) + non-finite guard
   int reason = 0;
   {
@@ -1382,6 +1528,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
     reward_out[robot] = rew;
     done_out[robot] = reason != 0;
   }
+  PT(13);
   long long total_snapshot = P.counters ? P.counters[ORR_CNT_TOTAL_STEP_COUNT] : 0;
   if (reason != 0) {
     if (lane == 0) {
@@ -1404,9 +1551,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
     }
   }
   WSYNC();
+  PT(14);
   store_robot(rec, S, lane, valid);
   if (valid)
     for (int i = lane; i < ORR_OBS_DIM; i += kLanes) obs_out[(size_t)robot * ORR_OBS_DIM + i] = obs[i];
+  PT(15);
+  PT_FLUSH();
   // the last wave to finish folds this launch's done count into the curriculum counter (wrapper_env.py:82-83)
   if (P.counters && valid && lane == 0) {
     const unsigned long long ticket = atomicAdd((unsigned long long*)&P.counters[ORR_CNT_TICKET], 1ull);
@@ -1647,5 +1797,18 @@ int32_t orr_time_steps(orr_handle* h, const float* actions_dev, float* obs_dev, 
   HIPCHK(hipEventElapsedTime(total_ms_out, h->ev0, h->ev1), "orr_time_steps: elapsed");
   return 0;
 }
+
+#ifdef ORR_PHASE_TIMERS
+// development aid: read (and optionally clear) the per-phase cycle totals of the instrumented wave
+int orr_debug_phase_cycles(long long* out16, int reset) {
+  HIPCHK(hipDeviceSynchronize(), "orr_debug_phase_cycles: sync");
+  HIPCHK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_cycles), 16 * sizeof(long long)), "orr_debug_phase_cycles: read");
+  if (reset) {
+    long long z[16] = {0};
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z)), "orr_debug_phase_cycles: clear");
+  }
+  return 0;
+}
+#endif
 
 }  // extern "C"

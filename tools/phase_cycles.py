@@ -1,0 +1,42 @@
+"""Per-phase shader-clock cycles of the step kernel, measured by one instrumented wave (development aid).
+
+usage (GPU box):  python tools/phase_cycles.py [steps]
+Builds a second library with -DORR_PHASE_TIMERS next to the shipped one and runs the bench workload through it.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+LIB = os.path.join(ROOT, "openroborl_amd", "libopenroborl_phase_timers.so")
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-Wno-unused-value",
+                       "-DORR_PHASE_TIMERS", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-o", LIB, os.path.join(ROOT, "openroborl_amd", "csrc", "orr_kernels.hip")])
+os.environ["ORR_LIB_PATH"] = LIB
+
+import torch  # noqa: E402
+from openroborl_amd import _lib  # noqa: E402
+from openroborl_amd.env import VecQuadrupedEnv  # noqa: E402
+
+NAMES = ["load+leg consts", "set_act/filter", "substep control", "ABA", "ustar+fall proxies", "row setup", "row response",
+         "Delassus columns", "PGS sweeps", "du+integrate", "receive_obs (ring)", "ctrl_obs+sensors", "reward+ref update",
+         "termination+obs", "episode end/reset", "store"]
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+env = VecQuadrupedEnv(task_name="imitation_learning_laikago", num_robot=4096, seed=0)
+env.reset()
+g = torch.Generator().manual_seed(0)
+act = (torch.randn(4096, 12, generator=g) * 0.1).to(env.device)
+L = _lib.load()
+L.orr_debug_phase_cycles.argtypes = [C.POINTER(C.c_longlong), C.c_int]
+buf = (C.c_longlong * 16)()
+for _ in range(50):
+    env.step(act)
+L.orr_debug_phase_cycles(buf, 1)
+for _ in range(steps):
+    env.step(act)
+L.orr_debug_phase_cycles(buf, 1)
+tot = float(sum(buf))
+print("cycles per env step (one wave, %d steps): %.0f" % (steps, tot / steps))
+for n, v in zip(NAMES, buf):
+    print("  %-22s %9.0f  %5.1f%%" % (n, v / steps, 100.0 * v / tot))
