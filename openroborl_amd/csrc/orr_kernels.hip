@@ -774,6 +774,48 @@ __device__ __forceinline__ void pgs_sweeps(int iters, unsigned int mask, int lan
   A.lam = lamA; B.lam = lamB;
 }
 
+// Delassus columns A[row][r] = J . W[r], kept in registers already scaled for the sweeps: Ac[r] = -A[row][r] / diag(row),
+// 0 on the diagonal; w = (A lambda) of the warm start.  Row groups as in pgs_sweeps: knee rows always (an inactive
+// one has a zero impulse response), joint-limit rows one by one, contact rows per leg.
+template <bool HAS_B>
+__device__ __forceinline__ void delassus_columns(const Shared& S, unsigned int mask, int lane, int sub, Row& A, Row& B,
+                                                 float (&AcA)[kMaxRows], float (&AcB)[kMaxRows]) {
+#pragma unroll
+  for (int r = 0; r < kMaxRows; r++) { AcA[r] = 0.0f; AcB[r] = 0.0f; }
+  auto column = [&](auto rc) __attribute__((always_inline)) {
+    constexpr int r = decltype(rc)::value;
+    constexpr bool inB = r >= 4 && r < 16;
+    constexpr int src = inB ? r : (r < 4 ? r : r - 12);
+    const float* Wr = S.ph.sub.W[r];
+    const float l0 = bcast_lane<src>(inB ? B.lam : A.lam, sub);
+    const float a = row_dot(A, Wr);
+    A.w += a * l0;
+    AcA[r] = (!inB && lane == src) ? 0.0f : -a * A.jdi;
+    if (r >= 16 && r < 20 && A.nrm_slot == r) A.lam_n = l0;
+    if (HAS_B) {
+      const float b = row_dot(B, Wr);
+      B.w += b * l0;
+      AcB[r] = (inB && lane == src) ? 0.0f : -b * B.jdi;
+    }
+    asm volatile("" : "+v"(AcA[r]), "+v"(AcB[r]));  // keep the scaled value (do not re-derive it inside the sweeps)
+  };
+  static_for<0, 4>(column);
+  if (HAS_B) {
+    static_for<4, 16>([&](auto rc) __attribute__((always_inline)) {
+      if ((mask >> decltype(rc)::value) & 1u) column(rc);
+    });
+  }
+  const unsigned int cm = (mask >> 16) & 0xFu;
+  static_for<0, 4>([&](auto gc) __attribute__((always_inline)) {
+    constexpr int g = decltype(gc)::value;
+    if ((cm >> g) & 1u) {
+      column(std::integral_constant<int, 16 + g>{});
+      column(std::integral_constant<int, 20 + 2 * g>{});
+      column(std::integral_constant<int, 21 + 2 * g>{});
+    }
+  });
+}
+
 // One physics sub-step.  Returns the fall-proxy flag (wave-uniform) when want_fall.
 __device__ static int physics_substep(const KParams& P, Shared& S, const LegConst& K, int lane, int sub, bool want_fall) {
   const orr_config& cfg = P.cfg;
@@ -827,29 +869,17 @@ __device__ static int physics_substep(const KParams& P, Shared& S, const LegCons
   if (anyB) row_response(S, cfg, B, (rowlane && lane >= 4) ? lane : 4);
   WSYNC();
   PT(6);
-  // Delassus columns A[row][r] = J . W[r], kept in registers already scaled for the sweeps: Ac[r] = -A[row][r] / diag(row), 0 on the diagonal;
-  // w = (A lambda) of the warm start
+  // Delassus columns, then the Gauss-Seidel sweeps; two instantiations: with and without the joint-limit bank
   float AcA[kMaxRows], AcB[kMaxRows];
-#pragma unroll
-  for (int r = 0; r < kMaxRows; r++) {
-    AcA[r] = 0.0f; AcB[r] = 0.0f;
-    if ((mask >> r) & 1u) {
-      const float* Wr = S.ph.sub.W[r];
-      const float l0 = (r >= 4 && r < 16) ? bcast_row(B.lam, r, sub) : bcast_row(A.lam, r < 4 ? r : r - 12, sub);
-      const float a = row_dot(A, Wr);
-      A.w += a * l0;
-      AcA[r] = (!(r >= 4 && r < 16) && lane == (r < 4 ? r : r - 12)) ? 0.0f : -a * A.jdi;
-      if (r >= 16 && r < 20 && A.nrm_slot == r) A.lam_n = l0;
-      if (anyB) { const float b = row_dot(B, Wr); B.w += b * l0; AcB[r] = (r >= 4 && r < 16 && lane == r) ? 0.0f : -b * B.jdi; }
-      asm volatile("" : "+v"(AcA[r]), "+v"(AcB[r]));  // keep the scaled value (do not re-derive it inside the sweeps)
-    }
+  if (anyB) {
+    delassus_columns<true>(S, mask, lane, sub, A, B, AcA, AcB);
+    PT(7);
+    pgs_sweeps<true>(cfg.solver_iters, mask, lane, sub, A, B, AcA, AcB);
+  } else {
+    delassus_columns<false>(S, mask, lane, sub, A, B, AcA, AcB);
+    PT(7);
+    pgs_sweeps<false>(cfg.solver_iters, mask, lane, sub, A, B, AcA, AcB);
   }
-  // projected Gauss-Seidel (btMultiBodyConstraintSolver::solveSingleIteration), Delassus form: every row lane keeps
-  // lambda and w = (A lambda) of its row(s); one broadcast per row update.  Two instantiations: with and without the
-  // joint-limit bank.
-  PT(7);
-  if (anyB) pgs_sweeps<true>(cfg.solver_iters, mask, lane, sub, A, B, AcA, AcB);
-  else pgs_sweeps<false>(cfg.solver_iters, mask, lane, sub, A, B, AcA, AcB);
   PT(8);
   // contact impulses are remembered for the next sub-step's warm start (0 for open contacts)
   if (rowlane && lane >= 4) S.s[O(LAMBDA) + A.warm] = A.active ? A.lam : 0.0f;
@@ -860,14 +890,27 @@ __device__ static int physics_substep(const KParams& P, Shared& S, const LegCons
     float du0 = 0.0f, du1 = 0.0f;
     const int k1 = lane + 16 < 18 ? lane + 16 : 0;
     const int k0 = lane < 18 ? lane : 0;
-#pragma unroll
-    for (int r = 0; r < kMaxRows; r++) {
-      if ((mask >> r) & 1u) {
-        const float lr = (r >= 4 && r < 16) ? bcast_row(B.lam, r, sub) : bcast_row(A.lam, r < 4 ? r : r - 12, sub);
-        du0 += S.ph.sub.W[r][k0] * lr;
-        if (kLanes < 18) du1 += S.ph.sub.W[r][k1] * lr;
-      }
+    auto add_row = [&](auto rc) __attribute__((always_inline)) {
+      constexpr int r = decltype(rc)::value;
+      constexpr bool inB = r >= 4 && r < 16;
+      const float lr = bcast_lane<inB ? r : (r < 4 ? r : r - 12)>(inB ? B.lam : A.lam, sub);
+      du0 += S.ph.sub.W[r][k0] * lr;
+      if (kLanes < 18) du1 += S.ph.sub.W[r][k1] * lr;
+    };
+    static_for<0, 4>(add_row);
+    if (anyB) {
+      static_for<4, 16>([&](auto rc) __attribute__((always_inline)) {
+        if ((mask >> decltype(rc)::value) & 1u) add_row(rc);
+      });
     }
+    static_for<0, 4>([&](auto gc) __attribute__((always_inline)) {
+      constexpr int g = decltype(gc)::value;
+      if ((mask >> (16 + g)) & 1u) {
+        add_row(std::integral_constant<int, 16 + g>{});
+        add_row(std::integral_constant<int, 20 + 2 * g>{});
+        add_row(std::integral_constant<int, 21 + 2 * g>{});
+      }
+    });
     const float vmax = cfg.max_coord_velocity;
     v0 = __builtin_amdgcn_fmed3f(S.ustar[k0] + du0, -vmax, vmax);
     v1 = __builtin_amdgcn_fmed3f(S.ustar[k1] + du1, -vmax, vmax);
