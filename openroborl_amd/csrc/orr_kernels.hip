@@ -694,25 +694,31 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for<I + 1, N>(f);
   }
 }
-// Row update tail: d = (sum - lam) of lane SRC broadcast to the robot's lanes; lam = sum in lane SRC.
+// One Gauss-Seidel row update (see pgs_sweeps): sum = clamp(y, lo, hi); d = (sum - lam) of lane SRC broadcast to the
+// robot's lanes; lam = sum in lane SRC; y += ac d.  Returns d.
 // Written out for the 16-lane layout: (a) the lane compare is redone at each use - hoisted out of the sweep loop the 28
 // lane masks cost 28 SGPR pairs (spills + reloads); (b) the compare + select sit between the subtraction and the DPP
-// move that reads its result, which covers the two wait states that hazard needs.
+// move that reads its result, which covers the two wait states of that hazard; (c) one block, so that no conservative
+// wait state is inserted between its instructions.
 template <int SRC>
-__device__ __forceinline__ float row_commit(float& lam, float sum, int lane, int sub) {
+__device__ __forceinline__ float row_update(float& y, float& lam, float lo, float hi, float ac, int lane, int sub) {
 #if !defined(ORR_READLANE_BCAST)
   if (kRPW == 4) {
-    float d;
-    asm("v_sub_f32_e32 %0, %3, %1\n\t"
-        "v_cmp_eq_u32_e32 vcc, %4, %2\n\t"
-        "v_cndmask_b32_e32 %1, %1, %3, vcc\n\t"
-        "v_mov_b32_dpp %0, %0 row_newbcast:%4 row_mask:0xf bank_mask:0xf"
-        : "=&v"(d), "+v"(lam) : "v"(lane), "v"(sum), "n"(SRC) : "vcc");
+    float d, sum;
+    asm("v_med3_f32 %1, %3, %4, %5\n\t"
+        "v_sub_f32_e32 %0, %1, %2\n\t"
+        "v_cmp_eq_u32_e32 vcc, %8, %6\n\t"
+        "v_cndmask_b32_e32 %2, %2, %1, vcc\n\t"
+        "v_mov_b32_dpp %0, %0 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_e32 %3, %7, %0"
+        : "=&v"(d), "=&v"(sum), "+v"(lam), "+v"(y) : "v"(lo), "v"(hi), "v"(lane), "v"(ac), "n"(SRC) : "vcc");
     return d;
   }
 #endif
+  const float sum = __builtin_amdgcn_fmed3f(y, lo, hi);
   const float d = bcast_lane<SRC>(sum - lam, sub);
   lam = lane == SRC ? sum : lam;
+  y = fmaf(ac, d, y);
   return d;
 }
 
@@ -738,9 +744,7 @@ __device__ __forceinline__ void pgs_sweeps(int iters, unsigned int mask, int lan
   for (int it = 0; it < iters; it++) {
     auto rowA = [&](auto rc) __attribute__((always_inline)) {
       constexpr int r = decltype(rc)::value, src = r < 4 ? r : r - 12;
-      const float sum = __builtin_amdgcn_fmed3f(yA, loE, hiE);
-      const float d = row_commit<src>(lamA, sum, lane, sub);
-      yA = fmaf(AcA[r], d, yA);
+      const float d = row_update<src>(yA, lamA, loE, hiE, AcA[r], lane, sub);
       if (HAS_B) yB = fmaf(AcB[r], d, yB);
       if (r >= 16 && r < 20) {  // a normal impulse moved: friction bounds of the rows of that toe follow
         constexpr int g = r >= 16 && r < 20 ? r - 16 : 0;
@@ -752,10 +756,8 @@ __device__ __forceinline__ void pgs_sweeps(int iters, unsigned int mask, int lan
       static_for<4, 16>([&](auto rc) __attribute__((always_inline)) {
         constexpr int r = decltype(rc)::value;
         if ((mask >> r) & 1u) {
-          const float sum = __builtin_amdgcn_fmed3f(yB, loB, hiB);
-          const float d = row_commit<r>(lamB, sum, lane, sub);
+          const float d = row_update<r>(yB, lamB, loB, hiB, AcB[r], lane, sub);
           yA = fmaf(AcA[r], d, yA);
-          yB = fmaf(AcB[r], d, yB);
         }
       });
     }

@@ -11,8 +11,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 LIB = os.path.join(ROOT, "openroborl_amd", "libopenroborl_phase_timers.so")
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-Wno-unused-value",
-                       "-DORR_PHASE_TIMERS", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-o", LIB, os.path.join(ROOT, "openroborl_amd", "csrc", "orr_kernels.hip")])
+from openroborl_amd import _lib as _build  # noqa: E402  (flags only; the library is loaded below)
+subprocess.check_call([_build.HIPCC] + _build.HIPCC_FLAGS + ["-DORR_PHASE_TIMERS", "-o", LIB,
+                       os.path.join(ROOT, "openroborl_amd", "csrc", "orr_kernels.hip")])
 os.environ["ORR_LIB_PATH"] = LIB
 
 import torch  # noqa: E402
