@@ -117,14 +117,12 @@ struct KParams {
 // LDS image of one robot (one wave): ~1.9 K words (7.6 KB) -> 16 waves per CU (4 per SIMD) fit in 160 KB
 // ------------------------------------------------------------------------------------------------
 struct LinkCache {  // per movable link, written by the leg lanes (0..3), read by the row lanes
-  float c, s;       // cos / sin of the internal joint angle
-  float U[6];
-  float invD;
-  float u;          // tau - S.pA
   float Rw[9];      // link -> world
   float ow[3];      // link origin, world
-  float cv[6];      // velocity-product acceleration
-  float pA[6];      // bias force of the link itself
+};
+struct LegSolve {   // per leg, written by the leg lanes, read by the row lanes (see leg_dynamics in orr_kernels.hip)
+  float T[3][6];    // F H^-1: column k = base wrench (angular; linear, world axes, about the base COM) per unit of joint k
+  float Hi[6];      // H^-1 of the leg's 3x3 joint-space inertia (00 11 22 01 02 12)
 };
 
 struct SubstepBuf {           // live only inside a physics sub-step
@@ -149,8 +147,9 @@ struct Shared {
   float mass[13];             // after randomisation ratios
   float Ic[13][6];
   LinkCache lc[12];
+  LegSolve leg[4];
   float Rb[9];                // kinematic base frame -> world
-  float IA0inv[36];
+  float IA0inv[36];           // inverse of the base's effective 6x6 inertia (world axes, about the base COM)
   float tau[12];              // joint torques (internal sign convention), joint order
   float acc[18];
   float ustar[18];

@@ -240,221 +240,206 @@ __device__ static void load_leg_const(const Shared& S, int leg, LegConst& K) {
     K.joff[k] = S.m.joff[j];
   }
 }
-// what pass 1 hands to passes 2 / 3 of the same lane (registers; the row lanes get their copy through LDS)
-struct LinkRegs {
-  float c, s, cv[6], pA[6];
+// ================================================================================================
+// Forward dynamics of the floating base + 4 x 3-link legs.
+//
+// Formulation (mathematically the articulated-body result; tools/crba_proto.py checks it against the oracle's ABA):
+// everything in world-aligned axes with the origin O at the base COM, spatial vectors (angular; linear),
+//   M = [[ Ic_tot , F ],     F_j = Ic_j S_j (composite inertia of the subtree of joint j times its motion axis),
+//        [ F^T    , H ]]     H block-diagonal: one symmetric 3x3 per leg
+//   bias forces by recursive Newton-Euler with zero accelerations (C per joint, p for the base)
+//   T_L = F_L H_L^-1;  A0 = Ic_tot - sum_L T_L F_L^T;  a0 = -A0^-1 (p + sum_L T_L (tau_L - C_L))
+//   qdd_L = H_L^-1 (tau_L - C_L - F_L^T a0)
+// A leg is a chain of three joints about coordinate axes of the link frames (hip x, upper / lower leg y), so its
+// world joint axis is a column of the link rotation.  What the constraint rows need afterwards is small and goes to
+// LDS: T_L (6x3), H_L^-1 per leg and A0^-1 (LegSolve / Shared::IA0inv) - the impulse response of a row is then
+//   da0 = A0^-1 (Jb - T_L jl);  dqdd_L = H_L^-1 jl - T_L^T da0;  dqdd_K = -T_K^T da0  (K != L).
+// Lanes with the same (lane & 3) do the same leg; results are written by lanes 0..3.
+// ================================================================================================
+
+// R S R^T for a symmetric S (xx yy zz xy xz yz) and a general rotation R (row-major)
+__device__ __forceinline__ void rot_sym_full(const float R[9], const float S[6], float O[6]) {
+  float T[9];  // T = R S
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    T[3 * i] = R[3 * i] * S[0] + R[3 * i + 1] * S[3] + R[3 * i + 2] * S[4];
+    T[3 * i + 1] = R[3 * i] * S[3] + R[3 * i + 1] * S[1] + R[3 * i + 2] * S[5];
+    T[3 * i + 2] = R[3 * i] * S[4] + R[3 * i + 1] * S[5] + R[3 * i + 2] * S[2];
+  }
+  O[0] = T[0] * R[0] + T[1] * R[1] + T[2] * R[2];
+  O[1] = T[3] * R[3] + T[4] * R[4] + T[5] * R[5];
+  O[2] = T[6] * R[6] + T[7] * R[7] + T[8] * R[8];
+  O[3] = T[0] * R[3] + T[1] * R[4] + T[2] * R[5];
+  O[4] = T[0] * R[6] + T[1] * R[7] + T[2] * R[8];
+  O[5] = T[3] * R[6] + T[4] * R[7] + T[5] * R[8];
+}
+// spatial inertia about O (I symmetric, first moment h, mass m) times a spatial motion vector (w; v)
+__device__ __forceinline__ void spatial_inertia_mul(const float I[6], const float h[3], float m, const float w[3], const float v[3],
+                                                    float oa[3], float ol[3]) {
+  float t[3], u[3];
+  symv(I, w, t);
+  cross3(h, v, u);
+  oa[0] = t[0] + u[0]; oa[1] = t[1] + u[1]; oa[2] = t[2] + u[2];
+  cross3(h, w, u);
+  ol[0] = m * v[0] - u[0]; ol[1] = m * v[1] - u[1]; ol[2] = m * v[2] - u[2];
+}
+
+struct LinkDyn {  // per link, registers of the leg lane
+  float s[3], sv[3];  // motion axis S = (s; d x s)
+  float I[6], h[3], m;  // spatial inertia about O (own link on the way down, composite of the subtree on the way up)
+  float f[6];         // bias force (own link, then subtree sum)
 };
 
-// ---- pass 1 for one link: velocities, velocity-product terms, bias force, world pose ----
+// one link on the way down the leg: pose, velocity, velocity-product acceleration, inertia about O, bias force
 template <int AX>
-__device__ __forceinline__ void pass1_link(Shared& S, const LegConst& K, int k, LinkRegs& G, int j, bool wr, float wp[3], float vp[3],
-                                           float Rwp[9], float owp[3]) {
-  const float r[3] = {K.r[k][0], K.r[k][1], K.r[k][2]};
+__device__ __forceinline__ void link_down(Shared& S, const LegConst& K, int k, int j, bool wr, float Rw[9], float d[3], float Vw[3],
+                                          float Vv[3], float Aa[3], float Al[3], LinkDyn& G) {
   const float a = K.jdir[k] * (S.s[O(Q) + j] - K.joff[k]);
   const float ad = K.jdir[k] * S.s[O(QD) + j];
   float sn, cs;
   joint_sincos(a, &sn, &cs);
-  float t[3], w[3], v[3];
-  cross3(wp, r, t);
-  t[0] += vp[0]; t[1] += vp[1]; t[2] += vp[2];
-  rot_inv<AX>(cs, sn, wp, w);
-  rot_inv<AX>(cs, sn, t, v);
-  w[AX] += ad;
-  float cv[6];  // c = [w x (e ad); v x (e ad)]
-  if (AX == 0) { cv[0] = 0.0f; cv[1] = w[2] * ad; cv[2] = -w[1] * ad; cv[3] = 0.0f; cv[4] = v[2] * ad; cv[5] = -v[1] * ad; }
-  else { cv[0] = -w[2] * ad; cv[1] = 0.0f; cv[2] = w[0] * ad; cv[3] = -v[2] * ad; cv[4] = 0.0f; cv[5] = v[0] * ad; }
-  const float m = K.m[k];
-  const float com[3] = {K.com[k][0], K.com[k][1], K.com[k][2]};
-  float wxc[3], f[3], n[3], cxf[3], t1[3], t2[3], pA[6];
-  cross3(w, com, wxc);
-  f[0] = m * (v[0] + wxc[0]); f[1] = m * (v[1] + wxc[1]); f[2] = m * (v[2] + wxc[2]);
-  symv(K.Ic[k], w, n);
-  cross3(com, f, cxf);
-  n[0] += cxf[0]; n[1] += cxf[1]; n[2] += cxf[2];
-  cross3(w, n, t1);
-  cross3(v, f, t2);
-  pA[0] = t1[0] + t2[0]; pA[1] = t1[1] + t2[1]; pA[2] = t1[2] + t2[2];
-  cross3(w, f, &pA[3]);
-  // forward kinematics: Rw = Rwp R, ow = owp + Rwp r
-  float Rw[9], ow[3];
+  // pose: d += Rw_parent r;  Rw = Rw_parent R(a)
+  {
+    float t[3];
+    mv3(Rw, K.r[k], t);
+    d[0] += t[0]; d[1] += t[1]; d[2] += t[2];
+  }
 #pragma unroll
   for (int i = 0; i < 3; i++) {
-    const float p0 = Rwp[3 * i], p1 = Rwp[3 * i + 1], p2 = Rwp[3 * i + 2];
-    if (AX == 0) { Rw[3 * i] = p0; Rw[3 * i + 1] = cs * p1 + sn * p2; Rw[3 * i + 2] = -sn * p1 + cs * p2; }
-    else { Rw[3 * i] = cs * p0 - sn * p2; Rw[3 * i + 1] = p1; Rw[3 * i + 2] = sn * p0 + cs * p2; }
+    const float p0 = Rw[3 * i], p1 = Rw[3 * i + 1], p2 = Rw[3 * i + 2];
+    if (AX == 0) { Rw[3 * i + 1] = cs * p1 + sn * p2; Rw[3 * i + 2] = -sn * p1 + cs * p2; }
+    else { Rw[3 * i] = cs * p0 - sn * p2; Rw[3 * i + 2] = sn * p0 + cs * p2; }
   }
-  mv3(Rwp, r, ow);
-  ow[0] += owp[0]; ow[1] += owp[1]; ow[2] += owp[2];
-  G.c = cs; G.s = sn;
-#pragma unroll
-  for (int i = 0; i < 6; i++) { G.cv[i] = cv[i]; G.pA[i] = pA[i]; }
   if (wr) {
     LinkCache& L = S.lc[j];
-    L.c = cs; L.s = sn;
 #pragma unroll
     for (int i = 0; i < 9; i++) L.Rw[i] = Rw[i];
 #pragma unroll
-    for (int i = 0; i < 3; i++) L.ow[i] = ow[i];
+    for (int i = 0; i < 3; i++) L.ow[i] = S.s[O(POS) + i] + d[i];
   }
+  G.s[0] = Rw[AX]; G.s[1] = Rw[3 + AX]; G.s[2] = Rw[6 + AX];
+  cross3(d, G.s, G.sv);
+  // V += S ad;  A += V x (S ad)
+  const float ga[3] = {G.s[0] * ad, G.s[1] * ad, G.s[2] * ad}, gl[3] = {G.sv[0] * ad, G.sv[1] * ad, G.sv[2] * ad};
 #pragma unroll
-  for (int i = 0; i < 3; i++) { wp[i] = w[i]; vp[i] = v[i]; owp[i] = ow[i]; }
+  for (int i = 0; i < 3; i++) { Vw[i] += ga[i]; Vv[i] += gl[i]; }
+  {
+    float t0[3], t1[3], t2[3];
+    cross3(Vw, ga, t0);
+    cross3(Vw, gl, t1);
+    cross3(Vv, ga, t2);
 #pragma unroll
-  for (int i = 0; i < 9; i++) Rwp[i] = Rw[i];
-}
-
-// ---- pass 2 for one link: articulated inertia / bias, eliminated along the joint, expressed in the parent ----
-// (Iacc, Hacc, Macc, pacc): contribution of the child subtree on entry, of this subtree (parent coords) on exit.
-// I and M symmetric (xx yy zz xy xz yz), H general row-major; 6x6 = [[I, H], [H^T, M]].
-template <int AX>
-__device__ __forceinline__ void pass2_link(Shared& S, const LegConst& K, int k, LinkRegs& G, int j, bool wr, float Iacc[6], float Hacc[9],
-                                           float Macc[6], float pacc[6], float Uo[6], float& invDo, float& uo) {
-  LinkCache& L = S.lc[j];
+    for (int i = 0; i < 3; i++) { Aa[i] += t0[i]; Al[i] += t1[i] + t2[i]; }
+  }
+  // spatial inertia about O
+  float c[3];
+  mv3(Rw, K.com[k], c);
+  c[0] += d[0]; c[1] += d[1]; c[2] += d[2];
   const float m = K.m[k];
-  const float c0 = K.com[k][0], c1 = K.com[k][1], c2 = K.com[k][2];
-  const float cc = c0 * c0 + c1 * c1 + c2 * c2;
-  float I[6], H[9], M[6], pA[6];
-  I[0] = K.Ic[k][0] + m * (cc - c0 * c0) + Iacc[0];
-  I[1] = K.Ic[k][1] + m * (cc - c1 * c1) + Iacc[1];
-  I[2] = K.Ic[k][2] + m * (cc - c2 * c2) + Iacc[2];
-  I[3] = K.Ic[k][3] - m * c0 * c1 + Iacc[3];
-  I[4] = K.Ic[k][4] - m * c0 * c2 + Iacc[4];
-  I[5] = K.Ic[k][5] - m * c1 * c2 + Iacc[5];
-  M[0] = m + Macc[0]; M[1] = m + Macc[1]; M[2] = m + Macc[2]; M[3] = Macc[3]; M[4] = Macc[4]; M[5] = Macc[5];
-  H[0] = Hacc[0]; H[1] = -m * c2 + Hacc[1]; H[2] = m * c1 + Hacc[2];
-  H[3] = m * c2 + Hacc[3]; H[4] = Hacc[4]; H[5] = -m * c0 + Hacc[5];
-  H[6] = -m * c1 + Hacc[6]; H[7] = m * c0 + Hacc[7]; H[8] = Hacc[8];
-#pragma unroll
-  for (int i = 0; i < 6; i++) pA[i] = G.pA[i] + pacc[i];
-  // U = IA S with S = e_AX: column AX of I on top, row AX of H below
-  float Ut[3], Ub[3];
-  if (AX == 0) { Ut[0] = I[0]; Ut[1] = I[3]; Ut[2] = I[4]; Ub[0] = H[0]; Ub[1] = H[1]; Ub[2] = H[2]; }
-  else { Ut[0] = I[3]; Ut[1] = I[1]; Ut[2] = I[5]; Ub[0] = H[3]; Ub[1] = H[4]; Ub[2] = H[5]; }
-  const float invD = __builtin_amdgcn_rcpf(Ut[AX]);
-  const float u = S.tau[j] - pA[AX];
-  const float uD = u * invD;
-  Uo[0] = Ut[0]; Uo[1] = Ut[1]; Uo[2] = Ut[2]; Uo[3] = Ub[0]; Uo[4] = Ub[1]; Uo[5] = Ub[2];
-  invDo = invD; uo = u;
-  if (wr) {
-    L.U[0] = Ut[0]; L.U[1] = Ut[1]; L.U[2] = Ut[2]; L.U[3] = Ub[0]; L.U[4] = Ub[1]; L.U[5] = Ub[2];
-    L.invD = invD;
-  }
-  // Ia = IA - U U^T / D  (row / column AX of I and row AX of H vanish identically)
+  G.m = m;
+  G.h[0] = m * c[0]; G.h[1] = m * c[1]; G.h[2] = m * c[2];
+  rot_sym_full(Rw, K.Ic[k], G.I);
   {
-    const float a0 = Ut[0] * invD, a1 = Ut[1] * invD, a2 = Ut[2] * invD;
-    I[0] -= a0 * Ut[0]; I[1] -= a1 * Ut[1]; I[2] -= a2 * Ut[2]; I[3] -= a0 * Ut[1]; I[4] -= a0 * Ut[2]; I[5] -= a1 * Ut[2];
-    H[0] -= a0 * Ub[0]; H[1] -= a0 * Ub[1]; H[2] -= a0 * Ub[2];
-    H[3] -= a1 * Ub[0]; H[4] -= a1 * Ub[1]; H[5] -= a1 * Ub[2];
-    H[6] -= a2 * Ub[0]; H[7] -= a2 * Ub[1]; H[8] -= a2 * Ub[2];
-    const float b0 = Ub[0] * invD, b1 = Ub[1] * invD, b2 = Ub[2] * invD;
-    M[0] -= b0 * Ub[0]; M[1] -= b1 * Ub[1]; M[2] -= b2 * Ub[2]; M[3] -= b0 * Ub[1]; M[4] -= b0 * Ub[2]; M[5] -= b1 * Ub[2];
-    if (AX == 0) { I[0] = 0.0f; I[3] = 0.0f; I[4] = 0.0f; H[0] = 0.0f; H[1] = 0.0f; H[2] = 0.0f; }
-    else { I[1] = 0.0f; I[3] = 0.0f; I[5] = 0.0f; H[3] = 0.0f; H[4] = 0.0f; H[5] = 0.0f; }
+    const float hc = G.h[0] * c[0] + G.h[1] * c[1] + G.h[2] * c[2];
+    G.I[0] += hc - G.h[0] * c[0]; G.I[1] += hc - G.h[1] * c[1]; G.I[2] += hc - G.h[2] * c[2];
+    G.I[3] -= G.h[0] * c[1]; G.I[4] -= G.h[0] * c[2]; G.I[5] -= G.h[1] * c[2];
   }
-  // pa = pA + Ia c + U u / D
-  float pat[3], pab[3], t1[3], t2[3], t3[3];
-  symv(I, &G.cv[0], t1);
-  mv3(H, &G.cv[3], t2);
+  // bias force f = I A + V x* (I V)
+  float Pa[3], Pl[3], Fa[3], Fl[3], t0[3], t1[3], t2[3];
+  spatial_inertia_mul(G.I, G.h, m, Vw, Vv, Pa, Pl);
+  spatial_inertia_mul(G.I, G.h, m, Aa, Al, Fa, Fl);
+  cross3(Vw, Pa, t0);
+  cross3(Vv, Pl, t1);
+  cross3(Vw, Pl, t2);
 #pragma unroll
-  for (int i = 0; i < 3; i++) pat[i] = pA[i] + t1[i] + t2[i] + Ut[i] * uD;
-  mtv3(H, &G.cv[0], t1);
-  symv(M, &G.cv[3], t3);
-#pragma unroll
-  for (int i = 0; i < 3; i++) pab[i] = pA[3 + i] + t1[i] + t3[i] + Ub[i] * uD;
-  // rotate into the parent orientation, then shift by r
-  const float cs = G.c, sn = G.s;
-  const float r[3] = {K.r[k][0], K.r[k][1], K.r[k][2]};
-  float Ip[6], Hp[9], Mp[6];
-  rot_sym<AX>(cs, sn, I, Ip);
-  rot_gen<AX>(cs, sn, H, Hp);
-  rot_sym<AX>(cs, sn, M, Mp);
-  // Km = Hp + rx Mp
-  float Mm[9], Km[9];
-  sym_to_m3(Mp, Mm);
-  skewmul(r, Mm, Km);
-#pragma unroll
-  for (int i = 0; i < 9; i++) Km[i] += Hp[i];
-  // Ipar = Ip + rx Hp^T - Km rx   (symmetric: only the 6 unique entries)
-  {
-    // (rx Hp^T)[a][b] = sum_k rx[a][k] Hp[b][k];  (K rx)[a][b] = sum_k K[a][k] rx[k][b]
-    const float r0 = r[0], r1 = r[1], r2 = r[2];
-    // rows of rx: [0,-r2,r1], [r2,0,-r0], [-r1,r0,0]
-#define RXHT(a, b) ((a) == 0 ? (-r2 * Hp[3 * (b) + 1] + r1 * Hp[3 * (b) + 2]) : ((a) == 1 ? (r2 * Hp[3 * (b)] - r0 * Hp[3 * (b) + 2]) : (-r1 * Hp[3 * (b)] + r0 * Hp[3 * (b) + 1])))
-#define KRX(a, b) ((b) == 0 ? (Km[3 * (a) + 1] * r2 - Km[3 * (a) + 2] * r1) : ((b) == 1 ? (-Km[3 * (a)] * r2 + Km[3 * (a) + 2] * r0) : (Km[3 * (a)] * r1 - Km[3 * (a) + 1] * r0)))
-    Iacc[0] = Ip[0] + RXHT(0, 0) - KRX(0, 0);
-    Iacc[1] = Ip[1] + RXHT(1, 1) - KRX(1, 1);
-    Iacc[2] = Ip[2] + RXHT(2, 2) - KRX(2, 2);
-    Iacc[3] = Ip[3] + 0.5f * (RXHT(0, 1) - KRX(0, 1) + RXHT(1, 0) - KRX(1, 0));
-    Iacc[4] = Ip[4] + 0.5f * (RXHT(0, 2) - KRX(0, 2) + RXHT(2, 0) - KRX(2, 0));
-    Iacc[5] = Ip[5] + 0.5f * (RXHT(1, 2) - KRX(1, 2) + RXHT(2, 1) - KRX(2, 1));
-#undef RXHT
-#undef KRX
-  }
-#pragma unroll
-  for (int i = 0; i < 9; i++) Hacc[i] = Km[i];
-#pragma unroll
-  for (int i = 0; i < 6; i++) Macc[i] = Mp[i];
-  float fp[3], np_[3], rxf[3];
-  rot_fwd<AX>(cs, sn, pab, fp);
-  rot_fwd<AX>(cs, sn, pat, np_);
-  cross3(r, fp, rxf);
-  pacc[0] = np_[0] + rxf[0]; pacc[1] = np_[1] + rxf[1]; pacc[2] = np_[2] + rxf[2];
-  pacc[3] = fp[0]; pacc[4] = fp[1]; pacc[5] = fp[2];
+  for (int i = 0; i < 3; i++) { G.f[i] = Fa[i] + t0[i] + t1[i]; G.f[3 + i] = Fl[i] + t2[i]; }
 }
 
-// ---- pass 3 for one link: joint acceleration ----
-template <int AX>
-__device__ __forceinline__ void pass3_link(Shared& S, const LegConst& K, int k, const LinkRegs& G, const float U[6], float invD, float u,
-                                           int j, bool wr, float ap[6]) {
-  const float r[3] = {K.r[k][0], K.r[k][1], K.r[k][2]};
-  float t[3], at[3], ab[3];
-  cross3(&ap[0], r, t);
-  t[0] += ap[3]; t[1] += ap[4]; t[2] += ap[5];
-  rot_inv<AX>(G.c, G.s, &ap[0], at);
-  rot_inv<AX>(G.c, G.s, t, ab);
-#pragma unroll
-  for (int i = 0; i < 3; i++) { at[i] += G.cv[i]; ab[i] += G.cv[3 + i]; }
-  const float Ud = U[0] * at[0] + U[1] * at[1] + U[2] * at[2] + U[3] * ab[0] + U[4] * ab[1] + U[5] * ab[2];
-  const float qdd = (u - Ud) * invD;
-  at[AX] += qdd;
-  if (wr) S.acc[6 + j] = qdd;
-#pragma unroll
-  for (int i = 0; i < 3; i++) { ap[i] = at[i]; ap[3 + i] = ab[i]; }
-}
-
-// Articulated-body algorithm.  Lanes with the same (lane & 3) do the same leg; results are written by lanes 0..3.
-__device__ static void aba_legs(const KParams& P, Shared& S, const LegConst& K, int lane) {
+__device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst& K, int lane) {
   const int leg = lane & 3;
   const bool wr = lane < 4;
-  float Rb[9], wb[3], vb[3];
+  float Rb[9];
   {
     float qi[4], qrel[4];
     qinv(S.m.init_quat, qi);
     qmul(&S.s[O(QUAT)], qi, qrel);
     q_to_mat(qrel, Rb);
   }
-  mtv3(Rb, &S.s[O(ANGVEL)], wb);
-  mtv3(Rb, &S.s[O(LINVEL)], vb);
   if (lane == 0) {
 #pragma unroll
     for (int i = 0; i < 9; i++) S.Rb[i] = Rb[i];
   }
-  LinkRegs G0, G1, G2;
-  float U0[6], U1[6], U2[6], iD0, iD1, iD2, u0, u1, u2;
+  const float wb[3] = {S.s[O(ANGVEL)], S.s[O(ANGVEL) + 1], S.s[O(ANGVEL) + 2]};
+  const float vb[3] = {S.s[O(LINVEL)], S.s[O(LINVEL) + 1], S.s[O(LINVEL) + 2]};
+  LinkDyn G0, G1, G2;
   {
-    float wp[3] = {wb[0], wb[1], wb[2]}, vp[3] = {vb[0], vb[1], vb[2]};
-    float Rwp[9], owp[3] = {S.s[O(POS)], S.s[O(POS) + 1], S.s[O(POS) + 2]};
+    float Rw[9], d[3] = {0, 0, 0}, Vw[3] = {wb[0], wb[1], wb[2]}, Vv[3] = {vb[0], vb[1], vb[2]};
+    float Aa[3] = {0, 0, 0}, Al[3] = {0, 0, 0};
 #pragma unroll
-    for (int i = 0; i < 9; i++) Rwp[i] = Rb[i];
-    pass1_link<0>(S, K, 0, G0, 3 * leg, wr, wp, vp, Rwp, owp);
-    pass1_link<1>(S, K, 1, G1, 3 * leg + 1, wr, wp, vp, Rwp, owp);
-    pass1_link<1>(S, K, 2, G2, 3 * leg + 2, wr, wp, vp, Rwp, owp);
+    for (int i = 0; i < 9; i++) Rw[i] = Rb[i];
+    link_down<0>(S, K, 0, 3 * leg, wr, Rw, d, Vw, Vv, Aa, Al, G0);
+    link_down<1>(S, K, 1, 3 * leg + 1, wr, Rw, d, Vw, Vv, Aa, Al, G1);
+    link_down<1>(S, K, 2, 3 * leg + 2, wr, Rw, d, Vw, Vv, Aa, Al, G2);
   }
-  SCHED_FENCE();
-  float Iacc[6] = {0, 0, 0, 0, 0, 0}, Hacc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Macc[6] = {0, 0, 0, 0, 0, 0};
-  float pacc[6] = {0, 0, 0, 0, 0, 0};
-  pass2_link<1>(S, K, 2, G2, 3 * leg + 2, wr, Iacc, Hacc, Macc, pacc, U2, iD2, u2);
-  pass2_link<1>(S, K, 1, G1, 3 * leg + 1, wr, Iacc, Hacc, Macc, pacc, U1, iD1, u1);
-  pass2_link<0>(S, K, 0, G0, 3 * leg, wr, Iacc, Hacc, Macc, pacc, U0, iD0, u0);
+  // way up: composite inertias and subtree force sums
+#pragma unroll
+  for (int i = 0; i < 6; i++) { G1.I[i] += G2.I[i]; G1.f[i] += G2.f[i]; }
+#pragma unroll
+  for (int i = 0; i < 3; i++) G1.h[i] += G2.h[i];
+  G1.m += G2.m;
+#pragma unroll
+  for (int i = 0; i < 6; i++) { G0.I[i] += G1.I[i]; G0.f[i] += G1.f[i]; }
+#pragma unroll
+  for (int i = 0; i < 3; i++) G0.h[i] += G1.h[i];
+  G0.m += G1.m;
+  // F columns, bias torques C, leg mass matrix H
+  float F[3][6], b[3];
+  spatial_inertia_mul(G0.I, G0.h, G0.m, G0.s, G0.sv, &F[0][0], &F[0][3]);
+  spatial_inertia_mul(G1.I, G1.h, G1.m, G1.s, G1.sv, &F[1][0], &F[1][3]);
+  spatial_inertia_mul(G2.I, G2.h, G2.m, G2.s, G2.sv, &F[2][0], &F[2][3]);
+  b[0] = S.tau[3 * leg] - (dot3(G0.s, &G0.f[0]) + dot3(G0.sv, &G0.f[3]));
+  b[1] = S.tau[3 * leg + 1] - (dot3(G1.s, &G1.f[0]) + dot3(G1.sv, &G1.f[3]));
+  b[2] = S.tau[3 * leg + 2] - (dot3(G2.s, &G2.f[0]) + dot3(G2.sv, &G2.f[3]));
+  const float H00 = dot3(G0.s, &F[0][0]) + dot3(G0.sv, &F[0][3]), H01 = dot3(G0.s, &F[1][0]) + dot3(G0.sv, &F[1][3]);
+  const float H02 = dot3(G0.s, &F[2][0]) + dot3(G0.sv, &F[2][3]), H11 = dot3(G1.s, &F[1][0]) + dot3(G1.sv, &F[1][3]);
+  const float H12 = dot3(G1.s, &F[2][0]) + dot3(G1.sv, &F[2][3]), H22 = dot3(G2.s, &F[2][0]) + dot3(G2.sv, &F[2][3]);
+  float Hi[6];  // H^-1, symmetric (00 11 22 01 02 12), by cofactors
+  {
+    const float c00 = H11 * H22 - H12 * H12, c01 = H02 * H12 - H01 * H22, c02 = H01 * H12 - H02 * H11;
+    const float c11 = H00 * H22 - H02 * H02, c12 = H01 * H02 - H00 * H12, c22 = H00 * H11 - H01 * H01;
+    const float idet = __builtin_amdgcn_rcpf(H00 * c00 + H01 * c01 + H02 * c02);
+    Hi[0] = c00 * idet; Hi[1] = c11 * idet; Hi[2] = c22 * idet; Hi[3] = c01 * idet; Hi[4] = c02 * idet; Hi[5] = c12 * idet;
+  }
+  float T[3][6];  // T = F H^-1 (column k of T = sum_m F_m Hi[m][k])
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    T[0][i] = F[0][i] * Hi[0] + F[1][i] * Hi[3] + F[2][i] * Hi[4];
+    T[1][i] = F[0][i] * Hi[3] + F[1][i] * Hi[1] + F[2][i] * Hi[5];
+    T[2][i] = F[0][i] * Hi[4] + F[1][i] * Hi[5] + F[2][i] * Hi[2];
+  }
+  if (wr) {
+    LegSolve& Q = S.leg[leg];
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+      for (int i = 0; i < 6; i++) Q.T[k][i] = T[k][i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) Q.Hi[i] = Hi[i];
+  }
+  // this leg's part of the base equation: composite inertia minus T F^T, force p + T b
+  float Iacc[6], Hacc[9], Macc[6], pacc[6];
+#define TFT(i, j) (T[0][i] * F[0][j] + T[1][i] * F[1][j] + T[2][i] * F[2][j])
+  Iacc[0] = G0.I[0] - TFT(0, 0); Iacc[1] = G0.I[1] - TFT(1, 1); Iacc[2] = G0.I[2] - TFT(2, 2);
+  Iacc[3] = G0.I[3] - TFT(0, 1); Iacc[4] = G0.I[4] - TFT(0, 2); Iacc[5] = G0.I[5] - TFT(1, 2);
+  Macc[0] = G0.m - TFT(3, 3); Macc[1] = G0.m - TFT(4, 4); Macc[2] = G0.m - TFT(5, 5);
+  Macc[3] = -TFT(3, 4); Macc[4] = -TFT(3, 5); Macc[5] = -TFT(4, 5);
+  // top-right block: skew(h) - (T F^T)[a][3 + b]
+  Hacc[0] = -TFT(0, 3);           Hacc[1] = -G0.h[2] - TFT(0, 4); Hacc[2] = G0.h[1] - TFT(0, 5);
+  Hacc[3] = G0.h[2] - TFT(1, 3);  Hacc[4] = -TFT(1, 4);           Hacc[5] = -G0.h[0] - TFT(1, 5);
+  Hacc[6] = -G0.h[1] - TFT(2, 3); Hacc[7] = G0.h[0] - TFT(2, 4);  Hacc[8] = -TFT(2, 5);
+#undef TFT
+#pragma unroll
+  for (int i = 0; i < 6; i++) pacc[i] = G0.f[i] + T[0][i] * b[0] + T[1][i] * b[1] + T[2][i] * b[2];
   // base: sum the four leg contributions (butterfly over lane bits 0, 1 = DPP quad permutes, fused into the adds)
 #pragma unroll
   for (int i = 0; i < 6; i++) { Iacc[i] = quad_sum(Iacc[i]); Macc[i] = quad_sum(Macc[i]); pacc[i] = quad_sum(pacc[i]); }
@@ -462,18 +447,19 @@ __device__ static void aba_legs(const KParams& P, Shared& S, const LegConst& K, 
   for (int i = 0; i < 9; i++) Hacc[i] = quad_sum(Hacc[i]);
   float a0[6];
   {
-    float A6[36], pA0[6];
+    float A6[36], pA0[6], Ibw[6];
     const float m0 = S.mass[0];
+    rot_sym_full(Rb, S.Ic[0], Ibw);
     float n[3], f[3] = {m0 * vb[0], m0 * vb[1], m0 * vb[2]}, t1[3], t2[3];
-    symv(S.Ic[0], wb, n);
+    symv(Ibw, wb, n);
     cross3(wb, n, t1);
     cross3(wb, f, t2);
-    // Bullet base damping (btMultiBody ABA): torque k_a I w, force k_l m v on the bias side
+    // Bullet base damping (btMultiBody): torque k_a I w, force k_l m v on the bias side
     const float kl = S.s[O(BASE_DAMPING)], ka = S.s[O(BASE_DAMPING) + 1];
 #pragma unroll
     for (int i = 0; i < 3; i++) { pA0[i] = t1[i] + ka * n[i] + pacc[i]; pA0[3 + i] = t2[i] + kl * f[i] + pacc[3 + i]; }
     float Ib[9], Im[9], Mm[9];
-    sym_to_m3(S.Ic[0], Ib);
+    sym_to_m3(Ibw, Ib);
     sym_to_m3(Iacc, Im);
     sym_to_m3(Macc, Mm);
 #pragma unroll
@@ -501,52 +487,25 @@ __device__ static void aba_legs(const KParams& P, Shared& S, const LegConst& K, 
       for (int i = 0; i < 6; i++) S.IA0inv[i * 6 + col] = x[i];
     }
   }
+  // joint accelerations qdd = H^-1 (b - F^T a0)
   {
-    float ap[6] = {a0[0], a0[1], a0[2], a0[3], a0[4], a0[5]};
-    pass3_link<0>(S, K, 0, G0, U0, iD0, u0, 3 * leg, wr, ap);
-    pass3_link<1>(S, K, 1, G1, U1, iD1, u1, 3 * leg + 1, wr, ap);
-    pass3_link<1>(S, K, 2, G2, U2, iD2, u2, 3 * leg + 2, wr, ap);
+    float g[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+      g[k] = b[k] - (F[k][0] * a0[0] + F[k][1] * a0[1] + F[k][2] * a0[2] + F[k][3] * a0[3] + F[k][4] * a0[4] + F[k][5] * a0[5]);
+    if (wr) {
+      S.acc[6 + 3 * leg] = Hi[0] * g[0] + Hi[3] * g[1] + Hi[4] * g[2];
+      S.acc[6 + 3 * leg + 1] = Hi[3] * g[0] + Hi[1] * g[1] + Hi[5] * g[2];
+      S.acc[6 + 3 * leg + 2] = Hi[4] * g[0] + Hi[5] * g[1] + Hi[2] * g[2];
+    }
   }
   if (lane == 0) {
-    // world-frame base accelerations (Bullet: vdot = R (a_lin + w x v)); gravity = uniform-field offset
-    float t[3], wxv[3];
-    mv3(Rb, &a0[0], t);
-    S.acc[0] = t[0]; S.acc[1] = t[1]; S.acc[2] = t[2];
+    // classical base acceleration (Bullet: vdot = a_lin + w x v); gravity = uniform-field offset
+    float wxv[3];
     cross3(wb, vb, wxv);
-    wxv[0] += a0[3]; wxv[1] += a0[4]; wxv[2] += a0[5];
-    mv3(Rb, wxv, t);
-    S.acc[3] = t[0]; S.acc[4] = t[1]; S.acc[5] = t[2] + P.cfg.gravity_z;
+    S.acc[0] = a0[0]; S.acc[1] = a0[1]; S.acc[2] = a0[2];
+    S.acc[3] = a0[3] + wxv[0]; S.acc[4] = a0[4] + wxv[1]; S.acc[5] = a0[5] + wxv[2] + P.cfg.gravity_z;
   }
-}
-
-// impulse response helpers (btMultiBody::calcAccelerationDeltasMultiDof), one link each
-template <int AX>
-__device__ __forceinline__ void delta_in(const Shared& S, int j, float jl, float pA[6], float& ud) {
-  const LinkCache& L = S.lc[j];
-  ud = jl - pA[AX];
-  const float sc = ud * L.invD;
-  const float pat[3] = {pA[0] + L.U[0] * sc, pA[1] + L.U[1] * sc, pA[2] + L.U[2] * sc};
-  const float pab[3] = {pA[3] + L.U[3] * sc, pA[4] + L.U[4] * sc, pA[5] + L.U[5] * sc};
-  float fp[3], np_[3], rxf[3];
-  rot_fwd<AX>(L.c, L.s, pab, fp);
-  rot_fwd<AX>(L.c, L.s, pat, np_);
-  cross3(S.m.joint_pos[j], fp, rxf);
-  pA[0] = np_[0] + rxf[0]; pA[1] = np_[1] + rxf[1]; pA[2] = np_[2] + rxf[2];
-  pA[3] = fp[0]; pA[4] = fp[1]; pA[5] = fp[2];
-}
-template <int AX>
-__device__ __forceinline__ float delta_out(const Shared& S, int j, float ud, float ap[6]) {
-  const LinkCache& L = S.lc[j];
-  float t[3], at[3], ab[3];
-  cross3(&ap[0], S.m.joint_pos[j], t);
-  t[0] += ap[3]; t[1] += ap[4]; t[2] += ap[5];
-  rot_inv<AX>(L.c, L.s, &ap[0], at);
-  rot_inv<AX>(L.c, L.s, t, ab);
-  const float Ud = L.U[0] * at[0] + L.U[1] * at[1] + L.U[2] * at[2] + L.U[3] * ab[0] + L.U[4] * ab[1] + L.U[5] * ab[2];
-  const float qdd = (ud - Ud) * L.invD;
-  at[AX] += qdd;
-  ap[0] = at[0]; ap[1] = at[1]; ap[2] = at[2]; ap[3] = ab[0]; ap[4] = ab[1]; ap[5] = ab[2];
-  return qdd;
 }
 
 // One constraint row (state of a row lane for one of its two banks)
@@ -641,20 +600,14 @@ __device__ __forceinline__ void row_setup(const Shared& S, const orr_config& cfg
   if (!R.active) R.rhs = 0.0f;
 }
 
-// impulse response M^-1 J^T of the row (btMultiBody::calcAccelerationDeltasMultiDof) -> W[slot]; 1/diag; warm start
+// impulse response M^-1 J^T of the row (what btMultiBody::calcAccelerationDeltasMultiDof returns) -> W[slot]; 1/diag;
+// warm start.  Block form, see leg_dynamics: da0 = A0^-1 (Jb - T_L jl); dqdd_L = H_L^-1 jl - T_L^T da0; dqdd_K = -T_K^T da0.
 __device__ __forceinline__ void row_response(Shared& S, const orr_config& cfg, Row& R, int slot) {
-  float diag = 0.0f;
-  float mj[6], mq[12];
-  float pA[6] = {0, 0, 0, 0, 0, 0}, ud0, ud1, ud2;
   const int leg = R.leg;
-  delta_in<1>(S, 3 * leg + 2, R.jl[2], pA, ud2);
-  delta_in<1>(S, 3 * leg + 1, R.jl[1], pA, ud1);
-  delta_in<0>(S, 3 * leg, R.jl[0], pA, ud0);
-  float fb[6], a0[6];
-  mtv3(S.Rb, &R.Jb[0], &fb[0]);
-  mtv3(S.Rb, &R.Jb[3], &fb[3]);
+  const LegSolve& QL = S.leg[leg];
+  float fb[6], a0[6], mq[12];
 #pragma unroll
-  for (int i = 0; i < 6; i++) fb[i] -= pA[i];
+  for (int i = 0; i < 6; i++) fb[i] = R.Jb[i] - (QL.T[0][i] * R.jl[0] + QL.T[1][i] * R.jl[1] + QL.T[2][i] * R.jl[2]);
 #pragma unroll
   for (int i = 0; i < 6; i++) {
     float sacc = 0.0f;
@@ -662,22 +615,28 @@ __device__ __forceinline__ void row_response(Shared& S, const orr_config& cfg, R
     for (int k = 0; k < 6; k++) sacc += S.IA0inv[i * 6 + k] * fb[k];
     a0[i] = sacc;
   }
+  const float h0 = QL.Hi[0] * R.jl[0] + QL.Hi[3] * R.jl[1] + QL.Hi[4] * R.jl[2];
+  const float h1 = QL.Hi[3] * R.jl[0] + QL.Hi[1] * R.jl[1] + QL.Hi[5] * R.jl[2];
+  const float h2 = QL.Hi[4] * R.jl[0] + QL.Hi[5] * R.jl[1] + QL.Hi[2] * R.jl[2];
+  float diag = 0.0f;
 #pragma unroll
   for (int L4 = 0; L4 < 4; L4++) {
-    float ap[6] = {a0[0], a0[1], a0[2], a0[3], a0[4], a0[5]};
+    const LegSolve& Q = S.leg[L4];
     const bool mine = (L4 == leg);
-    mq[3 * L4] = delta_out<0>(S, 3 * L4, mine ? ud0 : 0.0f, ap);
-    mq[3 * L4 + 1] = delta_out<1>(S, 3 * L4 + 1, mine ? ud1 : 0.0f, ap);
-    mq[3 * L4 + 2] = delta_out<1>(S, 3 * L4 + 2, mine ? ud2 : 0.0f, ap);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      float t = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 6; i++) t += Q.T[k][i] * a0[i];
+      mq[3 * L4 + k] = (mine ? (k == 0 ? h0 : (k == 1 ? h1 : h2)) : 0.0f) - t;
+    }
     diag += mine ? (R.jl[0] * mq[3 * L4] + R.jl[1] * mq[3 * L4 + 1] + R.jl[2] * mq[3 * L4 + 2]) : 0.0f;
   }
-  mv3(S.Rb, &a0[0], &mj[0]);
-  mv3(S.Rb, &a0[3], &mj[3]);
 #pragma unroll
-  for (int i = 0; i < 6; i++) diag += R.Jb[i] * mj[i];
+  for (int i = 0; i < 6; i++) diag += R.Jb[i] * a0[i];
   if (R.active) {
 #pragma unroll
-    for (int i = 0; i < 6; i++) S.ph.sub.W[slot][i] = mj[i];
+    for (int i = 0; i < 6; i++) S.ph.sub.W[slot][i] = a0[i];
 #pragma unroll
     for (int i = 0; i < 12; i++) S.ph.sub.W[slot][6 + i] = mq[i];
   }
@@ -822,7 +781,7 @@ __device__ __forceinline__ void delassus_columns(const Shared& S, unsigned int m
 __device__ static int physics_substep(const KParams& P, Shared& S, const LegConst& K, int lane, int sub, bool want_fall) {
   const orr_config& cfg = P.cfg;
   const float dt = cfg.sim_dt, inv_dt = 1.0f / cfg.sim_dt, erp_dt = cfg.contact_erp / cfg.sim_dt;
-  aba_legs(P, S, K, lane);
+  leg_dynamics(P, S, K, lane);
   WSYNC();
   PT(3);
   for (int i = lane; i < 18; i += kLanes) {
