@@ -687,8 +687,9 @@ __device__ __forceinline__ float row_update(float& y, float& lam, float lo, floa
 //   sum = clamp(y);  d = broadcast(sum - lambda);  lambda = sum (own lane);  y += Ac[r] d   (every row lane)
 // with Ac[r] = -A[row][r] / diag(row) off the diagonal and 0 on it (y of the updated row does not move)
 // = 6 vector instructions.  HAS_B: some robot of the wave has an active joint-limit row (bank B is swept too).
-// Knee rows are swept unconditionally, contact rows per leg when some robot of the wave has that toe in contact (a
-// row visited for a robot where it is inactive is a no-op: its bounds, 1/diag and lambda are zero).
+// Knee and contact rows are swept unconditionally (a row visited for a robot where it is inactive is a no-op: its
+// bounds, 1/diag, lambda and Delassus column are zero); measured 9 % faster than one scalar branch per leg, which also
+// stopped the scheduler from overlapping consecutive row updates.
 template <bool HAS_B>
 __device__ __forceinline__ void pgs_sweeps(int iters, unsigned int mask, int lane, int sub, Row& A, Row& B,
                                            const float (&AcA)[kMaxRows], const float (&AcB)[kMaxRows]) {
@@ -699,7 +700,6 @@ __device__ __forceinline__ void pgs_sweeps(int iters, unsigned int mask, int lan
 #pragma unroll
   for (int g = 0; g < 4; g++) mun[g] = A.nrm_slot == 16 + g ? A.mu_e : 0.0f;
   float hiE = fmaf(A.mu_e, A.lam_n, A.hi_c), loE = fmaf(-A.mu_e, A.lam_n, A.lo_c);
-  const unsigned int cm = (mask >> 16) & 0xFu;  // legs with a toe contact in some robot of the wave
   for (int it = 0; it < iters; it++) {
     auto rowA = [&](auto rc) __attribute__((always_inline)) {
       constexpr int r = decltype(rc)::value, src = r < 4 ? r : r - 12;
@@ -720,17 +720,7 @@ __device__ __forceinline__ void pgs_sweeps(int iters, unsigned int mask, int lan
         }
       });
     }
-    static_for<0, 4>([&](auto gc) __attribute__((always_inline)) {
-      constexpr int g = decltype(gc)::value;
-      if ((cm >> g) & 1u) rowA(std::integral_constant<int, 16 + g>{});
-    });
-    static_for<0, 4>([&](auto gc) __attribute__((always_inline)) {
-      constexpr int g = decltype(gc)::value;
-      if ((cm >> g) & 1u) {
-        rowA(std::integral_constant<int, 20 + 2 * g>{});
-        rowA(std::integral_constant<int, 21 + 2 * g>{});
-      }
-    });
+    static_for<16, 28>(rowA);
   }
   A.lam = lamA; B.lam = lamB;
 }
@@ -864,14 +854,7 @@ __device__ static int physics_substep(const KParams& P, Shared& S, const LegCons
         if ((mask >> decltype(rc)::value) & 1u) add_row(rc);
       });
     }
-    static_for<0, 4>([&](auto gc) __attribute__((always_inline)) {
-      constexpr int g = decltype(gc)::value;
-      if ((mask >> (16 + g)) & 1u) {
-        add_row(std::integral_constant<int, 16 + g>{});
-        add_row(std::integral_constant<int, 20 + 2 * g>{});
-        add_row(std::integral_constant<int, 21 + 2 * g>{});
-      }
-    });
+    static_for<16, 28>(add_row);
     const float vmax = cfg.max_coord_velocity;
     v0 = __builtin_amdgcn_fmed3f(S.ustar[k0] + du0, -vmax, vmax);
     v1 = __builtin_amdgcn_fmed3f(S.ustar[k1] + du1, -vmax, vmax);
