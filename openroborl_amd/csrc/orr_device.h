@@ -151,7 +151,6 @@ struct Shared {
   float Rb[9];                // kinematic base frame -> world
   float IA0inv[36];           // inverse of the base's effective 6x6 inertia (world axes, about the base COM)
   float tau[12];              // joint torques (internal sign convention), joint order
-  float acc[18];
   float ustar[18];
   float co[20];               // control (latency-delayed) observation
   float red[64];

@@ -293,9 +293,10 @@ struct LinkDyn {  // per link, registers of the leg lane
 // one link on the way down the leg: pose, velocity, velocity-product acceleration, inertia about O, bias force
 template <int AX>
 __device__ __forceinline__ void link_down(Shared& S, const LegConst& K, int k, int j, bool wr, float Rw[9], float d[3], float Vw[3],
-                                          float Vv[3], float Aa[3], float Al[3], LinkDyn& G) {
+                                          float Vv[3], float Aa[3], float Al[3], LinkDyn& G, float& ad_out) {
   const float a = K.jdir[k] * (S.s[O(Q) + j] - K.joff[k]);
   const float ad = K.jdir[k] * S.s[O(QD) + j];
+  ad_out = ad;
   float sn, cs;
   joint_sincos(a, &sn, &cs);
   // pose: d += Rw_parent r;  Rw = Rw_parent R(a)
@@ -372,14 +373,15 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
   const float wb[3] = {S.s[O(ANGVEL)], S.s[O(ANGVEL) + 1], S.s[O(ANGVEL) + 2]};
   const float vb[3] = {S.s[O(LINVEL)], S.s[O(LINVEL) + 1], S.s[O(LINVEL) + 2]};
   LinkDyn G0, G1, G2;
+  float ad0, ad1, ad2;  // joint rates (internal sign)
   {
     float Rw[9], d[3] = {0, 0, 0}, Vw[3] = {wb[0], wb[1], wb[2]}, Vv[3] = {vb[0], vb[1], vb[2]};
     float Aa[3] = {0, 0, 0}, Al[3] = {0, 0, 0};
 #pragma unroll
     for (int i = 0; i < 9; i++) Rw[i] = Rb[i];
-    link_down<0>(S, K, 0, 3 * leg, wr, Rw, d, Vw, Vv, Aa, Al, G0);
-    link_down<1>(S, K, 1, 3 * leg + 1, wr, Rw, d, Vw, Vv, Aa, Al, G1);
-    link_down<1>(S, K, 2, 3 * leg + 2, wr, Rw, d, Vw, Vv, Aa, Al, G2);
+    link_down<0>(S, K, 0, 3 * leg, wr, Rw, d, Vw, Vv, Aa, Al, G0, ad0);
+    link_down<1>(S, K, 1, 3 * leg + 1, wr, Rw, d, Vw, Vv, Aa, Al, G1, ad1);
+    link_down<1>(S, K, 2, 3 * leg + 2, wr, Rw, d, Vw, Vv, Aa, Al, G2, ad2);
   }
   // way up: composite inertias and subtree force sums
 #pragma unroll
@@ -487,24 +489,27 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
       for (int i = 0; i < 6; i++) S.IA0inv[i * 6 + col] = x[i];
     }
   }
-  // joint accelerations qdd = H^-1 (b - F^T a0)
+  // joint accelerations qdd = H^-1 (b - F^T a0); written as the unconstrained velocities u* = u + dt udot
+  const float dt = P.cfg.sim_dt;
   {
     float g[3];
 #pragma unroll
     for (int k = 0; k < 3; k++)
       g[k] = b[k] - (F[k][0] * a0[0] + F[k][1] * a0[1] + F[k][2] * a0[2] + F[k][3] * a0[3] + F[k][4] * a0[4] + F[k][5] * a0[5]);
     if (wr) {
-      S.acc[6 + 3 * leg] = Hi[0] * g[0] + Hi[3] * g[1] + Hi[4] * g[2];
-      S.acc[6 + 3 * leg + 1] = Hi[3] * g[0] + Hi[1] * g[1] + Hi[5] * g[2];
-      S.acc[6 + 3 * leg + 2] = Hi[4] * g[0] + Hi[5] * g[1] + Hi[2] * g[2];
+      S.ustar[6 + 3 * leg] = ad0 + dt * (Hi[0] * g[0] + Hi[3] * g[1] + Hi[4] * g[2]);
+      S.ustar[6 + 3 * leg + 1] = ad1 + dt * (Hi[3] * g[0] + Hi[1] * g[1] + Hi[5] * g[2]);
+      S.ustar[6 + 3 * leg + 2] = ad2 + dt * (Hi[4] * g[0] + Hi[5] * g[1] + Hi[2] * g[2]);
     }
   }
   if (lane == 0) {
     // classical base acceleration (Bullet: vdot = a_lin + w x v); gravity = uniform-field offset
     float wxv[3];
     cross3(wb, vb, wxv);
-    S.acc[0] = a0[0]; S.acc[1] = a0[1]; S.acc[2] = a0[2];
-    S.acc[3] = a0[3] + wxv[0]; S.acc[4] = a0[4] + wxv[1]; S.acc[5] = a0[5] + wxv[2] + P.cfg.gravity_z;
+    S.ustar[0] = wb[0] + dt * a0[0]; S.ustar[1] = wb[1] + dt * a0[1]; S.ustar[2] = wb[2] + dt * a0[2];
+    S.ustar[3] = vb[0] + dt * (a0[3] + wxv[0]);
+    S.ustar[4] = vb[1] + dt * (a0[4] + wxv[1]);
+    S.ustar[5] = vb[2] + dt * (a0[5] + wxv[2] + P.cfg.gravity_z);
   }
 }
 
@@ -748,7 +753,8 @@ __device__ __forceinline__ void delassus_columns(const Shared& S, unsigned int m
       B.w += b * l0;
       AcB[r] = (inB && lane == src) ? 0.0f : -b * B.jdi;
     }
-    asm volatile("" : "+v"(AcA[r]), "+v"(AcB[r]));  // keep the scaled value (do not re-derive it inside the sweeps)
+    asm("" : "+v"(AcA[r]), "+v"(AcB[r]));  // keep the scaled value (do not re-derive it inside the sweeps); not volatile:
+                                           // a volatile asm would end the scheduling region and expose every LDS read
   };
   static_for<0, 4>(column);
   if (HAS_B) {
@@ -771,13 +777,9 @@ __device__ __forceinline__ void delassus_columns(const Shared& S, unsigned int m
 __device__ static int physics_substep(const KParams& P, Shared& S, const LegConst& K, int lane, int sub, bool want_fall) {
   const orr_config& cfg = P.cfg;
   const float dt = cfg.sim_dt, inv_dt = 1.0f / cfg.sim_dt, erp_dt = cfg.contact_erp / cfg.sim_dt;
-  leg_dynamics(P, S, K, lane);
+  leg_dynamics(P, S, K, lane);  // -> link poses, leg solves, unconstrained velocities u*
   WSYNC();
   PT(3);
-  for (int i = lane; i < 18; i += kLanes) {
-    float u = i < 3 ? S.s[O(ANGVEL) + i] : (i < 6 ? S.s[O(LINVEL) + i - 3] : S.m.jdir[i - 6] * S.s[O(QD) + i - 6]);
-    S.ustar[i] = u + dt * S.acc[i];
-  }
   int fall = 0;
   if (want_fall) {  // termination-only collision proxies (imitation_task.py:536-546)
     bool hit = false;
@@ -790,7 +792,6 @@ __device__ static int physics_substep(const KParams& P, Shared& S, const LegCons
     }
     fall = ((__ballot(hit) >> (sub * kLanes)) & ((1ull << (kLanes - 1)) * 2ull - 1ull)) != 0ull;
   }
-  WSYNC();
   PT(4);
 
   // ---------------- constraint rows ----------------
