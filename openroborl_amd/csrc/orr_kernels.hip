@@ -81,15 +81,25 @@ __device__ static void ctrl_obs(const KParams& P, const float* rec, Shared& S, i
   WSYNC();
 }
 
+// Orientation relative to the initial one (minitaur.py:325-331) and its rotation matrix (kinematic base frame -> world)
+// -> Shared::Rb.  Called after every change of the base quaternion; the caller syncs.
+__device__ __forceinline__ void base_rotation(Shared& S, int lane, float rel[4], float Rb[9]) {
+  float qi[4];
+  qinv(S.m.init_quat, qi);
+  qmul(&S.s[O(QUAT)], qi, rel);
+  q_to_mat(rel, Rb);
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) S.Rb[i] = Rb[i];
+  }
+}
+
 // Minitaur.receive_obs + get_true_obs (minitaur.py:304-334): push the true observation
 __device__ static void receive_obs(float* rec, Shared& S, int lane, bool valid) {
   const int head = (geti(S, O(RING_HEAD)) + 1) % ORR_RING_DEPTH, len = geti(S, O(RING_LEN));
-  float qi[4], rel[4], ri[4], Rm[9], rate[3];
-  qinv(S.m.init_quat, qi);
-  qmul(&S.s[O(QUAT)], qi, rel);  // orientation relative to the initial one (minitaur.py:325-331)
-  qinv(rel, ri);
-  q_to_mat(ri, Rm);
-  mv3(Rm, &S.s[O(ANGVEL)], rate);  // get_true_base_rpy_rate (minitaur.py:640-672)
+  float rel[4], Rb[9], rate[3];
+  base_rotation(S, lane, rel, Rb);
+  mtv3(Rb, &S.s[O(ANGVEL)], rate);  // get_true_base_rpy_rate (minitaur.py:640-672): angular velocity in the base frame
   for (int i = lane; i < ORR_RING_ENTRY; i += kLanes) {
     float val = 0.0f;
     if (i < 12) {
@@ -151,12 +161,9 @@ __device__ __forceinline__ void ring_prefetch(const RingLatency& L, const float*
 __device__ __forceinline__ void ring_push_and_ctrl_obs(float* rec, Shared& S, int lane, bool valid, const RingFetch& F) {
   static_assert(ORR_RING_ENTRY == 20, "lane mapping below assumes 20-word entries");
   const int head = (geti(S, O(RING_HEAD)) + 1) % ORR_RING_DEPTH, len = geti(S, O(RING_LEN));
-  float qi[4], rel[4], ri[4], Rm[9], rate[3];
-  qinv(S.m.init_quat, qi);
-  qmul(&S.s[O(QUAT)], qi, rel);  // orientation relative to the initial one (minitaur.py:325-331)
-  qinv(rel, ri);
-  q_to_mat(ri, Rm);
-  mv3(Rm, &S.s[O(ANGVEL)], rate);  // get_true_base_rpy_rate (minitaur.py:640-672)
+  float rel[4], Rb[9], rate[3];
+  base_rotation(S, lane, rel, Rb);
+  mtv3(Rb, &S.s[O(ANGVEL)], rate);  // get_true_base_rpy_rate (minitaur.py:640-672): angular velocity in the base frame
   // word `lane`: motor angles 0..11, relative quaternion 12..15; word 16 + lane (lanes 0..3): rate 16..18, pad 19
   float va, vb;
   {
@@ -359,17 +366,9 @@ __device__ __forceinline__ void link_down(Shared& S, const LegConst& K, int k, i
 __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst& K, int lane) {
   const int leg = lane & 3;
   const bool wr = lane < 4;
-  float Rb[9];
-  {
-    float qi[4], qrel[4];
-    qinv(S.m.init_quat, qi);
-    qmul(&S.s[O(QUAT)], qi, qrel);
-    q_to_mat(qrel, Rb);
-  }
-  if (lane == 0) {
+  float Rb[9];  // kinematic base frame -> world: kept current by base_rotation() (after every change of the quaternion)
 #pragma unroll
-    for (int i = 0; i < 9; i++) S.Rb[i] = Rb[i];
-  }
+  for (int i = 0; i < 9; i++) Rb[i] = S.Rb[i];
   const float wb[3] = {S.s[O(ANGVEL)], S.s[O(ANGVEL) + 1], S.s[O(ANGVEL) + 2]};
   const float vb[3] = {S.s[O(LINVEL)], S.s[O(LINVEL) + 1], S.s[O(LINVEL) + 2]};
   LinkDyn G0, G1, G2;
@@ -1383,13 +1382,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
   WSYNC();
   LegConst K;
   load_leg_const(S, lane & 3, K);
+  {
+    float rel[4], Rb[9];
+    base_rotation(S, lane, rel, Rb);  // Shared::Rb for the first sub-step; the ring push keeps it current afterwards
+  }
   PT(0);
 
   if (MODE == 1) {
     if (lane < 12) { const int j = S.m.joint_of_motor[lane]; S.tau[j] = S.m.tau_sign[j] * actions[(size_t)robot * 12 + lane]; }
     WSYNC();
     int fall = 0;
-    for (int s = 0; s < nsub; s++) fall = physics_substep(P, S, K, lane, sub, true);
+    for (int s = 0; s < nsub; s++) {
+      fall = physics_substep(P, S, K, lane, sub, true);
+      float rel[4], Rb[9];
+      base_rotation(S, lane, rel, Rb);
+      WSYNC();
+    }
     if (valid && lane == 0 && done_out) done_out[robot] = (uint8_t)fall;
     store_robot(rec, S, lane, valid);
     return;
