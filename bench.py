@@ -103,9 +103,15 @@ def main():
     noise_pool = torch.randn(64, n, 12, generator=gen, device=dev) * 0.125 - (off * mdir + init)
     two_pi = 2.0 * 3.141592653589793
 
+    # the joint -> motor permutation and the motor direction signs as one 12x12 matrix: two kernels per step (GEMM, clamp)
+    perm = torch.zeros(12, 12, dtype=torch.float32, device=dev)
+    perm[jom, torch.arange(12, device=dev)] = mdir
+
     def make_action(obs, k):
         tar = obs[:, 84 + 7:84 + 19]
-        return torch.addcmul(noise_pool[k & 63], tar.index_select(1, jom), mdir).clamp_(-two_pi, two_pi)
+        if os.environ.get("ORR_BENCH_INDEX_SELECT"):
+            return torch.addcmul(noise_pool[k & 63], tar.index_select(1, jom), mdir).clamp_(-two_pi, two_pi)
+        return torch.addmm(noise_pool[k & 63], tar, perm).clamp_(-two_pi, two_pi)
 
     def sync_all():
         if world > 1:
