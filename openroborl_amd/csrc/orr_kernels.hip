@@ -657,48 +657,20 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for<I + 1, N>(f);
   }
 }
-// One Gauss-Seidel row update (see pgs_sweeps): sum = clamp(y, lo, hi); d = (sum - lam) of lane SRC broadcast to the
-// robot's lanes; lam = sum in lane SRC; y += ac d.  Returns d.
-// Written out for the 16-lane layout: (a) the lane compare is redone at each use - hoisted out of the sweep loop the 28
-// lane masks cost 28 SGPR pairs (spills + reloads); (b) the compare + select sit between the subtraction and the DPP
-// move that reads its result, which covers the two wait states of that hazard; (c) one block, so that no conservative
-// wait state is inserted between its instructions.
-template <int SRC>
-__device__ __forceinline__ float row_update(float& y, float& lam, float lo, float hi, float ac, int lane, int sub) {
-#if !defined(ORR_READLANE_BCAST)
-  if (kRPW == 4) {
-    float d, sum;
-    asm("v_med3_f32 %1, %3, %4, %5\n\t"
-        "v_sub_f32_e32 %0, %1, %2\n\t"
-        "v_cmp_eq_u32_e32 vcc, %8, %6\n\t"
-        "v_cndmask_b32_e32 %2, %2, %1, vcc\n\t"
-        "v_mov_b32_dpp %0, %0 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_e32 %3, %7, %0"
-        : "=&v"(d), "=&v"(sum), "+v"(lam), "+v"(y) : "v"(lo), "v"(hi), "v"(lane), "v"(ac), "n"(SRC) : "vcc");
-    return d;
-  }
-#endif
-  const float sum = __builtin_amdgcn_fmed3f(y, lo, hi);
-  const float d = bcast_lane<SRC>(sum - lam, sub);
-  lam = lane == SRC ? sum : lam;
-  y = fmaf(ac, d, y);
-  return d;
-}
-
 // The Gauss-Seidel sweeps over the row slots in solve order (btMultiBodyConstraintSolver::solveSingleIteration),
-// Delassus form.  Every row lane keeps, for its row, lambda and y = lambda + (rhs - (A lambda)) / diag (the unclamped
-// Gauss-Seidel value), so that a row update is
-//   sum = clamp(y);  d = broadcast(sum - lambda);  lambda = sum (own lane);  y += Ac[r] d   (every row lane)
-// with Ac[r] = -A[row][r] / diag(row) off the diagonal and 0 on it (y of the updated row does not move)
-// = 6 vector instructions.  HAS_B: some robot of the wave has an active joint-limit row (bank B is swept too).
+// Delassus form.  A row lane keeps y = lambda + (rhs - (A lambda)) / diag of its row (the unclamped Gauss-Seidel value),
+// and EVERY lane keeps the impulses of all rows (lam[r], equal in all lanes of the robot).  One row update is
+//   y' = y - Ac[r] lam[r];   lam[r] = broadcast_from_lane_of_r(clamp(y, lo, hi));   y = y' + Ac[r] lam[r]
+// with Ac[r] = -A[row][r] / diag(row) off the diagonal and 0 on it (y of the updated row does not move): four vector
+// instructions (fma, v_med3, v_mov_dpp row_newbcast, fma), three of them on the dependent chain.
+// HAS_B: some robot of the wave has an active joint-limit row (bank B is swept too).
 // Knee and contact rows are swept unconditionally (a row visited for a robot where it is inactive is a no-op: its
 // bounds, 1/diag, lambda and Delassus column are zero); measured 9 % faster than one scalar branch per leg, which also
 // stopped the scheduler from overlapping consecutive row updates.
 template <bool HAS_B>
 __device__ __forceinline__ void pgs_sweeps(int iters, unsigned int mask, int lane, int sub, Row& A, Row& B,
-                                           const float (&AcA)[kMaxRows], const float (&AcB)[kMaxRows]) {
-  float lamA = A.lam, lamB = B.lam;
-  float yA = lamA + fmaf(-A.w, A.jdi, A.rhs), yB = lamB + fmaf(-B.w, B.jdi, B.rhs);
+                                           const float (&AcA)[kMaxRows], const float (&AcB)[kMaxRows], float (&lam)[kMaxRows]) {
+  float yA = A.lam + fmaf(-A.w, A.jdi, A.rhs), yB = B.lam + fmaf(-B.w, B.jdi, B.rhs);
   const float hiB = B.hi_c, loB = B.lo_c;
   float mun[4];  // friction rows: d(bound) / d(normal impulse of their toe)
 #pragma unroll
@@ -707,10 +679,15 @@ __device__ __forceinline__ void pgs_sweeps(int iters, unsigned int mask, int lan
   for (int it = 0; it < iters; it++) {
     auto rowA = [&](auto rc) __attribute__((always_inline)) {
       constexpr int r = decltype(rc)::value, src = r < 4 ? r : r - 12;
-      const float d = row_update<src>(yA, lamA, loE, hiE, AcA[r], lane, sub);
-      if (HAS_B) yB = fmaf(AcB[r], d, yB);
+      const float old = lam[r];
+      const float yp = fmaf(-AcA[r], old, yA);
+      const float sb = bcast_lane<src>(__builtin_amdgcn_fmed3f(yA, loE, hiE), sub);
+      yA = fmaf(AcA[r], sb, yp);
+      lam[r] = sb;
+      if (HAS_B) yB = fmaf(AcB[r], sb - old, yB);
       if (r >= 16 && r < 20) {  // a normal impulse moved: friction bounds of the rows of that toe follow
         constexpr int g = r >= 16 && r < 20 ? r - 16 : 0;
+        const float d = sb - old;
         hiE = fmaf(mun[g], d, hiE); loE = fmaf(-mun[g], d, loE);
       }
     };
@@ -719,30 +696,34 @@ __device__ __forceinline__ void pgs_sweeps(int iters, unsigned int mask, int lan
       static_for<4, 16>([&](auto rc) __attribute__((always_inline)) {
         constexpr int r = decltype(rc)::value;
         if ((mask >> r) & 1u) {
-          const float d = row_update<r>(yB, lamB, loB, hiB, AcB[r], lane, sub);
-          yA = fmaf(AcA[r], d, yA);
+          const float old = lam[r];
+          const float yp = fmaf(-AcB[r], old, yB);
+          const float sb = bcast_lane<r>(__builtin_amdgcn_fmed3f(yB, loB, hiB), sub);
+          yB = fmaf(AcB[r], sb, yp);
+          lam[r] = sb;
+          yA = fmaf(AcA[r], sb - old, yA);
         }
       });
     }
     static_for<16, 28>(rowA);
   }
-  A.lam = lamA; B.lam = lamB;
 }
 
 // Delassus columns A[row][r] = J . W[r], kept in registers already scaled for the sweeps: Ac[r] = -A[row][r] / diag(row),
-// 0 on the diagonal; w = (A lambda) of the warm start.  Row groups as in pgs_sweeps: knee rows always (an inactive
-// one has a zero impulse response), joint-limit rows one by one, contact rows per leg.
+// 0 on the diagonal; w = (A lambda) of the warm start; lam[r] = warm-start impulse of row r (in every lane).  Knee rows
+// always (an inactive one has a zero impulse response), joint-limit rows one by one, contact rows per leg.
 template <bool HAS_B>
 __device__ __forceinline__ void delassus_columns(const Shared& S, unsigned int mask, int lane, int sub, Row& A, Row& B,
-                                                 float (&AcA)[kMaxRows], float (&AcB)[kMaxRows]) {
+                                                 float (&AcA)[kMaxRows], float (&AcB)[kMaxRows], float (&lam)[kMaxRows]) {
 #pragma unroll
-  for (int r = 0; r < kMaxRows; r++) { AcA[r] = 0.0f; AcB[r] = 0.0f; }
+  for (int r = 0; r < kMaxRows; r++) { AcA[r] = 0.0f; AcB[r] = 0.0f; lam[r] = 0.0f; }
   auto column = [&](auto rc) __attribute__((always_inline)) {
     constexpr int r = decltype(rc)::value;
     constexpr bool inB = r >= 4 && r < 16;
     constexpr int src = inB ? r : (r < 4 ? r : r - 12);
     const float* Wr = S.ph.sub.W[r];
     const float l0 = bcast_lane<src>(inB ? B.lam : A.lam, sub);
+    lam[r] = l0;
     const float a = row_dot(A, Wr);
     A.w += a * l0;
     AcA[r] = (!inB && lane == src) ? 0.0f : -a * A.jdi;
@@ -821,19 +802,26 @@ __device__ static int physics_substep(const KParams& P, Shared& S, const LegCons
   WSYNC();
   PT(6);
   // Delassus columns, then the Gauss-Seidel sweeps; two instantiations: with and without the joint-limit bank
-  float AcA[kMaxRows], AcB[kMaxRows];
+  float AcA[kMaxRows], AcB[kMaxRows], lam[kMaxRows];
   if (anyB) {
-    delassus_columns<true>(S, mask, lane, sub, A, B, AcA, AcB);
+    delassus_columns<true>(S, mask, lane, sub, A, B, AcA, AcB, lam);
     PT(7);
-    pgs_sweeps<true>(cfg.solver_iters, mask, lane, sub, A, B, AcA, AcB);
+    pgs_sweeps<true>(cfg.solver_iters, mask, lane, sub, A, B, AcA, AcB, lam);
   } else {
-    delassus_columns<false>(S, mask, lane, sub, A, B, AcA, AcB);
+    delassus_columns<false>(S, mask, lane, sub, A, B, AcA, AcB, lam);
     PT(7);
-    pgs_sweeps<false>(cfg.solver_iters, mask, lane, sub, A, B, AcA, AcB);
+    pgs_sweeps<false>(cfg.solver_iters, mask, lane, sub, A, B, AcA, AcB, lam);
   }
   PT(8);
   // contact impulses are remembered for the next sub-step's warm start (0 for open contacts)
-  if (rowlane && lane >= 4) S.s[O(LAMBDA) + A.warm] = A.active ? A.lam : 0.0f;
+  if (lane == 0) {  // warm-start slot 3 leg + d: normal (slot 16 + leg), then the two friction rows (20 + 2 leg, 21 + 2 leg)
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      S.s[O(LAMBDA) + 3 * g] = lam[16 + g];
+      S.s[O(LAMBDA) + 3 * g + 1] = lam[20 + 2 * g];
+      S.s[O(LAMBDA) + 3 * g + 2] = lam[21 + 2 * g];
+    }
+  }
   // ---------------- velocity update, Bullet coordinate-velocity clamp, semi-implicit Euler ----------------
   // lane l owns DOF l (v0) and, for l < 2, DOF 16 + l (v1); the new coordinates are written by the owning lane
   float v0, v1;
@@ -843,10 +831,8 @@ __device__ static int physics_substep(const KParams& P, Shared& S, const LegCons
     const int k0 = lane < 18 ? lane : 0;
     auto add_row = [&](auto rc) __attribute__((always_inline)) {
       constexpr int r = decltype(rc)::value;
-      constexpr bool inB = r >= 4 && r < 16;
-      const float lr = bcast_lane<inB ? r : (r < 4 ? r : r - 12)>(inB ? B.lam : A.lam, sub);
-      du0 += S.ph.sub.W[r][k0] * lr;
-      if (kLanes < 18) du1 += S.ph.sub.W[r][k1] * lr;
+      du0 += S.ph.sub.W[r][k0] * lam[r];
+      if (kLanes < 18) du1 += S.ph.sub.W[r][k1] * lam[r];
     };
     static_for<0, 4>(add_row);
     if (anyB) {
