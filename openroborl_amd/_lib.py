@@ -43,7 +43,11 @@ def build(force=False, verbose=False):
     """Compile the HIP kernels + C-ABI for gfx950 into the in-tree shared library."""
     if not force and not needs_build():
         return LIB_PATH
-    cmd = [HIPCC] + HIPCC_FLAGS + ["-o", LIB_PATH, SRC]
+    flags = list(HIPCC_FLAGS)
+    if os.environ.get("ORR_LANES_PER_ROBOT", "16") != "16":
+        # tuning builds with wider lane groups: this LLVM's register allocator crashes on them under iterative-ilp
+        flags = [f for f in flags if f not in ("-mllvm", "-amdgpu-sched-strategy=iterative-ilp")]
+    cmd = [HIPCC] + flags + ["-o", LIB_PATH, SRC]
     for var in ("ORR_WAVES_PER_EU", "ORR_LANES_PER_ROBOT"):      # tuning experiments only
         if os.environ.get(var):
             cmd.insert(-3, "-D%s=%d" % (var, int(os.environ[var])))
