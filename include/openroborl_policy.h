@@ -1,0 +1,61 @@
+/* openroborl_policy.h -- C-ABI of the fused policy / value forward pass ("policy inference
+ * in the loop on device").
+ *
+ * Replaces, for all N robots of a shard in ONE launch, what the reference does robot by robot with batch 1:
+ *   PPOImitation runner: `policy.step(ob.reshape(-1, *ob.shape))` per robot   (agents/imitation_runners.py:88-92)
+ *   ImitationPolicy: actor 160 -> 512 -> 256 -> 12 and critic 160 -> 512 -> 256 -> 1, ReLU (run.py:101-105;
+ *   agents/imitation_policies.py:44-51), fixed-std diagonal Gaussian, action = mean + std * N(0, 1)
+ *   (agents/imitation_policies.py:96-107), clipped to the action bounds by the runner (imitation_runners.py:140-143).
+ *
+ * Arithmetic: f32 inputs, f32 accumulation on the matrix cores (v_mfma_f32_16x16x4_f32: bit-for-bit a k-ordered fmaf
+ * chain), i.e. the precision of the reference's float32 TensorFlow graph.  All pointers are device pointers; calls are
+ * asynchronous on the caller's stream; return 0 or a negative code with text in orr_last_error() (openroborl_hip.h).
+ */
+#ifndef OPENROBORL_POLICY_H
+#define OPENROBORL_POLICY_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORR_POLICY_OBS_DIM 160
+#define ORR_POLICY_H0 512
+#define ORR_POLICY_H1 256
+#define ORR_POLICY_ACT_DIM 12
+
+/* Number of floats of the packed ("fragment-major") image of a K x N weight matrix: N is padded to a multiple of 16,
+ * K must be a multiple of 16. */
+int64_t orr_policy_packed_size(int32_t k, int32_t n);
+
+/* Repack a row-major [K][N] float32 weight matrix (the stable-baselines `model/<net>_fc<i>/w:0` layout, fan_in x fan_out)
+ * into the layout the forward kernel streams: for output-column tile nt (16 columns), k-group kg (16 rows), lane l, j < 4:
+ *   out[((nt * K/16 + kg) * 64 + l) * 4 + j] = W[16 kg + 4 j + (l >> 4)][16 nt + (l & 15)]      (0 beyond column N)
+ * so that one 16-byte load per lane yields its B operands of four consecutive MFMA k-steps. */
+int32_t orr_policy_pack(const float* w_dev, int32_t k, int32_t n, float* out_dev, void* stream);
+
+typedef struct orr_policy_net {
+  /* packed weights (orr_policy_pack) and plain biases of the actor ("pi") and the critic ("vf") */
+  const float* w0_pi; const float* b0_pi;   /* 160 x 512 */
+  const float* w1_pi; const float* b1_pi;   /* 512 x 256 */
+  const float* w2_pi; const float* b2_pi;   /* 256 x 12  (bias: 12 floats) */
+  const float* w0_vf; const float* b0_vf;   /* 160 x 512 */
+  const float* w1_vf; const float* b1_vf;   /* 512 x 256 */
+  const float* w2_vf; const float* b2_vf;   /* 256 x 1   (bias: 1 float) */
+} orr_policy_net;
+
+/* One forward pass for n robots.
+ *   obs      [n][160]  observation (the env's obs tensor)
+ *   noise    [n][12]   standard normal samples, or NULL for the deterministic action (mean)
+ *   action   [n][12]   clip(mean + std * noise, -clip, +clip)    -> what env.step() takes
+ *   raw      [n][12]   mean + std * noise (unclipped; what the learner's log-probability uses), may be NULL
+ *   value    [n]       critic output, may be NULL
+ *   mean     [n][12]   actor output, may be NULL */
+int32_t orr_policy_forward(const orr_policy_net* net, const float* obs, int32_t n, const float* noise, float std, float clip,
+                           float* action, float* raw, float* value, float* mean, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -12,8 +12,10 @@ from . import _abi
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(PKG_DIR, "csrc", "orr_kernels.hip")
-DEPS = [SRC, os.path.join(PKG_DIR, "csrc", "orr_device.h"),
-        os.path.join(os.path.dirname(PKG_DIR), "include", "openroborl_hip.h")]
+SRC_POLICY = os.path.join(PKG_DIR, "csrc", "orr_policy.hip")
+DEPS = [SRC, SRC_POLICY, os.path.join(PKG_DIR, "csrc", "orr_device.h"),
+        os.path.join(os.path.dirname(PKG_DIR), "include", "openroborl_hip.h"),
+        os.path.join(os.path.dirname(PKG_DIR), "include", "openroborl_policy.h")]
 LIB_PATH = os.path.join(PKG_DIR, "libopenroborl_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
@@ -29,6 +31,7 @@ EXPORTS = [
     "orr_layout_offset", "orr_layout_size", "orr_layout_is_int", "orr_sizeof_config", "orr_sizeof_model",
     "orr_create", "orr_destroy", "orr_set_model", "orr_set_motion", "orr_bind", "orr_reset", "orr_step",
     "orr_time_steps",
+    "orr_policy_packed_size", "orr_policy_pack", "orr_policy_forward",
 ]
 
 
@@ -39,24 +42,35 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in DEPS if os.path.exists(d))
 
 
-def build(force=False, verbose=False):
-    """Compile the HIP kernels + C-ABI for gfx950 into the in-tree shared library."""
-    if not force and not needs_build():
-        return LIB_PATH
-    flags = list(HIPCC_FLAGS)
+def build(force=False, verbose=False, out_path=None, extra_flags=()):
+    """Compile the HIP kernels + C-ABI for gfx950 into the in-tree shared library (or `out_path`, with `extra_flags`
+    for the env kernels: development builds such as tools/phase_cycles.py)."""
+    if out_path is None:
+        if not force and not needs_build():
+            return LIB_PATH
+        out_path = LIB_PATH
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"] + ["-c"]
     if os.environ.get("ORR_LANES_PER_ROBOT", "16") != "16":
         # tuning builds with wider lane groups: this LLVM's register allocator crashes on them under iterative-ilp
         flags = [f for f in flags if f not in ("-mllvm", "-amdgpu-sched-strategy=iterative-ilp")]
-    cmd = [HIPCC] + flags + ["-o", LIB_PATH, SRC]
     for var in ("ORR_WAVES_PER_EU", "ORR_LANES_PER_ROBOT"):      # tuning experiments only
         if os.environ.get(var):
-            cmd.insert(-3, "-D%s=%d" % (var, int(os.environ[var])))
+            flags.append("-D%s=%d" % (var, int(os.environ[var])))
     for d in os.environ.get("ORR_EXTRA_DEFS", "").split():
-        cmd.insert(-3, "-D" + d)
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    return LIB_PATH
+        flags.append("-D" + d)
+    flags += list(extra_flags)
+    tag = "" if out_path == LIB_PATH else "." + os.path.basename(out_path)
+    obj_env = os.path.join(PKG_DIR, "csrc", "orr_kernels%s.o" % tag)
+    obj_pol = os.path.join(PKG_DIR, "csrc", "orr_policy%s.o" % tag)
+    cmds = [[HIPCC] + flags + ["-o", obj_env, SRC],
+            # the policy forward pass (matrix cores) is its own translation unit with the compiler's default scheduling
+            [HIPCC, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-c", "-o", obj_pol, SRC_POLICY],
+            [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out_path, obj_env, obj_pol]]
+    for cmd in cmds:
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return out_path
 
 
 _lib = None
@@ -95,6 +109,13 @@ def load():
     L.orr_time_steps.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int32, C.POINTER(C.c_float)]
     L.orr_sizeof_config.restype = C.c_int32
     L.orr_sizeof_model.restype = C.c_int32
+    # include/openroborl_policy.h
+    L.orr_policy_packed_size.restype = C.c_int64
+    L.orr_policy_packed_size.argtypes = [C.c_int32, C.c_int32]
+    L.orr_policy_pack.restype = C.c_int32
+    L.orr_policy_pack.argtypes = [vp, C.c_int32, C.c_int32, vp, vp]
+    L.orr_policy_forward.restype = C.c_int32
+    L.orr_policy_forward.argtypes = [C.POINTER(_abi.OrrPolicyNet), vp, C.c_int32, vp, C.c_float, C.c_float, vp, vp, vp, vp, vp]
     if L.orr_abi_version() != _abi.ABI_VERSION:
         raise RuntimeError("libopenroborl_hip.so ABI version mismatch")
     if L.orr_sizeof_config() != C.sizeof(_abi.OrrConfig) or L.orr_sizeof_model() != C.sizeof(_abi.OrrModel):

@@ -1567,11 +1567,13 @@ struct orr_handle {
 };
 
 static thread_local char g_err[512] = "";
-static int fail(int code, const char* msg, hipError_t e = hipSuccess) {
+// records the message returned by orr_last_error(); shared with orr_policy.hip (same library)
+__attribute__((visibility("hidden"))) int orr_fail(int code, const char* msg, hipError_t e) {
   if (e != hipSuccess) snprintf(g_err, sizeof(g_err), "%s: %s", msg, hipGetErrorString(e));
   else snprintf(g_err, sizeof(g_err), "%s", msg);
   return code;
 }
+static int fail(int code, const char* msg, hipError_t e = hipSuccess) { return orr_fail(code, msg, e); }
 #define HIPCHK(call, msg)                         \
   do {                                            \
     hipError_t e_ = (call);                       \

@@ -1,0 +1,78 @@
+"""Fused policy / value forward pass (csrc/orr_policy.hip through the C-ABI) against a plain PyTorch float32 reference
+of the same MLPs, and against the golden outputs of the reference's shipped policy.  GPU only."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _torch_forward(p, obs):
+    import torch
+    hi = torch.float64          # reference in float64: the kernel and torch-f32 are both compared against it
+
+    @torch.no_grad()
+    def mlp(net):
+        h = torch.relu(obs.to(hi) @ p["model/%s_fc0/w:0" % net].to(hi) + p["model/%s_fc0/b:0" % net].to(hi))
+        h = torch.relu(h @ p["model/%s_fc1/w:0" % net].to(hi) + p["model/%s_fc1/b:0" % net].to(hi))
+        return h @ p["model/%s/w:0" % net].to(hi) + p["model/%s/b:0" % net].to(hi)
+    return mlp("pi"), mlp("vf")[:, 0]
+
+
+@pytest.mark.parametrize("n", [4096, 1000, 16, 3])
+def test_fused_forward_matches_torch(n):
+    import torch
+    from openroborl_amd import policy_hip, ppo
+    dev = torch.device("cuda", 0)
+    model = ppo.ActorCritic(dev, seed=3)
+    with torch.no_grad():
+        for k, v in model.p.items():          # non-trivial biases and a head that is not tiny
+            if k.endswith("/b:0"):
+                v.copy_(torch.randn(v.shape, generator=torch.Generator().manual_seed(len(k))).to(dev) * 0.1)
+        model.p["model/pi/w:0"].mul_(30.0)
+    fused = policy_hip.FusedActorCritic(model.p, dev, std=0.125)
+    g = torch.Generator(device=dev).manual_seed(n)
+    obs = torch.randn(n, 160, generator=g, device=dev) * 2.0
+    noise = torch.randn(n, 12, generator=g, device=dev)
+    act, raw, val, mean = fused.forward(obs, noise, want_mean=True)
+    mu64, v64 = _torch_forward(model.p, obs)
+    scale = float(mu64.abs().max())
+    # f32 MFMA = k-ordered fmaf chain: error ~1e-7 * sum |a b| (tolerance: 2e-5 of the output scale)
+    assert float((mean.double() - mu64).abs().max()) < 2e-5 * max(1.0, scale)
+    assert float((val.double() - v64).abs().max()) < 2e-5 * max(1.0, float(v64.abs().max()))
+    np.testing.assert_allclose(raw.cpu().numpy(), (mean + 0.125 * noise).cpu().numpy(), atol=1e-6)
+    np.testing.assert_allclose(act.cpu().numpy(), np.clip(raw.cpu().numpy(), -2 * math.pi, 2 * math.pi), atol=0)
+    # deterministic mode
+    act_d, raw_d, _, _ = fused.forward(obs, None)
+    np.testing.assert_allclose(raw_d.cpu().numpy(), mean.cpu().numpy(), atol=0)
+    # and no worse than torch's own float32 path
+    with torch.no_grad():
+        mu32 = model.mean(obs)
+    assert float((mean.double() - mu64).abs().max()) <= 4.0 * float((mu32.double() - mu64).abs().max()) + 1e-6
+
+
+def test_fused_forward_refresh_and_shipped_policy():
+    """The reference's shipped laikago_pace actor (tests/golden/policy_laikago_pace.npz, weights taken from
+    policies/laikago_pace.zip) through the fused kernel vs float64; then refresh() after a parameter change."""
+    import torch
+    from openroborl_amd import policy as pol, policy_hip, ppo
+    dev = torch.device("cuda", 0)
+    gold = np.load(os.path.join(GOLD, "policy_laikago_pace.npz"))
+    params = {pol._norm_key(k): gold[k] for k in gold.files}
+    model = ppo.ActorCritic(dev, params=params)
+    fused = policy_hip.FusedActorCritic(model.p, dev, std=0.125)
+    g = torch.Generator(device=dev).manual_seed(5)
+    obs = (torch.rand(2048, 160, generator=g, device=dev) * 2.0 - 1.0) * 3.0
+    _, raw, val, _ = fused.forward(obs, None)
+    mu64, v64 = _torch_forward(model.p, obs)
+    assert float((raw.double() - mu64).abs().max()) < 2e-5 * max(1.0, float(mu64.abs().max()))
+    assert float((val.double() - v64).abs().max()) < 2e-5 * max(1.0, float(v64.abs().max()))
+    with torch.no_grad():
+        model.p["model/pi/b:0"].add_(1.0)
+    fused.refresh()
+    _, raw2, _, _ = fused.forward(obs, None)
+    np.testing.assert_allclose(raw2.cpu().numpy(), raw.cpu().numpy() + 1.0, atol=1e-5)

@@ -11,9 +11,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 LIB = os.path.join(ROOT, "openroborl_amd", "libopenroborl_phase_timers.so")
-from openroborl_amd import _lib as _build  # noqa: E402  (flags only; the library is loaded below)
-subprocess.check_call([_build.HIPCC] + _build.HIPCC_FLAGS + ["-DORR_PHASE_TIMERS", "-o", LIB,
-                       os.path.join(ROOT, "openroborl_amd", "csrc", "orr_kernels.hip")])
+from openroborl_amd import _lib as _build  # noqa: E402  (build only; the library is loaded below)
+_build.build(out_path=LIB, extra_flags=["-DORR_PHASE_TIMERS"])
 os.environ["ORR_LIB_PATH"] = LIB
 
 import torch  # noqa: E402
