@@ -62,31 +62,38 @@ __device__ __forceinline__ void mma_group(f32x4 (&acc)[TILES], const float (&a)[
 }
 
 // One layer for this wave: TILES column tiles starting at tile index `nt0` of a packed K x (16 * ntiles) matrix.
-// `act` points at column 0 of the A operand in LDS (row stride `stride`).
-template <int TILES, int K>
+// `act` points at column 0 of the A operand in LDS (row stride `stride`).  The weight stream is software-pipelined
+// DEPTH k-groups deep (a k-group = 4 MFMA k-steps = one 16-byte load per lane and tile); the A fragments of the next
+// k-group are read from LDS before the MFMAs of the current one.  K / 16 must be a multiple of DEPTH.
+template <int TILES, int K, int DEPTH>
 __device__ __forceinline__ void layer(f32x4 (&acc)[TILES], const float* __restrict__ wp, int nt0, const float* act, int stride, int lane) {
   constexpr int KG = K / 16;
-  const f32x4* w4 = reinterpret_cast<const f32x4*>(wp);
-  const int row = lane & 15, kq = lane >> 4;
-  f32x4 b0[TILES], b1[TILES];
+  static_assert(KG % DEPTH == 0, "k-groups must be a multiple of the pipeline depth");
+  const f32x4* w4 = reinterpret_cast<const f32x4*>(wp) + (size_t)nt0 * KG * 64 + lane;   // tile t, k-group g: w4[(t * KG + g) * 64]
+  const float* arow = act + (lane & 15) * stride + (lane >> 4);                             // k-group g, k-step j: arow[16 g + 4 j]
+  f32x4 b[DEPTH][TILES];
+  float a[2][4];
 #pragma unroll
-  for (int t = 0; t < TILES; t++) b0[t] = w4[((size_t)(nt0 + t) * KG + 0) * 64 + lane];
+  for (int d = 0; d < DEPTH - 1; d++)
+#pragma unroll
+    for (int t = 0; t < TILES; t++) b[d][t] = w4[(t * KG + d) * 64];
+#pragma unroll
+  for (int j = 0; j < 4; j++) a[0][j] = arow[4 * j];
 #pragma unroll 1
-  for (int kg = 0; kg < KG; kg += 2) {
-    // prefetch k-group kg + 1 while computing kg, and kg + 2 while computing kg + 1 (KG is even for every layer here)
+  for (int g0 = 0; g0 < KG; g0 += DEPTH) {
 #pragma unroll
-    for (int t = 0; t < TILES; t++) b1[t] = w4[((size_t)(nt0 + t) * KG + kg + 1) * 64 + lane];
-    float a[4];
+    for (int d = 0; d < DEPTH; d++) {
+      const int g = g0 + d;
+      if (g + DEPTH - 1 < KG) {
 #pragma unroll
-    for (int j = 0; j < 4; j++) a[j] = act[row * stride + 16 * kg + 4 * j + kq];
-    mma_group<TILES>(acc, a, b0);
-    if (kg + 2 < KG) {
+        for (int t = 0; t < TILES; t++) b[(d + DEPTH - 1) % DEPTH][t] = w4[(t * KG + g + DEPTH - 1) * 64];
+      }
+      if (g + 1 < KG) {
 #pragma unroll
-      for (int t = 0; t < TILES; t++) b0[t] = w4[((size_t)(nt0 + t) * KG + kg + 2) * 64 + lane];
+        for (int j = 0; j < 4; j++) a[(d + 1) & 1][j] = arow[16 * (g + 1) + 4 * j];
+      }
+      mma_group<TILES>(acc, a[d & 1], b[d]);
     }
-#pragma unroll
-    for (int j = 0; j < 4; j++) a[j] = act[row * stride + 16 * (kg + 1) + 4 * j + kq];
-    mma_group<TILES>(acc, a, b1);
   }
 }
 
@@ -119,11 +126,11 @@ __global__ __launch_bounds__(256) void forward_kernel(Params P) {
     f32x4 acc[8];
 #pragma unroll
     for (int t = 0; t < 8; t++) acc[t] = f32x4{0, 0, 0, 0};
-    layer<8, kObs>(acc, P.net.w0_pi, 8 * wave, s_obs, kObsStride, lane);
+    layer<8, kObs, 2>(acc, P.net.w0_pi, 8 * wave, s_obs, kObsStride, lane);
     store_relu<8>(acc, P.net.b0_pi, 8 * wave, s_h0, kH0Stride, lane);
 #pragma unroll
     for (int t = 0; t < 8; t++) acc[t] = f32x4{0, 0, 0, 0};
-    layer<8, kObs>(acc, P.net.w0_vf, 8 * wave, s_obs, kObsStride, lane);
+    layer<8, kObs, 2>(acc, P.net.w0_vf, 8 * wave, s_obs, kObsStride, lane);
     store_relu<8>(acc, P.net.b0_vf, 8 * wave, s_h0 + kH0, kH0Stride, lane);
   }
   __syncthreads();
@@ -132,11 +139,11 @@ __global__ __launch_bounds__(256) void forward_kernel(Params P) {
     f32x4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) acc[t] = f32x4{0, 0, 0, 0};
-    layer<4, kH0>(acc, P.net.w1_pi, 4 * wave, s_h0, kH0Stride, lane);
+    layer<4, kH0, 4>(acc, P.net.w1_pi, 4 * wave, s_h0, kH0Stride, lane);
     store_relu<4>(acc, P.net.b1_pi, 4 * wave, s_h1, kH1Stride, lane);
 #pragma unroll
     for (int t = 0; t < 4; t++) acc[t] = f32x4{0, 0, 0, 0};
-    layer<4, kH0>(acc, P.net.w1_vf, 4 * wave, s_h0 + kH0, kH0Stride, lane);
+    layer<4, kH0, 4>(acc, P.net.w1_vf, 4 * wave, s_h0 + kH0, kH0Stride, lane);
     store_relu<4>(acc, P.net.b1_vf, 4 * wave, s_h1 + kH1, kH1Stride, lane);
   }
   __syncthreads();
@@ -145,7 +152,7 @@ __global__ __launch_bounds__(256) void forward_kernel(Params P) {
   f32x4 acc[1] = {f32x4{0, 0, 0, 0}};
   const int col = lane & 15, r0 = 4 * (lane >> 4);
   if (wave == 0) {
-    layer<1, kH1>(acc, P.net.w2_pi, 0, s_h1, kH1Stride, lane);
+    layer<1, kH1, 4>(acc, P.net.w2_pi, 0, s_h1, kH1Stride, lane);
     if (col < kAct) {
       const float b = P.net.b2_pi[col];
 #pragma unroll
@@ -162,7 +169,7 @@ __global__ __launch_bounds__(256) void forward_kernel(Params P) {
       }
     }
   } else {
-    layer<1, kH1>(acc, P.net.w2_vf, 0, s_h1 + kH1, kH1Stride, lane);
+    layer<1, kH1, 4>(acc, P.net.w2_vf, 0, s_h1 + kH1, kH1Stride, lane);
     if (col == 0 && P.value) {
       const float b = P.net.b2_vf[0];
 #pragma unroll

@@ -62,9 +62,10 @@ class FusedActorCritic(object):
                 self.biases[field] = w.clone()        # own copy: stays valid while the optimiser updates the original
                 setattr(self.net, field, self.biases[field].data_ptr())
 
-    def forward(self, obs, noise=None, want_mean=False):
+    def forward(self, obs, noise=None, want_mean=False, out_action=None, out_raw=None, out_value=None):
         """obs [N,160] float32 on the device; noise [N,12] standard normal or None (deterministic).
-        Returns (clipped action [N,12], raw action [N,12], value [N], mean [N,12] or None)."""
+        Returns (clipped action [N,12], raw action [N,12], value [N], mean [N,12] or None); the out_* tensors
+        (contiguous float32 of those shapes, e.g. rows of a rollout buffer) are written in place when given."""
         t = self.torch
         if obs.dtype != t.float32 or not obs.is_contiguous() or obs.device != self.device or obs.dim() != 2 or obs.shape[1] != 160:
             raise ValueError("obs must be a contiguous float32 [N,160] tensor on %s" % (self.device,))
@@ -72,9 +73,13 @@ class FusedActorCritic(object):
         if noise is not None and (noise.dtype != t.float32 or not noise.is_contiguous() or tuple(noise.shape) != (n, 12)
                                   or noise.device != self.device):
             raise ValueError("noise must be a contiguous float32 [N,12] tensor on the same device")
-        act = t.empty(n, 12, dtype=t.float32, device=self.device)
-        raw = t.empty(n, 12, dtype=t.float32, device=self.device)
-        val = t.empty(n, dtype=t.float32, device=self.device)
+        def out(x, shape):
+            if x is None:
+                return t.empty(shape, dtype=t.float32, device=self.device)
+            if x.dtype != t.float32 or not x.is_contiguous() or tuple(x.shape) != shape or x.device != self.device:
+                raise ValueError("output tensor must be contiguous float32 %s on %s" % (shape, self.device))
+            return x
+        act, raw, val = out(out_action, (n, 12)), out(out_raw, (n, 12)), out(out_value, (n,))
         mean = t.empty(n, 12, dtype=t.float32, device=self.device) if want_mean else None
         _lib.check(self.L.orr_policy_forward(C.byref(self.net), obs.data_ptr(), int(n), noise.data_ptr() if noise is not None else None,
                                              self.std, self.clip, act.data_ptr(), raw.data_ptr(), val.data_ptr(),

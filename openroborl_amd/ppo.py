@@ -37,6 +37,19 @@ class ActorCritic(object):
                     self.p[k].data.copy_(torch.as_tensor(np.asarray(v), dtype=torch.float32))
         for v in self.p.values():
             v.requires_grad_(True)
+        self.fused = None          # policy_hip.FusedActorCritic once enable_fused() was called
+        self._fused_dirty = True
+
+    def enable_fused(self):
+        """Route act() through the fused matrix-core forward pass (csrc/orr_policy.hip).  The packed weight copy is
+        refreshed lazily after mark_updated() (the learner calls it after every optimiser step)."""
+        from . import policy_hip
+        self.fused = policy_hip.FusedActorCritic(self.p, self.device, std=self.std)
+        self._fused_dirty = False
+        return self
+
+    def mark_updated(self):
+        self._fused_dirty = True
 
     def _init(self, name, fan_in, fan_out, g, gain):
         t = self.torch
@@ -59,11 +72,22 @@ class ActorCritic(object):
     def value(self, obs):
         return self._mlp("vf", obs)[:, 0]
 
-    def act(self, obs, deterministic=False, generator=None):
+    def act(self, obs, deterministic=False, generator=None, noise=None, out_raw=None, out_value=None):
+        """-> (clipped action, raw action, value).  `noise` ([N,12] standard normal) overrides the generator."""
         t = self.torch
+        if self.fused is not None:
+            if self._fused_dirty:
+                self.fused.refresh()
+                self._fused_dirty = False
+            if noise is None and not deterministic:
+                noise = t.randn((obs.shape[0], 12), device=obs.device, generator=generator)
+            a, raw, v, _ = self.fused.forward(obs, None if deterministic else noise, out_raw=out_raw, out_value=out_value)
+            return a, raw, v
         with t.no_grad():
             mu = self.mean(obs)
-            a = mu if deterministic else mu + self.std * t.randn(mu.shape, device=mu.device, generator=generator)
+            if noise is None and not deterministic:
+                noise = t.randn(mu.shape, device=mu.device, generator=generator)
+            a = mu if deterministic else mu + self.std * noise
             return t.clamp(a, -2.0 * math.pi, 2.0 * math.pi), a, self.value(obs)
 
     def log_prob(self, obs, actions):
@@ -123,5 +147,7 @@ class PPO(object):
                 loss.backward()
                 self._allreduce_grads()
                 self.opt.step()
+                if hasattr(self.model, "mark_updated"):
+                    self.model.mark_updated()
                 stats.append((float(surr.detach()), float(vf.detach())))
         return np.mean(stats, axis=0)

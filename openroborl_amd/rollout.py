@@ -28,11 +28,20 @@ def collect_rollout(env, policy, horizon, obs=None, deterministic=False, generat
         "rewards": t.empty((horizon, n), device=dev), "dones": t.empty((horizon, n), dtype=t.bool, device=dev),
         "vpred": t.empty((horizon, n), device=dev),
     }
+    fused = getattr(policy, "fused", None) is not None
+    noise = None
+    if fused and not deterministic:   # one launch for the whole segment's exploration noise
+        noise = t.randn((horizon, n, 12), device=dev, generator=generator)
     for k in range(horizon):
-        clipped, raw, v = policy.act(obs, deterministic=deterministic, generator=generator)
-        buf["obs"][k].copy_(obs)
-        buf["actions"][k].copy_(raw)
-        buf["vpred"][k].copy_(v)
+        if fused:   # one fused launch writes the raw action and the value straight into the buffers
+            clipped, _, _ = policy.act(obs, deterministic=deterministic, noise=None if noise is None else noise[k],
+                                       out_raw=buf["actions"][k], out_value=buf["vpred"][k])
+            buf["obs"][k].copy_(obs)
+        else:
+            clipped, raw, v = policy.act(obs, deterministic=deterministic, generator=generator)
+            buf["obs"][k].copy_(obs)
+            buf["actions"][k].copy_(raw)
+            buf["vpred"][k].copy_(v)
         obs, rew, done, _ = env.step(clipped.contiguous())
         buf["rewards"][k].copy_(rew)
         buf["dones"][k].copy_(done.bool())

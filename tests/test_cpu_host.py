@@ -69,7 +69,7 @@ def test_yaml_schema_and_config():
 
 def test_library_loads_and_exports_every_declared_symbol():
     L = _lib.load()
-    hdr = open(os.path.join(ROOT, "include", "openroborl_hip.h")).read()
+    hdr = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("openroborl_hip.h", "openroborl_policy.h"))
     declared = set(re.findall(r"\b(orr_[a-z_]+)\s*\(", hdr))
     declared -= {"orr_handle"}
     assert declared, "no declarations found"

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--log", default="")
     ap.add_argument("--save", default="", help="write the trained weights as a stable-baselines style zip")
+    ap.add_argument("--torch-policy", action="store_true", help="rollout policy through plain torch instead of the fused HIP kernel")
     args = ap.parse_args()
 
     import torch
@@ -42,6 +43,8 @@ def main():
                           device=dev, num_procs=world, robot_index_offset=rank * args.num_robot)
     params = pol.load_parameters(args.model_file) if args.model_file else None     # run.py:220-221
     model = ppo.ActorCritic(dev, params=params, seed=args.seed)                     # same seed -> identical replicas
+    if not args.torch_policy:
+        model.enable_fused()
     learner = ppo.PPO(model, lr=args.lr, minibatch=args.minibatch)
     gen = torch.Generator(device=dev)
     gen.manual_seed(args.seed * 1000 + rank)
