@@ -61,10 +61,10 @@ class ActorCritic(object):
         return [self.p[k] for k in sorted(self.p)]
 
     def _mlp(self, net, x):
-        t = self.torch
-        h = t.relu(x @ self.p["model/%s_fc0/w:0" % net] + self.p["model/%s_fc0/b:0" % net])
-        h = t.relu(h @ self.p["model/%s_fc1/w:0" % net] + self.p["model/%s_fc1/b:0" % net])
-        return h @ self.p["model/%s/w:0" % net] + self.p["model/%s/b:0" % net]
+        t = self.torch   # addmm: the bias rides in the GEMM epilogue (one kernel per layer instead of two)
+        h = t.relu(t.addmm(self.p["model/%s_fc0/b:0" % net], x, self.p["model/%s_fc0/w:0" % net]))
+        h = t.relu(t.addmm(self.p["model/%s_fc1/b:0" % net], h, self.p["model/%s_fc1/w:0" % net]))
+        return t.addmm(self.p["model/%s/b:0" % net], h, self.p["model/%s/w:0" % net])
 
     def mean(self, obs):
         return self._mlp("pi", obs)
@@ -135,13 +135,15 @@ class PPO(object):
         stats = []
         for _ in range(epochs):
             perm = t.randperm(B, device=obs.device, generator=generator)
+            # one gather per epoch; the minibatches are then contiguous views
+            obs_p, act_p, adv_p, ret_p, old_p = obs[perm], actions[perm], adv[perm], ret[perm], old_logp[perm]
             for s in range(0, B, self.minibatch):
-                idx = perm[s:s + self.minibatch]
-                logp = self.model.log_prob(obs[idx], actions[idx])
-                ratio = t.exp(logp - old_logp[idx])
-                a = adv[idx]
+                e = s + self.minibatch
+                logp = self.model.log_prob(obs_p[s:e], act_p[s:e])
+                ratio = t.exp(logp - old_p[s:e])
+                a = adv_p[s:e]
                 surr = -t.min(ratio * a, t.clamp(ratio, 1.0 - self.clip, 1.0 + self.clip) * a).mean()
-                vf = ((self.model.value(obs[idx]) - ret[idx]) ** 2).mean()
+                vf = ((self.model.value(obs_p[s:e]) - ret_p[s:e]) ** 2).mean()
                 loss = surr + self.vf_coef * vf
                 self.opt.zero_grad(set_to_none=True)
                 loss.backward()

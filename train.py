@@ -30,12 +30,15 @@ def main():
     ap.add_argument("--log", default="")
     ap.add_argument("--save", default="", help="write the trained weights as a stable-baselines style zip")
     ap.add_argument("--torch-policy", action="store_true", help="rollout policy through plain torch instead of the fused HIP kernel")
+    ap.add_argument("--tune-gemms", action="store_true", help="let PyTorch's TunableOp pick the learner's GEMM kernels (+7 %% samples/s after ~10 s of tuning)")
     args = ap.parse_args()
 
     import torch
     from openroborl_amd import dist as odist, policy as pol, ppo, rollout
     from openroborl_amd.env import VecQuadrupedEnv
 
+    if args.tune_gemms:
+        torch.cuda.tunable.enable(True)
     rank, world, local = odist.init_from_env()
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
