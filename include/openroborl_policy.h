@@ -55,6 +55,16 @@ typedef struct orr_policy_net {
 int32_t orr_policy_forward(const orr_policy_net* net, const float* obs, int32_t n, const float* noise, float std, float clip,
                            float* action, float* raw, float* value, float* mean, void* stream);
 
+/* Per-robot GAE(lambda) over a [T][N] rollout segment + per-robot advantage standardisation, one launch
+ * (reference: add_vtarg_and_adv, agents/ppo_imitation.py:68-93, and the per-robot normalisation :329-338; device
+ * layout and the deliberate use of each robot's own done flags: openroborl_amd/rollout.py).
+ *   rewards, vpred [T][N] float32; dones [T][N] uint8 (1 = the episode ended at that step);
+ *   bootstrap [N] value after the last step (NULL = 0, the reference's choice)
+ *   adv [T][N]: advantages, standardised per robot ((a - mean) / (population std + eps)) when normalize != 0
+ *   ret [T][N]: TD(lambda) targets = raw advantage + vpred */
+int32_t orr_gae(const float* rewards, const float* vpred, const uint8_t* dones, const float* bootstrap, int32_t t, int32_t n,
+                float gamma, float lam, int32_t normalize, float eps, float* adv, float* ret, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

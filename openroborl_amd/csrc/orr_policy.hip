@@ -181,6 +181,31 @@ __global__ __launch_bounds__(256) void forward_kernel(Params P) {
   }
 }
 
+// One thread per robot: backward recursion over the segment, then mean / variance / standardisation of its own T values.
+__global__ void gae_kernel(const float* __restrict__ rewards, const float* __restrict__ vpred, const uint8_t* __restrict__ dones,
+                           const float* __restrict__ bootstrap, int T, int N, float gamma, float lam, int normalize, float eps,
+                           float* __restrict__ adv, float* __restrict__ ret) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float last = 0.0f, next_v = bootstrap ? bootstrap[n] : 0.0f, sum = 0.0f;
+  for (int k = T - 1; k >= 0; k--) {
+    const size_t o = (size_t)k * N + n;
+    const float nonterminal = dones[o] ? 0.0f : 1.0f, v = vpred[o];
+    const float delta = rewards[o] + gamma * next_v * nonterminal - v;
+    last = delta + gamma * lam * nonterminal * last;
+    adv[o] = last;
+    ret[o] = last + v;
+    sum += last;
+    next_v = v;
+  }
+  if (!normalize) return;
+  const float mean = sum / (float)T;
+  float var = 0.0f;
+  for (int k = 0; k < T; k++) { const float d = adv[(size_t)k * N + n] - mean; var += d * d; }
+  const float inv = 1.0f / (sqrtf(var / (float)T) + eps);
+  for (int k = 0; k < T; k++) { const size_t o = (size_t)k * N + n; adv[o] = (adv[o] - mean) * inv; }
+}
+
 }  // namespace
 
 extern "C" {
@@ -212,6 +237,17 @@ int32_t orr_policy_forward(const orr_policy_net* net, const float* obs, int32_t 
   hipLaunchKernelGGL(forward_kernel, dim3((unsigned)((n + kRows - 1) / kRows)), dim3(256), 0, (hipStream_t)stream, P);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return orr_fail(-2, "orr_policy_forward: launch", e);
+  return 0;
+}
+
+int32_t orr_gae(const float* rewards, const float* vpred, const uint8_t* dones, const float* bootstrap, int32_t t, int32_t n,
+                float gamma, float lam, int32_t normalize, float eps, float* adv, float* ret, void* stream) {
+  if (!rewards || !vpred || !dones || !adv || !ret || t <= 0 || n < 0) return orr_fail(-1, "orr_gae: bad argument", hipSuccess);
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(gae_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rewards, vpred, dones, bootstrap,
+                     (int)t, (int)n, gamma, lam, (int)normalize, eps, adv, ret);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return orr_fail(-2, "orr_gae: launch", e);
   return 0;
 }
 

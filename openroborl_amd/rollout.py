@@ -71,3 +71,21 @@ def gae(rewards, vpred, dones, gamma=0.95, lam=0.95, bootstrap=None):
 def normalize_per_robot(adv, eps=0.0):
     """ppo_imitation.py:329-338: (a - mean) / std over each robot's own samples (population std, like numpy)."""
     return (adv - adv.mean(dim=0, keepdim=True)) / (adv.std(dim=0, unbiased=False, keepdim=True) + eps)
+
+
+def gae_fused(rewards, vpred, dones, gamma=0.95, lam=0.95, bootstrap=None, normalize=True, eps=0.0):
+    """gae() + normalize_per_robot() in one HIP launch (include/openroborl_policy.h: orr_gae).  GPU tensors only;
+    returns (advantages [T,N] - standardised per robot when `normalize` -, TD(lambda) targets [T,N])."""
+    import ctypes as C
+    import torch
+    from . import _lib
+    L = _lib.load()
+    T, n = rewards.shape
+    rewards, vpred = rewards.contiguous(), vpred.contiguous()
+    d8 = dones.to(torch.uint8).contiguous()
+    adv, ret = torch.empty_like(rewards), torch.empty_like(rewards)
+    boot = None if bootstrap is None else bootstrap.to(rewards.dtype).contiguous()
+    stream = C.c_void_p(torch.cuda.current_stream(rewards.device).cuda_stream)
+    _lib.check(L.orr_gae(rewards.data_ptr(), vpred.data_ptr(), d8.data_ptr(), None if boot is None else boot.data_ptr(), int(T), int(n),
+                         float(gamma), float(lam), int(bool(normalize)), float(eps), adv.data_ptr(), ret.data_ptr(), stream), L)
+    return adv, ret

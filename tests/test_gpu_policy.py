@@ -101,3 +101,27 @@ def test_rollout_fused_equals_torch_policy():
     # later steps differ only through the chaotic amplification of that rounding
     np.testing.assert_allclose(a["rewards"].cpu().numpy(), b["rewards"].cpu().numpy(), atol=5e-3)
     assert bool((a["dones"] == b["dones"]).all())
+
+
+@pytest.mark.parametrize("shape", [(32, 4096), (7, 33), (1, 5)])
+def test_fused_gae_matches_torch(shape):
+    """orr_gae (one launch) vs rollout.gae + normalize_per_robot (the plain PyTorch restatement of
+    agents/ppo_imitation.py:68-93,329-338)."""
+    import torch
+    from openroborl_amd import rollout
+    dev = torch.device("cuda", 0)
+    T, n = shape
+    g = torch.Generator(device=dev).manual_seed(T * 1000 + n)
+    rew = torch.rand(T, n, generator=g, device=dev)
+    vp = torch.randn(T, n, generator=g, device=dev)
+    dones = torch.rand(T, n, generator=g, device=dev) < 0.1
+    boot = torch.randn(n, generator=g, device=dev)
+    for bootstrap in (None, boot):
+        a0, r0 = rollout.gae(rew, vp, dones, 0.95, 0.95, bootstrap=bootstrap)
+        a1, r1 = rollout.gae_fused(rew, vp, dones, 0.95, 0.95, bootstrap=bootstrap, normalize=False)
+        np.testing.assert_allclose(a1.cpu().numpy(), a0.cpu().numpy(), rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(r1.cpu().numpy(), r0.cpu().numpy(), rtol=1e-5, atol=1e-5)
+        if T > 1:
+            a2, r2 = rollout.gae_fused(rew, vp, dones, 0.95, 0.95, bootstrap=bootstrap, normalize=True, eps=1e-8)
+            np.testing.assert_allclose(a2.cpu().numpy(), rollout.normalize_per_robot(a0, eps=1e-8).cpu().numpy(), rtol=2e-4, atol=2e-5)
+            np.testing.assert_allclose(r2.cpu().numpy(), r0.cpu().numpy(), rtol=1e-5, atol=1e-5)

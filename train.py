@@ -62,8 +62,7 @@ def main():
             boot = model.value(obs)
         # bootstrap with the critic at the segment end (the reference uses 0 there, imitation_runners.py:98-100;
         # with 32-step segments that bias would dominate)
-        adv, ret = rollout.gae(buf["rewards"], buf["vpred"], buf["dones"], 0.95, 0.95, bootstrap=boot)
-        adv = rollout.normalize_per_robot(adv, eps=1e-8)
+        adv, ret = rollout.gae_fused(buf["rewards"], buf["vpred"], buf["dones"], 0.95, 0.95, bootstrap=boot, normalize=True, eps=1e-8)
         T, n = buf["rewards"].shape
         surr, vf = learner.update(buf["obs"].reshape(T * n, -1), buf["actions"].reshape(T * n, -1), adv.reshape(-1),
                                   ret.reshape(-1), epochs=args.epochs, generator=gen)
