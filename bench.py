@@ -71,8 +71,8 @@ def cpu_baseline(env, seconds_target=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=2000)   # a fresh box needs seconds, not steps, to settle (first run -8 %)
+    ap.add_argument("--steps", type=int, default=3000)
+    ap.add_argument("--warmup", type=int, default=6000)   # the first process on a fresh box runs ~6 % slower for its first seconds
     ap.add_argument("--robots-per-gpu", type=int, default=ROBOTS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
