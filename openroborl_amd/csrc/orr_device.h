@@ -120,6 +120,12 @@ struct LinkCache {  // per movable link, written by the leg lanes (0..3), read b
   float Rw[9];      // link -> world
   float ow[3];      // link origin, world
 };
+struct LegExchange {  // per leg, hand-over between the lanes (parts) of a leg inside leg_dynamics
+  float F[3][6];      // F_k = Ic_k S_k of joint k, written by part k
+  float Hc[3][4];     // Hc[k][i] = S_i . F_k (valid for i <= k)
+  float b[4];         // tau_k - C_k
+  float I[6], h[3], m, f[6];  // composite of the whole leg about O (part 0) and its bias force
+};
 struct LegSolve {   // per leg, written by the leg lanes, read by the row lanes (see leg_dynamics in orr_kernels.hip)
   float T[3][6];    // F H^-1: column k = base wrench (angular; linear, world axes, about the base COM) per unit of joint k
   float Hi[6];      // H^-1 of the leg's 3x3 joint-space inertia (00 11 22 01 02 12)
@@ -148,6 +154,7 @@ struct Shared {
   float Ic[13][6];
   LinkCache lc[12];
   LegSolve leg[4];
+  LegExchange legx[4];
   float Rb[9];                // kinematic base frame -> world
   float IA0inv[36];           // inverse of the base's effective 6x6 inertia (world axes, about the base COM)
   float tau[12];              // joint torques (internal sign convention), joint order

@@ -229,24 +229,33 @@ __device__ __forceinline__ void chol6_solve(const float L[21], const float invdi
   }
 }
 
-// Per-lane constants of the leg this lane works on, loaded once per launch and kept in registers over the 33
-// sub-steps (a lone wave per SIMD cannot hide the LDS round trips of re-reading them every sub-step).
+// Per-lane constants, loaded once per launch and kept in registers over the 33 sub-steps (a lone wave per SIMD cannot
+// hide the LDS round trips of re-reading them every sub-step).  Lane (leg = lane & 3, part = (lane >> 2) & 3) walks the
+// joints 0..min(part, 2) of its leg and owns link `part` (part 3: an idle copy with zero inertia): the chain constants of
+// the joints beyond its own are zeroed, so that walking "through" them is the identity.
 struct LegConst {
-  float r[3][3], com[3][3], m[3], Ic[3][6], jdir[3], joff[3];
+  float r[3][3], jdir[3], joff[3];  // chain: joint origin in the parent frame, internal angle = jdir * (q - joff)
+  float com[3], m, Ic[6];           // own link: COM in the link frame, mass, inertia about the COM (xx yy zz xy xz yz)
 };
-__device__ static void load_leg_const(const Shared& S, int leg, LegConst& K) {
+__device__ static void load_leg_const(const Shared& S, int lane, LegConst& K) {
+  const int leg = lane & 3, part = (lane >> 2) & 3, own = 3 * leg + (part < 3 ? part : 2);
 #pragma unroll
   for (int k = 0; k < 3; k++) {
     const int j = 3 * leg + k;
+    const bool on = k <= part;
 #pragma unroll
-    for (int i = 0; i < 3; i++) { K.r[k][i] = S.m.joint_pos[j][i]; K.com[k][i] = S.m.link_com[j][i]; }
-#pragma unroll
-    for (int i = 0; i < 6; i++) K.Ic[k][i] = S.Ic[j + 1][i];
-    K.m[k] = S.mass[j + 1];
-    K.jdir[k] = S.m.jdir[j];
+    for (int i = 0; i < 3; i++) K.r[k][i] = on ? S.m.joint_pos[j][i] : 0.0f;
+    K.jdir[k] = on ? S.m.jdir[j] : 0.0f;
     K.joff[k] = S.m.joff[j];
   }
+  const bool real = part < 3;
+#pragma unroll
+  for (int i = 0; i < 3; i++) K.com[i] = real ? S.m.link_com[own][i] : 0.0f;
+#pragma unroll
+  for (int i = 0; i < 6; i++) K.Ic[i] = real ? S.Ic[own + 1][i] : 0.0f;
+  K.m = real ? S.mass[own + 1] : 0.0f;
 }
+
 // ================================================================================================
 // Forward dynamics of the floating base + 4 x 3-link legs.
 //
@@ -261,7 +270,10 @@ __device__ static void load_leg_const(const Shared& S, int leg, LegConst& K) {
 // world joint axis is a column of the link rotation.  What the constraint rows need afterwards is small and goes to
 // LDS: T_L (6x3), H_L^-1 per leg and A0^-1 (LegSolve / Shared::IA0inv) - the impulse response of a row is then
 //   da0 = A0^-1 (Jb - T_L jl);  dqdd_L = H_L^-1 jl - T_L^T da0;  dqdd_K = -T_K^T da0  (K != L).
-// Lanes with the same (lane & 3) do the same leg; results are written by lanes 0..3.
+// Lane (leg = lane & 3, part = (lane >> 2) & 3): all lanes of a leg walk down its joints, but each computes the costly
+// per-link terms (inertia about O, bias force) only for link `part`; subtree sums run over the parts with DPP row
+// shifts, F / H / bias torques of the three joints are exchanged through LDS (LegExchange), and from there on every
+// lane of the leg holds the whole leg again (the base system is solved redundantly in all lanes).
 // ================================================================================================
 
 // R S R^T for a symmetric S (xx yy zz xy xz yz) and a general rotation R (row-major)
@@ -291,16 +303,12 @@ __device__ __forceinline__ void spatial_inertia_mul(const float I[6], const floa
   ol[0] = m * v[0] - u[0]; ol[1] = m * v[1] - u[1]; ol[2] = m * v[2] - u[2];
 }
 
-struct LinkDyn {  // per link, registers of the leg lane
-  float s[3], sv[3];  // motion axis S = (s; d x s)
-  float I[6], h[3], m;  // spatial inertia about O (own link on the way down, composite of the subtree on the way up)
-  float f[6];         // bias force (own link, then subtree sum)
-};
-
-// one link on the way down the leg: pose, velocity, velocity-product acceleration, inertia about O, bias force
+// one joint on the way down the leg: pose of the link behind it, its motion axis S = (s; d x s) about O, spatial
+// velocity and velocity-product acceleration.  For a joint beyond the lane's own link the constants are zero and the
+// step is the identity (angle 0, rate 0, offset 0).
 template <int AX>
-__device__ __forceinline__ void link_down(Shared& S, const LegConst& K, int k, int j, bool wr, float Rw[9], float d[3], float Vw[3],
-                                          float Vv[3], float Aa[3], float Al[3], LinkDyn& G, float& ad_out) {
+__device__ __forceinline__ void joint_down(const Shared& S, const LegConst& K, int k, int j, float Rw[9], float d[3], float Vw[3],
+                                           float Vv[3], float Aa[3], float Al[3], float s[3], float sv[3], float& ad_out) {
   const float a = K.jdir[k] * (S.s[O(Q) + j] - K.joff[k]);
   const float ad = K.jdir[k] * S.s[O(QD) + j];
   ad_out = ad;
@@ -318,92 +326,127 @@ __device__ __forceinline__ void link_down(Shared& S, const LegConst& K, int k, i
     if (AX == 0) { Rw[3 * i + 1] = cs * p1 + sn * p2; Rw[3 * i + 2] = -sn * p1 + cs * p2; }
     else { Rw[3 * i] = cs * p0 - sn * p2; Rw[3 * i + 2] = sn * p0 + cs * p2; }
   }
-  if (wr) {
-    LinkCache& L = S.lc[j];
-#pragma unroll
-    for (int i = 0; i < 9; i++) L.Rw[i] = Rw[i];
-#pragma unroll
-    for (int i = 0; i < 3; i++) L.ow[i] = S.s[O(POS) + i] + d[i];
-  }
-  G.s[0] = Rw[AX]; G.s[1] = Rw[3 + AX]; G.s[2] = Rw[6 + AX];
-  cross3(d, G.s, G.sv);
+  s[0] = Rw[AX]; s[1] = Rw[3 + AX]; s[2] = Rw[6 + AX];
+  cross3(d, s, sv);
   // V += S ad;  A += V x (S ad)
-  const float ga[3] = {G.s[0] * ad, G.s[1] * ad, G.s[2] * ad}, gl[3] = {G.sv[0] * ad, G.sv[1] * ad, G.sv[2] * ad};
+  const float ga[3] = {s[0] * ad, s[1] * ad, s[2] * ad}, gl[3] = {sv[0] * ad, sv[1] * ad, sv[2] * ad};
 #pragma unroll
   for (int i = 0; i < 3; i++) { Vw[i] += ga[i]; Vv[i] += gl[i]; }
-  {
-    float t0[3], t1[3], t2[3];
-    cross3(Vw, ga, t0);
-    cross3(Vw, gl, t1);
-    cross3(Vv, ga, t2);
+  float t0[3], t1[3], t2[3];
+  cross3(Vw, ga, t0);
+  cross3(Vw, gl, t1);
+  cross3(Vv, ga, t2);
 #pragma unroll
-    for (int i = 0; i < 3; i++) { Aa[i] += t0[i]; Al[i] += t1[i] + t2[i]; }
-  }
-  // spatial inertia about O
-  float c[3];
-  mv3(Rw, K.com[k], c);
-  c[0] += d[0]; c[1] += d[1]; c[2] += d[2];
-  const float m = K.m[k];
-  G.m = m;
-  G.h[0] = m * c[0]; G.h[1] = m * c[1]; G.h[2] = m * c[2];
-  rot_sym_full(Rw, K.Ic[k], G.I);
-  {
-    const float hc = G.h[0] * c[0] + G.h[1] * c[1] + G.h[2] * c[2];
-    G.I[0] += hc - G.h[0] * c[0]; G.I[1] += hc - G.h[1] * c[1]; G.I[2] += hc - G.h[2] * c[2];
-    G.I[3] -= G.h[0] * c[1]; G.I[4] -= G.h[0] * c[2]; G.I[5] -= G.h[1] * c[2];
-  }
-  // bias force f = I A + V x* (I V)
-  float Pa[3], Pl[3], Fa[3], Fl[3], t0[3], t1[3], t2[3];
-  spatial_inertia_mul(G.I, G.h, m, Vw, Vv, Pa, Pl);
-  spatial_inertia_mul(G.I, G.h, m, Aa, Al, Fa, Fl);
-  cross3(Vw, Pa, t0);
-  cross3(Vv, Pl, t1);
-  cross3(Vw, Pl, t2);
-#pragma unroll
-  for (int i = 0; i < 3; i++) { G.f[i] = Fa[i] + t0[i] + t1[i]; G.f[3 + i] = Fl[i] + t2[i]; }
+  for (int i = 0; i < 3; i++) { Aa[i] += t0[i]; Al[i] += t1[i] + t2[i]; }
+}
+
+// x_q + x_{q+1} + x_{q+2} over the lanes of one leg (lane = leg + 4 q): two DPP row shifts, zero beyond the row
+__device__ __forceinline__ float part_suffix_sum(float x) {
+  const int v = __float_as_int(x);
+  const float a = __int_as_float(__builtin_amdgcn_update_dpp(0, v, 0x104, 0xF, 0xF, true));  // row_shl:4
+  const float b = __int_as_float(__builtin_amdgcn_update_dpp(0, v, 0x108, 0xF, 0xF, true));  // row_shl:8
+  return x + a + b;
 }
 
 __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst& K, int lane) {
-  const int leg = lane & 3;
-  const bool wr = lane < 4;
+  const int leg = lane & 3, part = (lane >> 2) & 3;
+  const bool first = lane < 4;            // the leg's results are written by its part-0 lane
   float Rb[9];  // kinematic base frame -> world: kept current by base_rotation() (after every change of the quaternion)
 #pragma unroll
   for (int i = 0; i < 9; i++) Rb[i] = S.Rb[i];
   const float wb[3] = {S.s[O(ANGVEL)], S.s[O(ANGVEL) + 1], S.s[O(ANGVEL) + 2]};
   const float vb[3] = {S.s[O(LINVEL)], S.s[O(LINVEL) + 1], S.s[O(LINVEL) + 2]};
-  LinkDyn G0, G1, G2;
-  float ad0, ad1, ad2;  // joint rates (internal sign)
-  {
-    float Rw[9], d[3] = {0, 0, 0}, Vw[3] = {wb[0], wb[1], wb[2]}, Vv[3] = {vb[0], vb[1], vb[2]};
-    float Aa[3] = {0, 0, 0}, Al[3] = {0, 0, 0};
+  // ---- way down: this lane stops at its own link (joints beyond it are identity steps) ----
+  float Rw[9], d[3] = {0, 0, 0}, Vw[3] = {wb[0], wb[1], wb[2]}, Vv[3] = {vb[0], vb[1], vb[2]};
+  float Aa[3] = {0, 0, 0}, Al[3] = {0, 0, 0};
+  float s0[3], sv0[3], s1[3], sv1[3], s2[3], sv2[3], ad0, ad1, ad2;
 #pragma unroll
-    for (int i = 0; i < 9; i++) Rw[i] = Rb[i];
-    link_down<0>(S, K, 0, 3 * leg, wr, Rw, d, Vw, Vv, Aa, Al, G0, ad0);
-    link_down<1>(S, K, 1, 3 * leg + 1, wr, Rw, d, Vw, Vv, Aa, Al, G1, ad1);
-    link_down<1>(S, K, 2, 3 * leg + 2, wr, Rw, d, Vw, Vv, Aa, Al, G2, ad2);
+  for (int i = 0; i < 9; i++) Rw[i] = Rb[i];
+  joint_down<0>(S, K, 0, 3 * leg, Rw, d, Vw, Vv, Aa, Al, s0, sv0, ad0);
+  joint_down<1>(S, K, 1, 3 * leg + 1, Rw, d, Vw, Vv, Aa, Al, s1, sv1, ad1);
+  joint_down<1>(S, K, 2, 3 * leg + 2, Rw, d, Vw, Vv, Aa, Al, s2, sv2, ad2);
+  if (lane < 12) {  // pose of the own link for the constraint rows
+    LinkCache& L = S.lc[3 * leg + part];
+#pragma unroll
+    for (int i = 0; i < 9; i++) L.Rw[i] = Rw[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) L.ow[i] = S.s[O(POS) + i] + d[i];
   }
-  // way up: composite inertias and subtree force sums
+  // own joint: axis and rate
+  float so[3], svo[3];
 #pragma unroll
-  for (int i = 0; i < 6; i++) { G1.I[i] += G2.I[i]; G1.f[i] += G2.f[i]; }
+  for (int i = 0; i < 3; i++) {
+    so[i] = part == 0 ? s0[i] : (part == 1 ? s1[i] : s2[i]);
+    svo[i] = part == 0 ? sv0[i] : (part == 1 ? sv1[i] : sv2[i]);
+  }
+  const float ado = part == 0 ? ad0 : (part == 1 ? ad1 : ad2);
+  // ---- own link: spatial inertia about O and bias force f = I A + V x* (I V) ----
+  float I[6], h[3], m = K.m, f[6];
+  {
+    float c[3];
+    mv3(Rw, K.com, c);
+    c[0] += d[0]; c[1] += d[1]; c[2] += d[2];
+    h[0] = m * c[0]; h[1] = m * c[1]; h[2] = m * c[2];
+    rot_sym_full(Rw, K.Ic, I);
+    const float hc = h[0] * c[0] + h[1] * c[1] + h[2] * c[2];
+    I[0] += hc - h[0] * c[0]; I[1] += hc - h[1] * c[1]; I[2] += hc - h[2] * c[2];
+    I[3] -= h[0] * c[1]; I[4] -= h[0] * c[2]; I[5] -= h[1] * c[2];
+    float Pa[3], Pl[3], Fa[3], Fl[3], t0[3], t1[3], t2[3];
+    spatial_inertia_mul(I, h, m, Vw, Vv, Pa, Pl);
+    spatial_inertia_mul(I, h, m, Aa, Al, Fa, Fl);
+    cross3(Vw, Pa, t0);
+    cross3(Vv, Pl, t1);
+    cross3(Vw, Pl, t2);
 #pragma unroll
-  for (int i = 0; i < 3; i++) G1.h[i] += G2.h[i];
-  G1.m += G2.m;
+    for (int i = 0; i < 3; i++) { f[i] = Fa[i] + t0[i] + t1[i]; f[3 + i] = Fl[i] + t2[i]; }
+  }
+  // ---- way up: composite inertia and force sum of the subtree behind the own joint (sum over the leg's later parts) ----
 #pragma unroll
-  for (int i = 0; i < 6; i++) { G0.I[i] += G1.I[i]; G0.f[i] += G1.f[i]; }
+  for (int i = 0; i < 6; i++) { I[i] = part_suffix_sum(I[i]); f[i] = part_suffix_sum(f[i]); }
 #pragma unroll
-  for (int i = 0; i < 3; i++) G0.h[i] += G1.h[i];
-  G0.m += G1.m;
-  // F columns, bias torques C, leg mass matrix H
-  float F[3][6], b[3];
-  spatial_inertia_mul(G0.I, G0.h, G0.m, G0.s, G0.sv, &F[0][0], &F[0][3]);
-  spatial_inertia_mul(G1.I, G1.h, G1.m, G1.s, G1.sv, &F[1][0], &F[1][3]);
-  spatial_inertia_mul(G2.I, G2.h, G2.m, G2.s, G2.sv, &F[2][0], &F[2][3]);
-  b[0] = S.tau[3 * leg] - (dot3(G0.s, &G0.f[0]) + dot3(G0.sv, &G0.f[3]));
-  b[1] = S.tau[3 * leg + 1] - (dot3(G1.s, &G1.f[0]) + dot3(G1.sv, &G1.f[3]));
-  b[2] = S.tau[3 * leg + 2] - (dot3(G2.s, &G2.f[0]) + dot3(G2.sv, &G2.f[3]));
-  const float H00 = dot3(G0.s, &F[0][0]) + dot3(G0.sv, &F[0][3]), H01 = dot3(G0.s, &F[1][0]) + dot3(G0.sv, &F[1][3]);
-  const float H02 = dot3(G0.s, &F[2][0]) + dot3(G0.sv, &F[2][3]), H11 = dot3(G1.s, &F[1][0]) + dot3(G1.sv, &F[1][3]);
-  const float H12 = dot3(G1.s, &F[2][0]) + dot3(G1.sv, &F[2][3]), H22 = dot3(G2.s, &F[2][0]) + dot3(G2.sv, &F[2][3]);
+  for (int i = 0; i < 3; i++) h[i] = part_suffix_sum(h[i]);
+  m = part_suffix_sum(m);
+  // own column of F and of the leg's joint-space inertia H (entries H[i][part], i <= part), own bias torque
+  {
+    float Fo[6];
+    spatial_inertia_mul(I, h, m, so, svo, &Fo[0], &Fo[3]);
+    const float bo = S.tau[3 * leg + (part < 3 ? part : 2)] - (dot3(so, &f[0]) + dot3(svo, &f[3]));
+    const float hc0 = dot3(s0, &Fo[0]) + dot3(sv0, &Fo[3]), hc1 = dot3(s1, &Fo[0]) + dot3(sv1, &Fo[3]);
+    const float hc2 = dot3(s2, &Fo[0]) + dot3(sv2, &Fo[3]);
+    if (lane < 12) {
+      LegExchange& X = S.legx[leg];
+#pragma unroll
+      for (int i = 0; i < 6; i++) X.F[part][i] = Fo[i];
+      X.b[part] = bo;
+      X.Hc[part][0] = hc0; X.Hc[part][1] = hc1; X.Hc[part][2] = hc2;
+      if (part == 0) {  // composite of the whole leg
+#pragma unroll
+        for (int i = 0; i < 6; i++) { X.I[i] = I[i]; X.f[i] = f[i]; }
+#pragma unroll
+        for (int i = 0; i < 3; i++) X.h[i] = h[i];
+        X.m = m;
+      }
+    }
+  }
+  WSYNC();
+  // ---- every lane of the leg: all three F columns, H, the leg composite ----
+  float F[3][6], b[3], GI[6], Gh[3], Gm, Gf[6];
+  float H00, H01, H02, H11, H12, H22;
+  {
+    const LegExchange& X = S.legx[leg];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) F[k][i] = X.F[k][i];
+      b[k] = X.b[k];
+    }
+    H00 = X.Hc[0][0]; H01 = X.Hc[1][0]; H11 = X.Hc[1][1]; H02 = X.Hc[2][0]; H12 = X.Hc[2][1]; H22 = X.Hc[2][2];
+#pragma unroll
+    for (int i = 0; i < 6; i++) { GI[i] = X.I[i]; Gf[i] = X.f[i]; }
+#pragma unroll
+    for (int i = 0; i < 3; i++) Gh[i] = X.h[i];
+    Gm = X.m;
+  }
   float Hi[6];  // H^-1, symmetric (00 11 22 01 02 12), by cofactors
   {
     const float c00 = H11 * H22 - H12 * H12, c01 = H02 * H12 - H01 * H22, c02 = H01 * H12 - H02 * H11;
@@ -418,7 +461,7 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
     T[1][i] = F[0][i] * Hi[3] + F[1][i] * Hi[1] + F[2][i] * Hi[5];
     T[2][i] = F[0][i] * Hi[4] + F[1][i] * Hi[5] + F[2][i] * Hi[2];
   }
-  if (wr) {
+  if (first) {
     LegSolve& Q = S.leg[leg];
 #pragma unroll
     for (int k = 0; k < 3; k++)
@@ -430,17 +473,17 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
   // this leg's part of the base equation: composite inertia minus T F^T, force p + T b
   float Iacc[6], Hacc[9], Macc[6], pacc[6];
 #define TFT(i, j) (T[0][i] * F[0][j] + T[1][i] * F[1][j] + T[2][i] * F[2][j])
-  Iacc[0] = G0.I[0] - TFT(0, 0); Iacc[1] = G0.I[1] - TFT(1, 1); Iacc[2] = G0.I[2] - TFT(2, 2);
-  Iacc[3] = G0.I[3] - TFT(0, 1); Iacc[4] = G0.I[4] - TFT(0, 2); Iacc[5] = G0.I[5] - TFT(1, 2);
-  Macc[0] = G0.m - TFT(3, 3); Macc[1] = G0.m - TFT(4, 4); Macc[2] = G0.m - TFT(5, 5);
+  Iacc[0] = GI[0] - TFT(0, 0); Iacc[1] = GI[1] - TFT(1, 1); Iacc[2] = GI[2] - TFT(2, 2);
+  Iacc[3] = GI[3] - TFT(0, 1); Iacc[4] = GI[4] - TFT(0, 2); Iacc[5] = GI[5] - TFT(1, 2);
+  Macc[0] = Gm - TFT(3, 3); Macc[1] = Gm - TFT(4, 4); Macc[2] = Gm - TFT(5, 5);
   Macc[3] = -TFT(3, 4); Macc[4] = -TFT(3, 5); Macc[5] = -TFT(4, 5);
   // top-right block: skew(h) - (T F^T)[a][3 + b]
-  Hacc[0] = -TFT(0, 3);           Hacc[1] = -G0.h[2] - TFT(0, 4); Hacc[2] = G0.h[1] - TFT(0, 5);
-  Hacc[3] = G0.h[2] - TFT(1, 3);  Hacc[4] = -TFT(1, 4);           Hacc[5] = -G0.h[0] - TFT(1, 5);
-  Hacc[6] = -G0.h[1] - TFT(2, 3); Hacc[7] = G0.h[0] - TFT(2, 4);  Hacc[8] = -TFT(2, 5);
+  Hacc[0] = -TFT(0, 3);          Hacc[1] = -Gh[2] - TFT(0, 4); Hacc[2] = Gh[1] - TFT(0, 5);
+  Hacc[3] = Gh[2] - TFT(1, 3);   Hacc[4] = -TFT(1, 4);         Hacc[5] = -Gh[0] - TFT(1, 5);
+  Hacc[6] = -Gh[1] - TFT(2, 3);  Hacc[7] = Gh[0] - TFT(2, 4);  Hacc[8] = -TFT(2, 5);
 #undef TFT
 #pragma unroll
-  for (int i = 0; i < 6; i++) pacc[i] = G0.f[i] + T[0][i] * b[0] + T[1][i] * b[1] + T[2][i] * b[2];
+  for (int i = 0; i < 6; i++) pacc[i] = Gf[i] + T[0][i] * b[0] + T[1][i] * b[1] + T[2][i] * b[2];
   // base: sum the four leg contributions (butterfly over lane bits 0, 1 = DPP quad permutes, fused into the adds)
 #pragma unroll
   for (int i = 0; i < 6; i++) { Iacc[i] = quad_sum(Iacc[i]); Macc[i] = quad_sum(Macc[i]); pacc[i] = quad_sum(pacc[i]); }
@@ -451,14 +494,14 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
     float A6[36], pA0[6], Ibw[6];
     const float m0 = S.mass[0];
     rot_sym_full(Rb, S.Ic[0], Ibw);
-    float n[3], f[3] = {m0 * vb[0], m0 * vb[1], m0 * vb[2]}, t1[3], t2[3];
+    float n[3], fb[3] = {m0 * vb[0], m0 * vb[1], m0 * vb[2]}, t1[3], t2[3];
     symv(Ibw, wb, n);
     cross3(wb, n, t1);
-    cross3(wb, f, t2);
+    cross3(wb, fb, t2);
     // Bullet base damping (btMultiBody): torque k_a I w, force k_l m v on the bias side
     const float kl = S.s[O(BASE_DAMPING)], ka = S.s[O(BASE_DAMPING) + 1];
 #pragma unroll
-    for (int i = 0; i < 3; i++) { pA0[i] = t1[i] + ka * n[i] + pacc[i]; pA0[3 + i] = t2[i] + kl * f[i] + pacc[3 + i]; }
+    for (int i = 0; i < 3; i++) { pA0[i] = t1[i] + ka * n[i] + pacc[i]; pA0[3 + i] = t2[i] + kl * fb[i] + pacc[3 + i]; }
     float Ib[9], Im[9], Mm[9];
     sym_to_m3(Ibw, Ib);
     sym_to_m3(Iacc, Im);
@@ -488,18 +531,17 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
       for (int i = 0; i < 6; i++) S.IA0inv[i * 6 + col] = x[i];
     }
   }
-  // joint accelerations qdd = H^-1 (b - F^T a0); written as the unconstrained velocities u* = u + dt udot
+  // joint accelerations qdd = H^-1 (b - F^T a0); written as the unconstrained velocities u* = u + dt udot by the lane
+  // that owns the joint (it has the joint rate)
   const float dt = P.cfg.sim_dt;
   {
     float g[3];
 #pragma unroll
     for (int k = 0; k < 3; k++)
       g[k] = b[k] - (F[k][0] * a0[0] + F[k][1] * a0[1] + F[k][2] * a0[2] + F[k][3] * a0[3] + F[k][4] * a0[4] + F[k][5] * a0[5]);
-    if (wr) {
-      S.ustar[6 + 3 * leg] = ad0 + dt * (Hi[0] * g[0] + Hi[3] * g[1] + Hi[4] * g[2]);
-      S.ustar[6 + 3 * leg + 1] = ad1 + dt * (Hi[3] * g[0] + Hi[1] * g[1] + Hi[5] * g[2]);
-      S.ustar[6 + 3 * leg + 2] = ad2 + dt * (Hi[4] * g[0] + Hi[5] * g[1] + Hi[2] * g[2]);
-    }
+    const float q0 = Hi[0] * g[0] + Hi[3] * g[1] + Hi[4] * g[2], q1 = Hi[3] * g[0] + Hi[1] * g[1] + Hi[5] * g[2];
+    const float q2 = Hi[4] * g[0] + Hi[5] * g[1] + Hi[2] * g[2];
+    if (lane < 12) S.ustar[6 + 3 * leg + part] = ado + dt * (part == 0 ? q0 : (part == 1 ? q1 : q2));
   }
   if (lane == 0) {
     // classical base acceleration (Bullet: vdot = a_lin + w x v); gravity = uniform-field offset
@@ -1355,8 +1397,10 @@ __global__ __launch_bounds__(64) void orr_reset_kernel(KParams P, const uint8_t*
 #ifndef ORR_WAVES_PER_EU
 #define ORR_WAVES_PER_EU 1  // 4096 robots, four per wave = one wave on each of the 1024 SIMDs: the whole batch is resident at once
 #endif
+// (min, max) waves per SIMD are pinned to the same value: with a higher maximum this LLVM's iterative-ilp scheduler tries
+// occupancy-improving reschedules once the kernel fits 256 VGPRs and then crashes in the register allocator.
 template <int MODE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PER_EU, 8))) void orr_step_kernel(KParams P, const float* actions, float* obs_out, float* reward_out,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PER_EU, ORR_WAVES_PER_EU))) void orr_step_kernel(KParams P, const float* actions, float* obs_out, float* reward_out,
                                                       uint8_t* done_out, int nsub) {
   ORR_PROLOGUE();
   const bool valid = in_range;
@@ -1367,7 +1411,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
   for (int i = lane; i < kMaxRows * 18; i += kLanes) (&S.ph.sub.W[0][0])[i] = 0.0f;
   WSYNC();
   LegConst K;
-  load_leg_const(S, lane & 3, K);
+  load_leg_const(S, lane, K);
   {
     float rel[4], Rb[9];
     base_rotation(S, lane, rel, Rb);  // Shared::Rb for the first sub-step; the ring push keeps it current afterwards
