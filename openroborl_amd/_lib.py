@@ -50,9 +50,6 @@ def build(force=False, verbose=False, out_path=None, extra_flags=()):
             return LIB_PATH
         out_path = LIB_PATH
     flags = [f for f in HIPCC_FLAGS if f != "-shared"] + ["-c"]
-    if os.environ.get("ORR_LANES_PER_ROBOT", "16") != "16":
-        # tuning builds with wider lane groups: this LLVM's register allocator crashes on them under iterative-ilp
-        flags = [f for f in flags if f not in ("-mllvm", "-amdgpu-sched-strategy=iterative-ilp")]
     for var in ("ORR_WAVES_PER_EU", "ORR_LANES_PER_ROBOT"):      # tuning experiments only
         if os.environ.get(var):
             flags.append("-D%s=%d" % (var, int(os.environ[var])))
