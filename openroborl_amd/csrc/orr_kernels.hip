@@ -1453,26 +1453,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
   int fall = 0;
   const float inv_repeat = 1.0f / (float)c.action_repeat;
   const RingLatency rlat = ring_latency(P, S);
+  // per-motor constants of the PD loop and the step's filtered target, in registers over the sub-steps (lane = motor)
+  const int ml = lane < 12 ? lane : 0;
+  const int mj = S.m.joint_of_motor[ml];
+  const float m_off = S.m.motor_offset[ml], m_dir = S.m.motor_dir[ml], m_kp = S.m.kp[ml], m_kd = S.m.kd[ml];
+  const float m_gain = S.m.tau_sign[mj] * S.s[O(STRENGTH) + ml];
+  const float m_target = S.s[O(ACTION) + ml], m_prev = S.s[O(FILTER_ACTION) + ml];
+  const bool m_has_prev = geti(S, O(FILTER_VALID)) != 0;
+  int action_counter = geti(S, O(STATE_ACTION_COUNTER));
   for (int sstep = 0; sstep < c.action_repeat; sstep++) {
     if (kLanes != 16 && sstep > 0) ctrl_obs(P, rec, S, lane);
     if (lane < 12) {
       const float lerp = (float)(sstep + 1) * inv_repeat;  // process_action (minitaur.py:438-460)
       const float cur = map_pi(S.co[lane]);
-      const float prev = geti(S, O(FILTER_VALID)) ? S.s[O(FILTER_ACTION) + lane] : cur;
-      float cmd = prev + lerp * (S.s[O(ACTION) + lane] - prev);
+      const float prev = m_has_prev ? m_prev : cur;
+      float cmd = prev + lerp * (m_target - prev);
       cmd = fminf(fmaxf(cmd, cur - c.max_angle_change), cur + c.max_angle_change);  // _clip_motor_commands (:706-723)
-      const int j = S.m.joint_of_motor[lane];
-      const float qm = (S.s[O(Q) + j] - S.m.motor_offset[lane]) * S.m.motor_dir[lane];  // pd latency 0 (:359-363)
-      const float qdm = S.s[O(QD) + j] * S.m.motor_dir[lane];
+      const float qm = (S.s[O(Q) + mj] - m_off) * m_dir;  // pd latency 0 (:359-363)
+      const float qdm = S.s[O(QD) + mj] * m_dir;
       // MotorModel.convert_to_torque, POSITION mode (minitaur_motor.py:163-171)
-      S.tau[j] = S.m.tau_sign[j] * (S.s[O(STRENGTH) + lane] * (-1.0f * (S.m.kp[lane] * (qm - cmd)) - S.m.kd[lane] * qdm));
+      S.tau[mj] = m_gain * (-1.0f * (m_kp * (qm - cmd)) - m_kd * qdm);
     }
     WSYNC();
-    if (lane == 0) {  // robot_step bookkeeping (minitaur.py:287-293)
-      seti(S, O(STATE_ACTION_COUNTER), geti(S, O(STATE_ACTION_COUNTER)) + 1);
-      if (sstep == c.action_repeat - 1) { seti(S, O(FILTER_VALID), 1); seti(S, O(STEP_COUNTER), geti(S, O(STEP_COUNTER)) + 1); }
-    }
-    if (sstep == c.action_repeat - 1 && lane < 12) S.s[O(FILTER_ACTION) + lane] = S.s[O(ACTION) + lane];
+    action_counter++;  // robot_step bookkeeping (minitaur.py:287-293); written back after the loop
     PT(2);
     if (kLanes == 16) {  // receive_obs, then the control observation of the next sub-step / of get_obs
       RingFetch F;
@@ -1485,6 +1488,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
     }
     PT(10);
   }
+  if (lane == 0) {  // end of robot_step (minitaur.py:287-293)
+    seti(S, O(STATE_ACTION_COUNTER), action_counter);
+    seti(S, O(FILTER_VALID), 1);
+    seti(S, O(STEP_COUNTER), geti(S, O(STEP_COUNTER)) + 1);
+  }
+  if (lane < 12) S.s[O(FILTER_ACTION) + lane] = m_target;
+  WSYNC();
   // ---- get_obs: sensors on_step (minitaur.py:295-299) ----
   if (kLanes != 16) ctrl_obs(P, rec, S, lane);
   sensors_push(S, lane, false);
