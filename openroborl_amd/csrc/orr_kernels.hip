@@ -141,9 +141,12 @@ __device__ __forceinline__ RingLatency ring_latency(const KParams& P, const Shar
   L.al = (lat - L.n * dt) / dt;
   return L;
 }
-__device__ __forceinline__ void ring_prefetch(const RingLatency& L, const float* rec, const Shared& S, int lane, RingFetch& F) {
-  const int len0 = geti(S, O(RING_LEN)), head = (geti(S, O(RING_HEAD)) + 1) % ORR_RING_DEPTH;  // after the push
-  const int len = len0 + 1 > ORR_RING_DEPTH ? ORR_RING_DEPTH : len0 + 1;
+struct RingCursor { int head, len; };  // RING_HEAD / RING_LEN carried in registers over the sub-steps
+__device__ __forceinline__ int ring_wrap_up(int i) { return i >= ORR_RING_DEPTH ? i - ORR_RING_DEPTH : i; }   // i < 2 depth
+__device__ __forceinline__ int ring_wrap_down(int i) { return i < 0 ? i + ORR_RING_DEPTH : i; }                 // i >= -depth
+__device__ __forceinline__ void ring_prefetch(const RingLatency& L, const float* rec, const RingCursor& C, int lane, RingFetch& F) {
+  const int head = ring_wrap_up(C.head + 1);  // after the push
+  const int len = C.len + 1 > ORR_RING_DEPTH ? ORR_RING_DEPTH : C.len + 1;
   int k0 = 0, k1 = 0;
   F.al = 0.0f;
   if (!(L.none || len == 1)) {
@@ -151,28 +154,27 @@ __device__ __forceinline__ void ring_prefetch(const RingLatency& L, const float*
     else { k0 = L.n; k1 = L.n + 1; F.al = L.al; }
   }
   F.same = k0 == k1; F.new0 = k0 == 0; F.new1 = k1 == 0;
-  const int i0 = (head - k0 + 2 * ORR_RING_DEPTH) % ORR_RING_DEPTH, i1 = (head - k1 + 2 * ORR_RING_DEPTH) % ORR_RING_DEPTH;
+  const int i0 = ring_wrap_down(head - k0), i1 = ring_wrap_down(head - k1);   // k < len <= depth
   const float* p0 = rec + O(RING) + i0 * ORR_RING_ENTRY;
   const float* p1 = rec + O(RING) + i1 * ORR_RING_ENTRY;
   const int hi = lane < 3 ? 16 + lane : lane;  // lanes >= 3: harmless duplicate of word `lane`
   F.e0[0] = p0[lane]; F.e0[1] = p0[hi];
   F.e1[0] = p1[lane]; F.e1[1] = p1[hi];
 }
-__device__ __forceinline__ void ring_push_and_ctrl_obs(float* rec, Shared& S, int lane, bool valid, const RingFetch& F) {
+// mang: this lane's true motor angle (lane < 12), computed by the caller from its register copy of the motor constants
+__device__ __forceinline__ void ring_push_and_ctrl_obs(float* rec, Shared& S, int lane, bool valid, const RingFetch& F, RingCursor& C,
+                                                       float mang) {
   static_assert(ORR_RING_ENTRY == 20, "lane mapping below assumes 20-word entries");
-  const int head = (geti(S, O(RING_HEAD)) + 1) % ORR_RING_DEPTH, len = geti(S, O(RING_LEN));
+  C.head = ring_wrap_up(C.head + 1);
+  C.len = C.len + 1 > ORR_RING_DEPTH ? ORR_RING_DEPTH : C.len + 1;
   float rel[4], Rb[9], rate[3];
   base_rotation(S, lane, rel, Rb);
   mtv3(Rb, &S.s[O(ANGVEL)], rate);  // get_true_base_rpy_rate (minitaur.py:640-672): angular velocity in the base frame
-  // word `lane`: motor angles 0..11, relative quaternion 12..15; word 16 + lane (lanes 0..3): rate 16..18, pad 19
-  float va, vb;
-  {
-    const int m = lane < 12 ? lane : 0, j = S.m.joint_of_motor[m];
-    const float ang = (S.s[O(Q) + j] - S.m.motor_offset[m]) * S.m.motor_dir[m];  // get_true_motor_angles (:543-553)
-    va = lane < 12 ? ang : (lane == 12 ? rel[0] : (lane == 13 ? rel[1] : (lane == 14 ? rel[2] : rel[3])));
-    vb = lane == 0 ? rate[0] : (lane == 1 ? rate[1] : (lane == 2 ? rate[2] : 0.0f));
-  }
-  float* dst = rec + O(RING) + head * ORR_RING_ENTRY;
+  // word `lane`: motor angles 0..11 (get_true_motor_angles, :543-553), relative quaternion 12..15;
+  // word 16 + lane (lanes 0..3): rate 16..18, pad 19
+  const float va = lane < 12 ? mang : (lane == 12 ? rel[0] : (lane == 13 ? rel[1] : (lane == 14 ? rel[2] : rel[3])));
+  const float vb = lane == 0 ? rate[0] : (lane == 1 ? rate[1] : (lane == 2 ? rate[2] : 0.0f));
+  float* dst = rec + O(RING) + C.head * ORR_RING_ENTRY;
   if (valid) {
     dst[lane] = va;
     if (lane < 4) dst[16 + lane] = vb;
@@ -181,10 +183,6 @@ __device__ __forceinline__ void ring_push_and_ctrl_obs(float* rec, Shared& S, in
   const float b0 = F.new0 ? vb : F.e0[1], b1 = F.new1 ? vb : F.e1[1];
   S.co[lane] = F.same ? a0 : (1.0f - F.al) * a0 + F.al * a1;
   if (lane < 3) S.co[16 + lane] = F.same ? b0 : (1.0f - F.al) * b0 + F.al * b1;
-  if (lane == 0) {
-    seti(S, O(RING_HEAD), head);
-    seti(S, O(RING_LEN), len + 1 > ORR_RING_DEPTH ? ORR_RING_DEPTH : len + 1);
-  }
   WSYNC();
 }
 
@@ -1461,6 +1459,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
   const float m_target = S.s[O(ACTION) + ml], m_prev = S.s[O(FILTER_ACTION) + ml];
   const bool m_has_prev = geti(S, O(FILTER_VALID)) != 0;
   int action_counter = geti(S, O(STATE_ACTION_COUNTER));
+  RingCursor ring = {geti(S, O(RING_HEAD)), geti(S, O(RING_LEN))};
   for (int sstep = 0; sstep < c.action_repeat; sstep++) {
     if (kLanes != 16 && sstep > 0) ctrl_obs(P, rec, S, lane);
     if (lane < 12) {
@@ -1479,9 +1478,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
     PT(2);
     if (kLanes == 16) {  // receive_obs, then the control observation of the next sub-step / of get_obs
       RingFetch F;
-      ring_prefetch(rlat, rec, S, lane, F);
+      ring_prefetch(rlat, rec, ring, lane, F);
       fall = physics_substep(P, S, K, lane, sub, sstep == c.action_repeat - 1);
-      ring_push_and_ctrl_obs(rec, S, lane, valid, F);
+      ring_push_and_ctrl_obs(rec, S, lane, valid, F, ring, (S.s[O(Q) + mj] - m_off) * m_dir);
     } else {
       fall = physics_substep(P, S, K, lane, sub, sstep == c.action_repeat - 1);
       receive_obs(rec, S, lane, valid);
@@ -1489,6 +1488,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
     PT(10);
   }
   if (lane == 0) {  // end of robot_step (minitaur.py:287-293)
+    if (kLanes == 16) { seti(S, O(RING_HEAD), ring.head); seti(S, O(RING_LEN), ring.len); }
     seti(S, O(STATE_ACTION_COUNTER), action_counter);
     seti(S, O(FILTER_VALID), 1);
     seti(S, O(STEP_COUNTER), geti(S, O(STEP_COUNTER)) + 1);
