@@ -119,6 +119,7 @@ struct KParams {
 struct LinkCache {  // per movable link, written by the leg lanes (0..3), read by the row lanes
   float Rw[9];      // link -> world
   float ow[3];      // link origin, world
+  float s[3], sv[3];  // motion axis of the joint in front of the link, about the base COM: (axis; (origin - base) x axis)
 };
 struct LegExchange {  // per leg, hand-over between the lanes (parts) of a leg inside leg_dynamics
   float F[3][6];      // F_k = Ic_k S_k of joint k, written by part k

@@ -363,13 +363,6 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
   joint_down<0>(S, K, 0, 3 * leg, Rw, d, Vw, Vv, Aa, Al, s0, sv0, ad0);
   joint_down<1>(S, K, 1, 3 * leg + 1, Rw, d, Vw, Vv, Aa, Al, s1, sv1, ad1);
   joint_down<1>(S, K, 2, 3 * leg + 2, Rw, d, Vw, Vv, Aa, Al, s2, sv2, ad2);
-  if (lane < 12) {  // pose of the own link for the constraint rows
-    LinkCache& L = S.lc[3 * leg + part];
-#pragma unroll
-    for (int i = 0; i < 9; i++) L.Rw[i] = Rw[i];
-#pragma unroll
-    for (int i = 0; i < 3; i++) L.ow[i] = S.s[O(POS) + i] + d[i];
-  }
   // own joint: axis and rate
   float so[3], svo[3];
 #pragma unroll
@@ -378,6 +371,13 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
     svo[i] = part == 0 ? sv0[i] : (part == 1 ? sv1[i] : sv2[i]);
   }
   const float ado = part == 0 ? ad0 : (part == 1 ? ad1 : ad2);
+  if (lane < 12) {  // pose and joint axis of the own link for the constraint rows
+    LinkCache& L = S.lc[3 * leg + part];
+#pragma unroll
+    for (int i = 0; i < 9; i++) L.Rw[i] = Rw[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) { L.ow[i] = S.s[O(POS) + i] + d[i]; L.s[i] = so[i]; L.sv[i] = svo[i]; }
+  }
   // ---- own link: spatial inertia about O and bias force f = I A + V x* (I V) ----
   float I[6], h[3], m = K.m, f[6];
   {
@@ -616,13 +616,11 @@ __device__ __forceinline__ void row_setup(const Shared& S, const orr_config& cfg
     float rel = R.Jb[0] * S.ustar[0] + R.Jb[1] * S.ustar[1] + R.Jb[2] * S.ustar[2] + R.Jb[3] * S.ustar[3] + R.Jb[4] * S.ustar[4] + R.Jb[5] * S.ustar[5];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
+      // velocity of the contact point per unit joint rate: s x (P - o) = s x rr + (d x s), rr and d relative to the base COM
       const LinkCache& L = S.lc[3 * leg + k];
-      const int ax = k == 0 ? 0 : 1;  // world joint axis = column ax of Rw
-      const float axw[3] = {L.Rw[ax], L.Rw[3 + ax], L.Rw[6 + ax]};
       float cr[3];
-      rr[0] = Pw[0] - L.ow[0]; rr[1] = Pw[1] - L.ow[1]; rr[2] = Pw[2] - L.ow[2];
-      cross3(axw, rr, cr);
-      R.jl[k] = dot3(dir, cr);
+      cross3(L.s, rr, cr);
+      R.jl[k] = dir[0] * (cr[0] + L.sv[0]) + dir[1] * (cr[1] + L.sv[1]) + dir[2] * (cr[2] + L.sv[2]);
       rel += R.jl[k] * S.ustar[6 + 3 * leg + k];
     }
     R.warm = 3 * leg + d;
