@@ -214,7 +214,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "orr_step_kernel<0>", "kernel_ms": kern_ms, "alg_bytes_per_robot_step": B_ALG,
                          "pmc": valu,
-                         "note": "VALU/latency-bound serial chain (33 x (ABA + 9 PGS sweeps)); HBM fraction is reported "
+                         "note": "instruction-issue-bound serial chain of a lone wave (33 x (leg dynamics + rows + 9 PGS sweeps)); HBM fraction is reported "
                                  "because the north star asks for it, see DESIGN.md section 6"},
         }
         if not args.no_cpu_baseline and world == 1:

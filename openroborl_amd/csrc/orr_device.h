@@ -3,10 +3,11 @@
 // A wavefront serves kRPW = 4 robots, 16 lanes each (ORR_LANES_PER_ROBOT; 32 / 64 are kept for experiments).
 // Lane roles inside a robot's lane group change phase by phase:
 //   motors      lanes 0..11   action filter / interpolation / clip / PD torque (minitaur.py:280-293,438-460,706-769)
-//   legs        lanes 0..3    articulated-body passes over the 3-link leg chains (pybullet stepSimulation)
+//   legs        leg = lane & 3, link = lane >> 2: forward dynamics of the 3-link leg chains (pybullet stepSimulation)
 //   rows        lanes 0..15   constraint rows in two banks: impulse response, Delassus column, PGS state
-//   dofs        18 generalised velocities u = [omega_w, v_w, joint rates], strided over the lanes
-// Cross-lane data goes through LDS (register arrays are never indexed dynamically).
+//   dofs        18 generalised velocities u = [omega_w, v_w, joint rates]: lane l owns DOF l (lanes 0, 1 also 16, 17)
+// Cross-lane data goes through DPP (a robot's 16 lanes are one DPP row) or LDS; register arrays are never indexed
+// dynamically.
 //
 // Arithmetic: float32.  Reference citations are relative to /root/reference/OpenRoboRL/.
 #pragma once

@@ -19,7 +19,7 @@ import torch  # noqa: E402
 from openroborl_amd import _lib  # noqa: E402
 from openroborl_amd.env import VecQuadrupedEnv  # noqa: E402
 
-NAMES = ["load+leg consts", "set_act/filter", "substep control", "ABA", "ustar+fall proxies", "row setup", "row response",
+NAMES = ["load+leg consts", "set_act/filter", "substep control", "leg dynamics", "fall proxies", "row setup", "row response",
          "Delassus columns", "PGS sweeps", "du+integrate", "receive_obs (ring)", "ctrl_obs+sensors", "reward+ref update",
          "termination+obs", "episode end/reset", "store"]
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
