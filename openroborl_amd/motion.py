@@ -116,3 +116,41 @@ class MotionClip(object):
     def joint_bounds(self):
         """Per-dimension min / max over frames (imitation_task.py:303-335, before root overrides)."""
         return self.frames.min(axis=0), self.frames.max(axis=0)
+
+
+def validate(path):
+    """Clip validator: loads the clip exactly as the env does and reports what a
+    retargeted file most often gets wrong.  Returns (report dict, list of problem strings)."""
+    clip = MotionClip(path)
+    raw = np.array(json.load(open(clip.path))["Frames"], dtype=np.float64)
+    problems = []
+    qn = np.linalg.norm(raw[:, 3:7], axis=1)
+    if np.abs(qn - 1.0).max() > 1e-3:
+        problems.append("root quaternions are not unit length (max |norm - 1| = %.2e); they are normalised on load" % np.abs(qn - 1.0).max())
+    if not np.all(np.isfinite(raw)):
+        problems.append("non-finite values in Frames")
+    speed = np.abs(clip.frame_vels[:, 6:]).max()
+    if speed > 40.0:
+        problems.append("joint rate of %.1f rad/s between two frames (frame duration or angle unwrapping?)" % speed)
+    if clip.loop_wrap and clip.num_frames > 1:
+        jump = np.abs(clip.frames[-1, 7:] - clip.frames[0, 7:]).max()
+        if jump > 0.6:
+            problems.append("wrap-around clip: joint angles of the last and first frame differ by %.2f rad" % jump)
+    if clip.frames[:, 2].min() <= 0.0:
+        problems.append("root height <= 0 in some frame")
+    report = {"path": clip.path, "frames": clip.num_frames, "frame_duration": clip.frame_duration, "duration": clip.duration,
+              "loop": "Wrap" if clip.loop_wrap else "Clamp", "cycle_offset_position": clip.cycle_pos,
+              "cycle_offset_rotation": clip.cycle_rot, "cycle_delta_xy_heading": [float(clip.cycle_delta[0]), float(clip.cycle_delta[1]),
+                                                                                 float(clip.cycle_delta[3])],
+              "root_height_range": [float(clip.frames[:, 2].min()), float(clip.frames[:, 2].max())],
+              "max_joint_rate": float(speed), "max_root_speed": float(np.linalg.norm(clip.frame_vels[:, 0:3], axis=1).max())}
+    return report, problems
+
+
+if __name__ == "__main__":   # python -m openroborl_amd.motion <clip.txt | clip name>
+    import sys
+    rep, probs = validate(sys.argv[1])
+    print(json.dumps(rep, indent=1))
+    for p_ in probs:
+        print("PROBLEM:", p_)
+    sys.exit(1 if probs else 0)

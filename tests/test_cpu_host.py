@@ -116,3 +116,17 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "liborr_oracle" not in txt and "orc_" not in txt and "oracle_lib" not in txt, f
+
+
+def test_motion_clip_validator():
+    from openroborl_amd import motion
+    rep, problems = motion.validate("laikago_pace")
+    assert rep["frames"] > 10 and rep["loop"] == "Wrap" and not problems
+    import json, tempfile
+    js = json.load(open(motion.resolve_path("laikago_pace")))
+    js["Frames"][3][7] += 5.0                       # a wrapped angle in one frame
+    with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as f:
+        json.dump(js, f)
+    rep, problems = motion.validate(f.name)
+    assert any("joint rate" in p for p in problems)
+    os.unlink(f.name)
