@@ -67,6 +67,10 @@ def build(force=False, verbose=False, out_path=None, extra_flags=()):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+    if tag:   # development builds leave no objects behind
+        for o in (obj_env, obj_pol):
+            if os.path.exists(o):
+                os.remove(o)
     return out_path
 
 
