@@ -16,6 +16,31 @@ import numpy as np
 from . import policy as pol
 
 
+_LINEAR_RELU = None
+
+
+def _linear_relu(torch):
+    """relu(x W + b) as one GEMM with a bias + ReLU epilogue (torch._addmm_activation has no autograd formula, so the
+    backward is spelled out: mask by the saved output, bias gradient = column sums, two GEMMs)."""
+    global _LINEAR_RELU
+    if _LINEAR_RELU is None:
+        class LinearReLU(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, x, w, b):
+                h = torch._addmm_activation(b, x, w)
+                ctx.save_for_backward(x, w, h)
+                return h
+
+            @staticmethod
+            def backward(ctx, gh):
+                x, w, h = ctx.saved_tensors
+                gz = gh * (h > 0).to(gh.dtype)
+                gx = gz @ w.t() if ctx.needs_input_grad[0] else None
+                return gx, x.t() @ gz, gz.sum(dim=0)
+        _LINEAR_RELU = LinearReLU.apply
+    return _LINEAR_RELU
+
+
 class ActorCritic(object):
     """Trainable twin of policy.MLPPolicy (same parameter names as the stable-baselines zips)."""
 
@@ -61,9 +86,10 @@ class ActorCritic(object):
         return [self.p[k] for k in sorted(self.p)]
 
     def _mlp(self, net, x):
-        t = self.torch   # addmm: the bias rides in the GEMM epilogue (one kernel per layer instead of two)
-        h = t.relu(t.addmm(self.p["model/%s_fc0/b:0" % net], x, self.p["model/%s_fc0/w:0" % net]))
-        h = t.relu(t.addmm(self.p["model/%s_fc1/b:0" % net], h, self.p["model/%s_fc1/w:0" % net]))
+        t = self.torch   # bias and ReLU ride in the GEMM epilogue (hipBLASLt): one kernel per layer instead of three
+        f = _linear_relu(t)
+        h = f(x, self.p["model/%s_fc0/w:0" % net], self.p["model/%s_fc0/b:0" % net])
+        h = f(h, self.p["model/%s_fc1/w:0" % net], self.p["model/%s_fc1/b:0" % net])
         return t.addmm(self.p["model/%s/b:0" % net], h, self.p["model/%s/w:0" % net])
 
     def mean(self, obs):
@@ -151,5 +177,5 @@ class PPO(object):
                 self.opt.step()
                 if hasattr(self.model, "mark_updated"):
                     self.model.mark_updated()
-                stats.append((float(surr.detach()), float(vf.detach())))
-        return np.mean(stats, axis=0)
+                stats.append(t.stack((surr.detach(), vf.detach())))   # stays on the device: no sync per minibatch
+        return t.stack(stats).mean(dim=0).cpu().numpy()
