@@ -16,29 +16,37 @@ import numpy as np
 from . import policy as pol
 
 
-_LINEAR_RELU = None
+_LINEAR = {}
 
 
-def _linear_relu(torch):
-    """relu(x W + b) as one GEMM with a bias + ReLU epilogue (torch._addmm_activation has no autograd formula, so the
-    backward is spelled out: mask by the saved output, bias gradient = column sums, two GEMMs)."""
-    global _LINEAR_RELU
-    if _LINEAR_RELU is None:
-        class LinearReLU(torch.autograd.Function):
+def _wgrad(torch, x, g):
+    """x^T g for a tall batch: hipBLASLt picks a 32x32 macro-tile for these (K = batch) shapes and fills a third of the
+    chip; a 16-way split over the batch (one bmm + a sum) is 2.5-3x faster on MI355X (100 -> 35 us at 16384 x 160 x 512)."""
+    B = x.shape[0]
+    if B >= 4096 and B % 16 == 0:
+        return torch.bmm(x.view(16, B // 16, x.shape[1]).transpose(1, 2), g.view(16, B // 16, g.shape[1])).sum(0)
+    return x.t() @ g
+
+
+def _linear(torch, relu):
+    """x W + b (optionally ReLU) as one GEMM with a bias (+ ReLU) epilogue; the backward is spelled out because
+    torch._addmm_activation has no autograd formula and to route the weight gradient through _wgrad."""
+    if relu not in _LINEAR:
+        class Linear(torch.autograd.Function):
             @staticmethod
             def forward(ctx, x, w, b):
-                h = torch._addmm_activation(b, x, w)
-                ctx.save_for_backward(x, w, h)
+                h = torch._addmm_activation(b, x, w) if relu else torch.addmm(b, x, w)
+                ctx.save_for_backward(x, w, h if relu else b)
                 return h
 
             @staticmethod
             def backward(ctx, gh):
                 x, w, h = ctx.saved_tensors
-                gz = gh * (h > 0).to(gh.dtype)
+                gz = gh * (h > 0).to(gh.dtype) if relu else gh
                 gx = gz @ w.t() if ctx.needs_input_grad[0] else None
-                return gx, x.t() @ gz, gz.sum(dim=0)
-        _LINEAR_RELU = LinearReLU.apply
-    return _LINEAR_RELU
+                return gx, _wgrad(torch, x, gz.contiguous()), gz.sum(dim=0)
+        _LINEAR[relu] = Linear.apply
+    return _LINEAR[relu]
 
 
 class ActorCritic(object):
@@ -87,10 +95,10 @@ class ActorCritic(object):
 
     def _mlp(self, net, x):
         t = self.torch   # bias and ReLU ride in the GEMM epilogue (hipBLASLt): one kernel per layer instead of three
-        f = _linear_relu(t)
+        f, out = _linear(t, True), _linear(t, False)
         h = f(x, self.p["model/%s_fc0/w:0" % net], self.p["model/%s_fc0/b:0" % net])
         h = f(h, self.p["model/%s_fc1/w:0" % net], self.p["model/%s_fc1/b:0" % net])
-        return t.addmm(self.p["model/%s/b:0" % net], h, self.p["model/%s/w:0" % net])
+        return out(h, self.p["model/%s/w:0" % net], self.p["model/%s/b:0" % net])
 
     def mean(self, obs):
         return self._mlp("pi", obs)
@@ -134,7 +142,9 @@ class PPO(object):
         self.minibatch = int(minibatch)
         self.vf_coef = vf_coef
         self.group = group
-        self.opt = torch.optim.Adam(model.parameters(), lr=lr, eps=adam_eps)
+        params = model.parameters()
+        # one fused multi-tensor kernel per step on the GPU (the default foreach path is ~7 launches, 0.2 ms per step)
+        self.opt = torch.optim.Adam(params, lr=lr, eps=adam_eps, fused=bool(params and params[0].is_cuda))
 
     def _allreduce_grads(self):
         import torch.distributed as dist
