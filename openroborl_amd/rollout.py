@@ -46,6 +46,11 @@ def collect_rollout(env, policy, horizon, obs=None, deterministic=False, generat
         buf["rewards"][k].copy_(rew)
         buf["dones"][k].copy_(done.bool())
     buf["last_obs"] = obs
+    if noise is not None:
+        # log-probability of the sampled actions under the sampling policy: a - mean = std * noise
+        import math
+        std = float(policy.std)
+        buf["logp"] = -0.5 * (noise * noise).sum(dim=-1) - 12.0 * math.log(std * math.sqrt(2.0 * math.pi))
     return buf
 
 

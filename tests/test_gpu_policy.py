@@ -125,3 +125,19 @@ def test_fused_gae_matches_torch(shape):
             a2, r2 = rollout.gae_fused(rew, vp, dones, 0.95, 0.95, bootstrap=bootstrap, normalize=True, eps=1e-8)
             np.testing.assert_allclose(a2.cpu().numpy(), rollout.normalize_per_robot(a0, eps=1e-8).cpu().numpy(), rtol=2e-4, atol=2e-5)
             np.testing.assert_allclose(r2.cpu().numpy(), r0.cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_rollout_logp_matches_learner_log_prob():
+    """The log-probabilities derived from the rollout noise equal ActorCritic.log_prob at the sampling parameters."""
+    import torch
+    from openroborl_amd import ppo, rollout
+    from openroborl_amd.env import VecQuadrupedEnv
+    dev = torch.device("cuda", 0)
+    env = VecQuadrupedEnv(task_name="imitation_learning_laikago", num_robot=128, seed=2, device=dev)
+    model = ppo.ActorCritic(dev, seed=3).enable_fused()
+    g = torch.Generator(device=dev).manual_seed(0)
+    buf = rollout.collect_rollout(env, model, 4, obs=env.reset(), generator=g)
+    with torch.no_grad():
+        lp = model.log_prob(buf["obs"].reshape(-1, 160), buf["actions"].reshape(-1, 12))
+    np.testing.assert_allclose(buf["logp"].reshape(-1).cpu().numpy(), lp.cpu().numpy(), atol=2e-3, rtol=1e-4)
+    env.close()

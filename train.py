@@ -65,7 +65,8 @@ def main():
         adv, ret = rollout.gae_fused(buf["rewards"], buf["vpred"], buf["dones"], 0.95, 0.95, bootstrap=boot, normalize=True, eps=1e-8)
         T, n = buf["rewards"].shape
         surr, vf = learner.update(buf["obs"].reshape(T * n, -1), buf["actions"].reshape(T * n, -1), adv.reshape(-1),
-                                  ret.reshape(-1), epochs=args.epochs, generator=gen)
+                                  ret.reshape(-1), old_logp=buf["logp"].reshape(-1) if "logp" in buf else None,
+                                  epochs=args.epochs, generator=gen)
         samples += T * n * world
         rets, lens, ts, dropped = odist.gather_env_episodes(env, args.horizon)
         if rank == 0 and (it % 10 == 0 or it == args.iters - 1):
