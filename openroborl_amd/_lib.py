@@ -13,7 +13,7 @@ from . import _abi
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(PKG_DIR, "csrc", "orr_kernels.hip")
 SRC_POLICY = os.path.join(PKG_DIR, "csrc", "orr_policy.hip")
-DEPS = [SRC, SRC_POLICY, os.path.join(PKG_DIR, "csrc", "orr_device.h"),
+DEPS = [SRC, SRC_POLICY] + [os.path.join(PKG_DIR, "csrc", h) for h in ("orr_device.h", "orr_robot_io.h", "orr_physics.h", "orr_task.h")] + [
         os.path.join(os.path.dirname(PKG_DIR), "include", "openroborl_hip.h"),
         os.path.join(os.path.dirname(PKG_DIR), "include", "openroborl_policy.h")]
 LIB_PATH = os.path.join(PKG_DIR, "libopenroborl_hip.so")

@@ -128,7 +128,7 @@ struct LegExchange {  // per leg, hand-over between the lanes (parts) of a leg i
   float b[4];         // tau_k - C_k
   float I[6], h[3], m, f[6];  // composite of the whole leg about O (part 0) and its bias force
 };
-struct LegSolve {   // per leg, written by the leg lanes, read by the row lanes (see leg_dynamics in orr_kernels.hip)
+struct LegSolve {   // per leg, written by the leg lanes, read by the row lanes (see leg_dynamics in orr_physics.h)
   float T[3][6];    // F H^-1: column k = base wrench (angular; linear, world axes, about the base COM) per unit of joint k
   float Hi[6];      // H^-1 of the leg's 3x3 joint-space inertia (00 11 22 01 02 12)
 };

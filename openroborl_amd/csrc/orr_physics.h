@@ -1,0 +1,769 @@
+// orr_physics.h -- one physics sub-step: leg dynamics, constraint rows, Gauss-Seidel sweeps, integration (pybullet stepSimulation)
+// (device code of libopenroborl_hip.so, included by orr_kernels.hip after orr_device.h; see DESIGN.md sections 3-5)
+#pragma once
+
+// ================================================================================================
+// physics sub-step (pybullet stepSimulation, quadruped_gym_env.py:223)
+// ================================================================================================
+
+// Cholesky factor of a 6x6 SPD matrix (row-major full storage); L packed row-wise, (i,j) -> i(i+1)/2 + j
+__device__ __forceinline__ void chol6(const float A[36], float L[21], float invdiag[6]) {
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+#pragma unroll
+    for (int j = 0; j <= i; j++) {
+      float s = A[i * 6 + j];
+#pragma unroll
+      for (int k = 0; k < j; k++) s -= L[i * (i + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
+      if (i == j) {
+        const float rs = rsqrtf(s);
+        L[i * (i + 1) / 2 + j] = s * rs;
+        invdiag[i] = rs;
+      } else {
+        L[i * (i + 1) / 2 + j] = s * invdiag[j];
+      }
+    }
+  }
+}
+__device__ __forceinline__ void chol6_solve(const float L[21], const float invdiag[6], const float b[6], float x[6]) {
+  float y[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    float s = b[i];
+#pragma unroll
+    for (int k = 0; k < i; k++) s -= L[i * (i + 1) / 2 + k] * y[k];
+    y[i] = s * invdiag[i];
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; i--) {
+    float s = y[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; k++) s -= L[k * (k + 1) / 2 + i] * x[k];
+    x[i] = s * invdiag[i];
+  }
+}
+
+// Per-lane constants, loaded once per launch and kept in registers over the 33 sub-steps (a lone wave per SIMD cannot
+// hide the LDS round trips of re-reading them every sub-step).  Lane (leg = lane & 3, part = (lane >> 2) & 3) walks the
+// joints 0..min(part, 2) of its leg and owns link `part` (part 3: an idle copy with zero inertia): the chain constants of
+// the joints beyond its own are zeroed, so that walking "through" them is the identity.
+struct LegConst {
+  float r[3][3], jdir[3], joff[3];  // chain: joint origin in the parent frame, internal angle = jdir * (q - joff)
+  float com[3], m, Ic[6];           // own link: COM in the link frame, mass, inertia about the COM (xx yy zz xy xz yz)
+};
+__device__ static void load_leg_const(const Shared& S, int lane, LegConst& K) {
+  const int leg = lane & 3, part = (lane >> 2) & 3, own = 3 * leg + (part < 3 ? part : 2);
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const int j = 3 * leg + k;
+    const bool on = k <= part;
+#pragma unroll
+    for (int i = 0; i < 3; i++) K.r[k][i] = on ? S.m.joint_pos[j][i] : 0.0f;
+    K.jdir[k] = on ? S.m.jdir[j] : 0.0f;
+    K.joff[k] = S.m.joff[j];
+  }
+  const bool real = part < 3;
+#pragma unroll
+  for (int i = 0; i < 3; i++) K.com[i] = real ? S.m.link_com[own][i] : 0.0f;
+#pragma unroll
+  for (int i = 0; i < 6; i++) K.Ic[i] = real ? S.Ic[own + 1][i] : 0.0f;
+  K.m = real ? S.mass[own + 1] : 0.0f;
+}
+
+// ================================================================================================
+// Forward dynamics of the floating base + 4 x 3-link legs.
+//
+// Formulation (mathematically the articulated-body result; tools/crba_proto.py checks it against the oracle's ABA):
+// everything in world-aligned axes with the origin O at the base COM, spatial vectors (angular; linear),
+//   M = [[ Ic_tot , F ],     F_j = Ic_j S_j (composite inertia of the subtree of joint j times its motion axis),
+//        [ F^T    , H ]]     H block-diagonal: one symmetric 3x3 per leg
+//   bias forces by recursive Newton-Euler with zero accelerations (C per joint, p for the base)
+//   T_L = F_L H_L^-1;  A0 = Ic_tot - sum_L T_L F_L^T;  a0 = -A0^-1 (p + sum_L T_L (tau_L - C_L))
+//   qdd_L = H_L^-1 (tau_L - C_L - F_L^T a0)
+// A leg is a chain of three joints about coordinate axes of the link frames (hip x, upper / lower leg y), so its
+// world joint axis is a column of the link rotation.  What the constraint rows need afterwards is small and goes to
+// LDS: T_L (6x3), H_L^-1 per leg and A0^-1 (LegSolve / Shared::IA0inv) - the impulse response of a row is then
+//   da0 = A0^-1 (Jb - T_L jl);  dqdd_L = H_L^-1 jl - T_L^T da0;  dqdd_K = -T_K^T da0  (K != L).
+// Lane (leg = lane & 3, part = (lane >> 2) & 3): all lanes of a leg walk down its joints, but each computes the costly
+// per-link terms (inertia about O, bias force) only for link `part`; subtree sums run over the parts with DPP row
+// shifts, F / H / bias torques of the three joints are exchanged through LDS (LegExchange), and from there on every
+// lane of the leg holds the whole leg again (the base system is solved redundantly in all lanes).
+// ================================================================================================
+
+// R S R^T for a symmetric S (xx yy zz xy xz yz) and a general rotation R (row-major)
+__device__ __forceinline__ void rot_sym_full(const float R[9], const float S[6], float O[6]) {
+  float T[9];  // T = R S
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    T[3 * i] = R[3 * i] * S[0] + R[3 * i + 1] * S[3] + R[3 * i + 2] * S[4];
+    T[3 * i + 1] = R[3 * i] * S[3] + R[3 * i + 1] * S[1] + R[3 * i + 2] * S[5];
+    T[3 * i + 2] = R[3 * i] * S[4] + R[3 * i + 1] * S[5] + R[3 * i + 2] * S[2];
+  }
+  O[0] = T[0] * R[0] + T[1] * R[1] + T[2] * R[2];
+  O[1] = T[3] * R[3] + T[4] * R[4] + T[5] * R[5];
+  O[2] = T[6] * R[6] + T[7] * R[7] + T[8] * R[8];
+  O[3] = T[0] * R[3] + T[1] * R[4] + T[2] * R[5];
+  O[4] = T[0] * R[6] + T[1] * R[7] + T[2] * R[8];
+  O[5] = T[3] * R[6] + T[4] * R[7] + T[5] * R[8];
+}
+// spatial inertia about O (I symmetric, first moment h, mass m) times a spatial motion vector (w; v)
+__device__ __forceinline__ void spatial_inertia_mul(const float I[6], const float h[3], float m, const float w[3], const float v[3],
+                                                    float oa[3], float ol[3]) {
+  float t[3], u[3];
+  symv(I, w, t);
+  cross3(h, v, u);
+  oa[0] = t[0] + u[0]; oa[1] = t[1] + u[1]; oa[2] = t[2] + u[2];
+  cross3(h, w, u);
+  ol[0] = m * v[0] - u[0]; ol[1] = m * v[1] - u[1]; ol[2] = m * v[2] - u[2];
+}
+
+// one joint on the way down the leg: pose of the link behind it, its motion axis S = (s; d x s) about O, spatial
+// velocity and velocity-product acceleration.  For a joint beyond the lane's own link the constants are zero and the
+// step is the identity (angle 0, rate 0, offset 0).
+template <int AX>
+__device__ __forceinline__ void joint_down(const Shared& S, const LegConst& K, int k, int j, float Rw[9], float d[3], float Vw[3],
+                                           float Vv[3], float Aa[3], float Al[3], float s[3], float sv[3], float& ad_out) {
+  const float a = K.jdir[k] * (S.s[O(Q) + j] - K.joff[k]);
+  const float ad = K.jdir[k] * S.s[O(QD) + j];
+  ad_out = ad;
+  float sn, cs;
+  joint_sincos(a, &sn, &cs);
+  // pose: d += Rw_parent r;  Rw = Rw_parent R(a)
+  {
+    float t[3];
+    mv3(Rw, K.r[k], t);
+    d[0] += t[0]; d[1] += t[1]; d[2] += t[2];
+  }
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const float p0 = Rw[3 * i], p1 = Rw[3 * i + 1], p2 = Rw[3 * i + 2];
+    if (AX == 0) { Rw[3 * i + 1] = cs * p1 + sn * p2; Rw[3 * i + 2] = -sn * p1 + cs * p2; }
+    else { Rw[3 * i] = cs * p0 - sn * p2; Rw[3 * i + 2] = sn * p0 + cs * p2; }
+  }
+  s[0] = Rw[AX]; s[1] = Rw[3 + AX]; s[2] = Rw[6 + AX];
+  cross3(d, s, sv);
+  // V += S ad;  A += V x (S ad)
+  const float ga[3] = {s[0] * ad, s[1] * ad, s[2] * ad}, gl[3] = {sv[0] * ad, sv[1] * ad, sv[2] * ad};
+#pragma unroll
+  for (int i = 0; i < 3; i++) { Vw[i] += ga[i]; Vv[i] += gl[i]; }
+  float t0[3], t1[3], t2[3];
+  cross3(Vw, ga, t0);
+  cross3(Vw, gl, t1);
+  cross3(Vv, ga, t2);
+#pragma unroll
+  for (int i = 0; i < 3; i++) { Aa[i] += t0[i]; Al[i] += t1[i] + t2[i]; }
+}
+
+// x_q + x_{q+1} + x_{q+2} over the lanes of one leg (lane = leg + 4 q): two DPP row shifts, zero beyond the row
+__device__ __forceinline__ float part_suffix_sum(float x) {
+  const int v = __float_as_int(x);
+  const float a = __int_as_float(__builtin_amdgcn_update_dpp(0, v, 0x104, 0xF, 0xF, true));  // row_shl:4
+  const float b = __int_as_float(__builtin_amdgcn_update_dpp(0, v, 0x108, 0xF, 0xF, true));  // row_shl:8
+  return x + a + b;
+}
+
+__device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst& K, int lane) {
+  const int leg = lane & 3, part = (lane >> 2) & 3;
+  const bool first = lane < 4;            // the leg's results are written by its part-0 lane
+  float Rb[9];  // kinematic base frame -> world: kept current by base_rotation() (after every change of the quaternion)
+#pragma unroll
+  for (int i = 0; i < 9; i++) Rb[i] = S.Rb[i];
+  const float wb[3] = {S.s[O(ANGVEL)], S.s[O(ANGVEL) + 1], S.s[O(ANGVEL) + 2]};
+  const float vb[3] = {S.s[O(LINVEL)], S.s[O(LINVEL) + 1], S.s[O(LINVEL) + 2]};
+  // ---- way down: this lane stops at its own link (joints beyond it are identity steps) ----
+  float Rw[9], d[3] = {0, 0, 0}, Vw[3] = {wb[0], wb[1], wb[2]}, Vv[3] = {vb[0], vb[1], vb[2]};
+  float Aa[3] = {0, 0, 0}, Al[3] = {0, 0, 0};
+  float s0[3], sv0[3], s1[3], sv1[3], s2[3], sv2[3], ad0, ad1, ad2;
+#pragma unroll
+  for (int i = 0; i < 9; i++) Rw[i] = Rb[i];
+  joint_down<0>(S, K, 0, 3 * leg, Rw, d, Vw, Vv, Aa, Al, s0, sv0, ad0);
+  joint_down<1>(S, K, 1, 3 * leg + 1, Rw, d, Vw, Vv, Aa, Al, s1, sv1, ad1);
+  joint_down<1>(S, K, 2, 3 * leg + 2, Rw, d, Vw, Vv, Aa, Al, s2, sv2, ad2);
+  // own joint: axis and rate
+  float so[3], svo[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    so[i] = part == 0 ? s0[i] : (part == 1 ? s1[i] : s2[i]);
+    svo[i] = part == 0 ? sv0[i] : (part == 1 ? sv1[i] : sv2[i]);
+  }
+  const float ado = part == 0 ? ad0 : (part == 1 ? ad1 : ad2);
+  if (lane < 12) {  // pose and joint axis of the own link for the constraint rows
+    LinkCache& L = S.lc[3 * leg + part];
+#pragma unroll
+    for (int i = 0; i < 9; i++) L.Rw[i] = Rw[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) { L.ow[i] = S.s[O(POS) + i] + d[i]; L.s[i] = so[i]; L.sv[i] = svo[i]; }
+  }
+  // ---- own link: spatial inertia about O and bias force f = I A + V x* (I V) ----
+  float I[6], h[3], m = K.m, f[6];
+  {
+    float c[3];
+    mv3(Rw, K.com, c);
+    c[0] += d[0]; c[1] += d[1]; c[2] += d[2];
+    h[0] = m * c[0]; h[1] = m * c[1]; h[2] = m * c[2];
+    rot_sym_full(Rw, K.Ic, I);
+    const float hc = h[0] * c[0] + h[1] * c[1] + h[2] * c[2];
+    I[0] += hc - h[0] * c[0]; I[1] += hc - h[1] * c[1]; I[2] += hc - h[2] * c[2];
+    I[3] -= h[0] * c[1]; I[4] -= h[0] * c[2]; I[5] -= h[1] * c[2];
+    float Pa[3], Pl[3], Fa[3], Fl[3], t0[3], t1[3], t2[3];
+    spatial_inertia_mul(I, h, m, Vw, Vv, Pa, Pl);
+    spatial_inertia_mul(I, h, m, Aa, Al, Fa, Fl);
+    cross3(Vw, Pa, t0);
+    cross3(Vv, Pl, t1);
+    cross3(Vw, Pl, t2);
+#pragma unroll
+    for (int i = 0; i < 3; i++) { f[i] = Fa[i] + t0[i] + t1[i]; f[3 + i] = Fl[i] + t2[i]; }
+  }
+  // ---- way up: composite inertia and force sum of the subtree behind the own joint (sum over the leg's later parts) ----
+#pragma unroll
+  for (int i = 0; i < 6; i++) { I[i] = part_suffix_sum(I[i]); f[i] = part_suffix_sum(f[i]); }
+#pragma unroll
+  for (int i = 0; i < 3; i++) h[i] = part_suffix_sum(h[i]);
+  m = part_suffix_sum(m);
+  // own column of F and of the leg's joint-space inertia H (entries H[i][part], i <= part), own bias torque
+  {
+    float Fo[6];
+    spatial_inertia_mul(I, h, m, so, svo, &Fo[0], &Fo[3]);
+    const float bo = S.tau[3 * leg + (part < 3 ? part : 2)] - (dot3(so, &f[0]) + dot3(svo, &f[3]));
+    const float hc0 = dot3(s0, &Fo[0]) + dot3(sv0, &Fo[3]), hc1 = dot3(s1, &Fo[0]) + dot3(sv1, &Fo[3]);
+    const float hc2 = dot3(s2, &Fo[0]) + dot3(sv2, &Fo[3]);
+    if (lane < 12) {
+      LegExchange& X = S.legx[leg];
+#pragma unroll
+      for (int i = 0; i < 6; i++) X.F[part][i] = Fo[i];
+      X.b[part] = bo;
+      X.Hc[part][0] = hc0; X.Hc[part][1] = hc1; X.Hc[part][2] = hc2;
+      if (part == 0) {  // composite of the whole leg
+#pragma unroll
+        for (int i = 0; i < 6; i++) { X.I[i] = I[i]; X.f[i] = f[i]; }
+#pragma unroll
+        for (int i = 0; i < 3; i++) X.h[i] = h[i];
+        X.m = m;
+      }
+    }
+  }
+  WSYNC();
+  // ---- every lane of the leg: all three F columns, H, the leg composite ----
+  float F[3][6], b[3], GI[6], Gh[3], Gm, Gf[6];
+  float H00, H01, H02, H11, H12, H22;
+  {
+    const LegExchange& X = S.legx[leg];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) F[k][i] = X.F[k][i];
+      b[k] = X.b[k];
+    }
+    H00 = X.Hc[0][0]; H01 = X.Hc[1][0]; H11 = X.Hc[1][1]; H02 = X.Hc[2][0]; H12 = X.Hc[2][1]; H22 = X.Hc[2][2];
+#pragma unroll
+    for (int i = 0; i < 6; i++) { GI[i] = X.I[i]; Gf[i] = X.f[i]; }
+#pragma unroll
+    for (int i = 0; i < 3; i++) Gh[i] = X.h[i];
+    Gm = X.m;
+  }
+  float Hi[6];  // H^-1, symmetric (00 11 22 01 02 12), by cofactors
+  {
+    const float c00 = H11 * H22 - H12 * H12, c01 = H02 * H12 - H01 * H22, c02 = H01 * H12 - H02 * H11;
+    const float c11 = H00 * H22 - H02 * H02, c12 = H01 * H02 - H00 * H12, c22 = H00 * H11 - H01 * H01;
+    const float idet = __builtin_amdgcn_rcpf(H00 * c00 + H01 * c01 + H02 * c02);
+    Hi[0] = c00 * idet; Hi[1] = c11 * idet; Hi[2] = c22 * idet; Hi[3] = c01 * idet; Hi[4] = c02 * idet; Hi[5] = c12 * idet;
+  }
+  float T[3][6];  // T = F H^-1 (column k of T = sum_m F_m Hi[m][k])
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    T[0][i] = F[0][i] * Hi[0] + F[1][i] * Hi[3] + F[2][i] * Hi[4];
+    T[1][i] = F[0][i] * Hi[3] + F[1][i] * Hi[1] + F[2][i] * Hi[5];
+    T[2][i] = F[0][i] * Hi[4] + F[1][i] * Hi[5] + F[2][i] * Hi[2];
+  }
+  if (first) {
+    LegSolve& Q = S.leg[leg];
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+      for (int i = 0; i < 6; i++) Q.T[k][i] = T[k][i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) Q.Hi[i] = Hi[i];
+  }
+  // this leg's part of the base equation: composite inertia minus T F^T, force p + T b
+  float Iacc[6], Hacc[9], Macc[6], pacc[6];
+#define TFT(i, j) (T[0][i] * F[0][j] + T[1][i] * F[1][j] + T[2][i] * F[2][j])
+  Iacc[0] = GI[0] - TFT(0, 0); Iacc[1] = GI[1] - TFT(1, 1); Iacc[2] = GI[2] - TFT(2, 2);
+  Iacc[3] = GI[3] - TFT(0, 1); Iacc[4] = GI[4] - TFT(0, 2); Iacc[5] = GI[5] - TFT(1, 2);
+  Macc[0] = Gm - TFT(3, 3); Macc[1] = Gm - TFT(4, 4); Macc[2] = Gm - TFT(5, 5);
+  Macc[3] = -TFT(3, 4); Macc[4] = -TFT(3, 5); Macc[5] = -TFT(4, 5);
+  // top-right block: skew(h) - (T F^T)[a][3 + b]
+  Hacc[0] = -TFT(0, 3);          Hacc[1] = -Gh[2] - TFT(0, 4); Hacc[2] = Gh[1] - TFT(0, 5);
+  Hacc[3] = Gh[2] - TFT(1, 3);   Hacc[4] = -TFT(1, 4);         Hacc[5] = -Gh[0] - TFT(1, 5);
+  Hacc[6] = -Gh[1] - TFT(2, 3);  Hacc[7] = Gh[0] - TFT(2, 4);  Hacc[8] = -TFT(2, 5);
+#undef TFT
+#pragma unroll
+  for (int i = 0; i < 6; i++) pacc[i] = Gf[i] + T[0][i] * b[0] + T[1][i] * b[1] + T[2][i] * b[2];
+  // base: sum the four leg contributions (butterfly over lane bits 0, 1 = DPP quad permutes, fused into the adds)
+#pragma unroll
+  for (int i = 0; i < 6; i++) { Iacc[i] = quad_sum(Iacc[i]); Macc[i] = quad_sum(Macc[i]); pacc[i] = quad_sum(pacc[i]); }
+#pragma unroll
+  for (int i = 0; i < 9; i++) Hacc[i] = quad_sum(Hacc[i]);
+  float a0[6];
+  {
+    float A6[36], pA0[6], Ibw[6];
+    const float m0 = S.mass[0];
+    rot_sym_full(Rb, S.Ic[0], Ibw);
+    float n[3], fb[3] = {m0 * vb[0], m0 * vb[1], m0 * vb[2]}, t1[3], t2[3];
+    symv(Ibw, wb, n);
+    cross3(wb, n, t1);
+    cross3(wb, fb, t2);
+    // Bullet base damping (btMultiBody): torque k_a I w, force k_l m v on the bias side
+    const float kl = S.s[O(BASE_DAMPING)], ka = S.s[O(BASE_DAMPING) + 1];
+#pragma unroll
+    for (int i = 0; i < 3; i++) { pA0[i] = t1[i] + ka * n[i] + pacc[i]; pA0[3 + i] = t2[i] + kl * fb[i] + pacc[3 + i]; }
+    float Ib[9], Im[9], Mm[9];
+    sym_to_m3(Ibw, Ib);
+    sym_to_m3(Iacc, Im);
+    sym_to_m3(Macc, Mm);
+#pragma unroll
+    for (int a_ = 0; a_ < 3; a_++)
+#pragma unroll
+      for (int b_ = 0; b_ < 3; b_++) {
+        A6[a_ * 6 + b_] = Ib[a_ * 3 + b_] + Im[a_ * 3 + b_];
+        A6[a_ * 6 + 3 + b_] = Hacc[a_ * 3 + b_];
+        A6[(3 + a_) * 6 + b_] = Hacc[b_ * 3 + a_];
+        A6[(3 + a_) * 6 + 3 + b_] = Mm[a_ * 3 + b_] + (a_ == b_ ? m0 : 0.0f);
+      }
+    float Lc[21], idg[6], nb[6];
+    chol6(A6, Lc, idg);
+#pragma unroll
+    for (int i = 0; i < 6; i++) nb[i] = -pA0[i];
+    chol6_solve(Lc, idg, nb, a0);
+    // explicit inverse for the impulse responses: lane c (< 6) solves for unit column c
+    float e[6], x[6];
+    const int col = lane % 6;
+#pragma unroll
+    for (int i = 0; i < 6; i++) e[i] = (i == col) ? 1.0f : 0.0f;
+    chol6_solve(Lc, idg, e, x);
+    if (lane < 6) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) S.IA0inv[i * 6 + col] = x[i];
+    }
+  }
+  // joint accelerations qdd = H^-1 (b - F^T a0); written as the unconstrained velocities u* = u + dt udot by the lane
+  // that owns the joint (it has the joint rate)
+  const float dt = P.cfg.sim_dt;
+  {
+    float g[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+      g[k] = b[k] - (F[k][0] * a0[0] + F[k][1] * a0[1] + F[k][2] * a0[2] + F[k][3] * a0[3] + F[k][4] * a0[4] + F[k][5] * a0[5]);
+    const float q0 = Hi[0] * g[0] + Hi[3] * g[1] + Hi[4] * g[2], q1 = Hi[3] * g[0] + Hi[1] * g[1] + Hi[5] * g[2];
+    const float q2 = Hi[4] * g[0] + Hi[5] * g[1] + Hi[2] * g[2];
+    if (lane < 12) S.ustar[6 + 3 * leg + part] = ado + dt * (part == 0 ? q0 : (part == 1 ? q1 : q2));
+  }
+  if (lane == 0) {
+    // classical base acceleration (Bullet: vdot = a_lin + w x v); gravity = uniform-field offset
+    float wxv[3];
+    cross3(wb, vb, wxv);
+    S.ustar[0] = wb[0] + dt * a0[0]; S.ustar[1] = wb[1] + dt * a0[1]; S.ustar[2] = wb[2] + dt * a0[2];
+    S.ustar[3] = vb[0] + dt * (a0[3] + wxv[0]);
+    S.ustar[4] = vb[1] + dt * (a0[4] + wxv[1]);
+    S.ustar[5] = vb[2] + dt * (a0[5] + wxv[2] + P.cfg.gravity_z);
+  }
+}
+
+// One constraint row (state of a row lane for one of its two banks)
+struct Row {
+  bool active;
+  int leg, nrm_slot, warm;
+  float Jb[6], jl[3];          // Jacobian: base part (world angular, linear) and the 3 joints of `leg`
+  float rhs, jdi, lam, w, lam_n;
+  float lo_c, hi_c, mu_e;      // bounds = constant part -/+ mu_e * lambda_normal
+};
+
+__device__ __forceinline__ float row_dot(const Row& R, const float* Wr) {
+  float a = R.Jb[0] * Wr[0] + R.Jb[1] * Wr[1] + R.Jb[2] * Wr[2] + R.Jb[3] * Wr[3] + R.Jb[4] * Wr[4] + R.Jb[5] * Wr[5];
+  a += R.jl[0] * Wr[6 + 3 * R.leg] + R.jl[1] * Wr[6 + 3 * R.leg + 1] + R.jl[2] * Wr[6 + 3 * R.leg + 2];
+  return a;
+}
+
+// Jacobian, right-hand side (not yet scaled by 1/diag) and bounds of row slot `slot`
+__device__ __forceinline__ void row_setup(const Shared& S, const orr_config& cfg, int slot, bool enable, float dt, float inv_dt,
+                                          float erp_dt, Row& R) {
+  R.active = false; R.leg = 0; R.nrm_slot = -1; R.warm = -1;
+#pragma unroll
+  for (int i = 0; i < 6; i++) R.Jb[i] = 0.0f;
+  R.jl[0] = R.jl[1] = R.jl[2] = 0.0f;
+  R.rhs = 0.0f; R.jdi = 0.0f; R.lam = 0.0f; R.w = 0.0f; R.lam_n = 0.0f;
+  float lo = 0.0f, hi = 0.0f, mu = 0.0f;
+  if (slot < 4) {
+    R.leg = slot;
+    const float fr = S.s[O(KNEE_FRICTION) + R.leg];
+    R.active = fr > 0.0f;
+    R.jl[2] = 1.0f;
+    lo = -fr * dt; hi = fr * dt;
+    R.rhs = -S.ustar[6 + 3 * R.leg + 2];
+  } else if (slot < 16) {
+    const int j = slot - 4;
+    R.leg = j / 3;
+    const int kk = j - 3 * R.leg;
+    const float a = S.m.jdir[j] * (S.s[O(Q) + j] - S.m.joff[j]);
+    const float pen_lo = a - S.m.joint_lo[j], pen_hi = S.m.joint_hi[j] - a;
+    const bool use_lo = pen_lo < cfg.limit_activation;
+    const bool use_hi = (!use_lo) && pen_hi < cfg.limit_activation;
+    R.active = use_lo || use_hi;
+    const float sgn = use_lo ? 1.0f : -1.0f, pen = use_lo ? pen_lo : pen_hi;
+    R.jl[0] = kk == 0 ? sgn : 0.0f; R.jl[1] = kk == 1 ? sgn : 0.0f; R.jl[2] = kk == 2 ? sgn : 0.0f;
+    const float rel = sgn * S.ustar[6 + j];
+    lo = 0.0f; hi = 1e30f;
+    R.rhs = pen > 0.0f ? -rel - pen * inv_dt : -rel - pen * erp_dt;
+  } else {
+    int d;
+    if (slot < 20) { R.leg = slot - 16; d = 0; }
+    else { R.leg = (slot - 20) >> 1; d = 1 + ((slot - 20) & 1); }
+    const int leg = R.leg;
+    const LinkCache& Lb = S.lc[3 * leg + 2];
+    float cw[3];
+    mv3(Lb.Rw, S.m.toe_pos[leg], cw);
+    cw[0] += Lb.ow[0]; cw[1] += Lb.ow[1]; cw[2] += Lb.ow[2];
+    const float dist = cw[2] - S.m.toe_radius;
+    R.active = dist < cfg.contact_margin;
+    const float Pw[3] = {cw[0], cw[1], cw[2] - S.m.toe_radius};
+    const float dir[3] = {d == 1 ? 1.0f : 0.0f, d == 2 ? 1.0f : 0.0f, d == 0 ? 1.0f : 0.0f};
+    float rr[3] = {Pw[0] - S.s[O(POS)], Pw[1] - S.s[O(POS) + 1], Pw[2] - S.s[O(POS) + 2]};
+    cross3(rr, dir, &R.Jb[0]);
+    R.Jb[3] = dir[0]; R.Jb[4] = dir[1]; R.Jb[5] = dir[2];
+    float rel = R.Jb[0] * S.ustar[0] + R.Jb[1] * S.ustar[1] + R.Jb[2] * S.ustar[2] + R.Jb[3] * S.ustar[3] + R.Jb[4] * S.ustar[4] + R.Jb[5] * S.ustar[5];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      // velocity of the contact point per unit joint rate: s x (P - o) = s x rr + (d x s), rr and d relative to the base COM
+      const LinkCache& L = S.lc[3 * leg + k];
+      float cr[3];
+      cross3(L.s, rr, cr);
+      R.jl[k] = dir[0] * (cr[0] + L.sv[0]) + dir[1] * (cr[1] + L.sv[1]) + dir[2] * (cr[2] + L.sv[2]);
+      rel += R.jl[k] * S.ustar[6 + 3 * leg + k];
+    }
+    R.warm = 3 * leg + d;
+    if (d == 0) {
+      lo = 0.0f; hi = 1e30f;
+      R.rhs = dist > 0.0f ? -rel - dist * inv_dt : -rel - dist * erp_dt;
+    } else {
+      R.nrm_slot = 16 + leg;
+      mu = S.s[O(FOOT_MU)] * cfg.plane_friction;  // combined friction = product of the two coefficients
+      R.rhs = -rel;
+    }
+  }
+  if (!enable) R.active = false;
+  // bounds as (constant part) + mu * lambda_normal: friction rows have a zero constant part, the others mu = 0;
+  // an inactive row is pinned to zero
+  R.mu_e = (R.active && R.nrm_slot >= 0) ? mu : 0.0f;
+  R.hi_c = (R.active && R.nrm_slot < 0) ? hi : 0.0f;
+  R.lo_c = (R.active && R.nrm_slot < 0) ? lo : 0.0f;
+  if (!R.active) R.rhs = 0.0f;
+}
+
+// impulse response M^-1 J^T of the row (what btMultiBody::calcAccelerationDeltasMultiDof returns) -> W[slot]; 1/diag;
+// warm start.  Block form, see leg_dynamics: da0 = A0^-1 (Jb - T_L jl); dqdd_L = H_L^-1 jl - T_L^T da0; dqdd_K = -T_K^T da0.
+__device__ __forceinline__ void row_response(Shared& S, const orr_config& cfg, Row& R, int slot) {
+  const int leg = R.leg;
+  const LegSolve& QL = S.leg[leg];
+  float fb[6], a0[6], mq[12];
+#pragma unroll
+  for (int i = 0; i < 6; i++) fb[i] = R.Jb[i] - (QL.T[0][i] * R.jl[0] + QL.T[1][i] * R.jl[1] + QL.T[2][i] * R.jl[2]);
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    float sacc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 6; k++) sacc += S.IA0inv[i * 6 + k] * fb[k];
+    a0[i] = sacc;
+  }
+  const float h0 = QL.Hi[0] * R.jl[0] + QL.Hi[3] * R.jl[1] + QL.Hi[4] * R.jl[2];
+  const float h1 = QL.Hi[3] * R.jl[0] + QL.Hi[1] * R.jl[1] + QL.Hi[5] * R.jl[2];
+  const float h2 = QL.Hi[4] * R.jl[0] + QL.Hi[5] * R.jl[1] + QL.Hi[2] * R.jl[2];
+  float diag = 0.0f;
+#pragma unroll
+  for (int L4 = 0; L4 < 4; L4++) {
+    const LegSolve& Q = S.leg[L4];
+    const bool mine = (L4 == leg);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      float t = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 6; i++) t += Q.T[k][i] * a0[i];
+      mq[3 * L4 + k] = (mine ? (k == 0 ? h0 : (k == 1 ? h1 : h2)) : 0.0f) - t;
+    }
+    diag += mine ? (R.jl[0] * mq[3 * L4] + R.jl[1] * mq[3 * L4 + 1] + R.jl[2] * mq[3 * L4 + 2]) : 0.0f;
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) diag += R.Jb[i] * a0[i];
+  if (R.active) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) S.ph.sub.W[slot][i] = a0[i];
+#pragma unroll
+    for (int i = 0; i < 12; i++) S.ph.sub.W[slot][6 + i] = mq[i];
+  }
+  R.jdi = R.active ? __builtin_amdgcn_rcpf(diag) : 0.0f;
+  R.rhs *= R.jdi;
+  R.lam = (R.active && R.warm >= 0) ? cfg.warmstart_factor * S.s[O(LAMBDA) + R.warm] : 0.0f;
+}
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+// The Gauss-Seidel sweeps over the row slots in solve order (btMultiBodyConstraintSolver::solveSingleIteration),
+// Delassus form.  A row lane keeps y = lambda + (rhs - (A lambda)) / diag of its row (the unclamped Gauss-Seidel value),
+// and EVERY lane keeps the impulses of all rows (lam[r], equal in all lanes of the robot).  One row update is
+//   y' = y - Ac[r] lam[r];   lam[r] = broadcast_from_lane_of_r(clamp(y, lo, hi));   y = y' + Ac[r] lam[r]
+// with Ac[r] = -A[row][r] / diag(row) off the diagonal and 0 on it (y of the updated row does not move): four vector
+// instructions (fma, v_med3, v_mov_dpp row_newbcast, fma), three of them on the dependent chain.
+// HAS_B: some robot of the wave has an active joint-limit row (bank B is swept too).
+// Knee and contact rows are swept unconditionally (a row visited for a robot where it is inactive is a no-op: its
+// bounds, 1/diag, lambda and Delassus column are zero); measured 9 % faster than one scalar branch per leg, which also
+// stopped the scheduler from overlapping consecutive row updates.
+template <bool HAS_B>
+__device__ __forceinline__ void pgs_sweeps(int iters, unsigned int mask, int lane, int sub, Row& A, Row& B,
+                                           const float (&AcA)[kMaxRows], const float (&AcB)[kMaxRows], float (&lam)[kMaxRows]) {
+  float yA = A.lam + fmaf(-A.w, A.jdi, A.rhs), yB = B.lam + fmaf(-B.w, B.jdi, B.rhs);
+  const float hiB = B.hi_c, loB = B.lo_c;
+  float mun[4];  // friction rows: d(bound) / d(normal impulse of their toe)
+#pragma unroll
+  for (int g = 0; g < 4; g++) mun[g] = A.nrm_slot == 16 + g ? A.mu_e : 0.0f;
+  float hiE = fmaf(A.mu_e, A.lam_n, A.hi_c), loE = fmaf(-A.mu_e, A.lam_n, A.lo_c);
+  for (int it = 0; it < iters; it++) {
+    auto rowA = [&](auto rc) __attribute__((always_inline)) {
+      constexpr int r = decltype(rc)::value, src = r < 4 ? r : r - 12;
+      const float old = lam[r];
+      const float yp = fmaf(-AcA[r], old, yA);
+      const float sb = bcast_lane<src>(__builtin_amdgcn_fmed3f(yA, loE, hiE), sub);
+      yA = fmaf(AcA[r], sb, yp);
+      lam[r] = sb;
+      if (HAS_B) yB = fmaf(AcB[r], sb - old, yB);
+      if (r >= 16 && r < 20) {  // a normal impulse moved: friction bounds of the rows of that toe follow
+        constexpr int g = r >= 16 && r < 20 ? r - 16 : 0;
+        const float d = sb - old;
+        hiE = fmaf(mun[g], d, hiE); loE = fmaf(-mun[g], d, loE);
+      }
+    };
+    static_for<0, 4>(rowA);
+    if (HAS_B) {
+      static_for<4, 16>([&](auto rc) __attribute__((always_inline)) {
+        constexpr int r = decltype(rc)::value;
+        if ((mask >> r) & 1u) {
+          const float old = lam[r];
+          const float yp = fmaf(-AcB[r], old, yB);
+          const float sb = bcast_lane<r>(__builtin_amdgcn_fmed3f(yB, loB, hiB), sub);
+          yB = fmaf(AcB[r], sb, yp);
+          lam[r] = sb;
+          yA = fmaf(AcA[r], sb - old, yA);
+        }
+      });
+    }
+    static_for<16, 28>(rowA);
+  }
+}
+
+// Delassus columns A[row][r] = J . W[r], kept in registers already scaled for the sweeps: Ac[r] = -A[row][r] / diag(row),
+// 0 on the diagonal; w = (A lambda) of the warm start; lam[r] = warm-start impulse of row r (in every lane).  Knee rows
+// always (an inactive one has a zero impulse response), joint-limit rows one by one, contact rows per leg.
+template <bool HAS_B>
+__device__ __forceinline__ void delassus_columns(const Shared& S, unsigned int mask, int lane, int sub, Row& A, Row& B,
+                                                 float (&AcA)[kMaxRows], float (&AcB)[kMaxRows], float (&lam)[kMaxRows]) {
+#pragma unroll
+  for (int r = 0; r < kMaxRows; r++) { AcA[r] = 0.0f; AcB[r] = 0.0f; lam[r] = 0.0f; }
+  auto column = [&](auto rc) __attribute__((always_inline)) {
+    constexpr int r = decltype(rc)::value;
+    constexpr bool inB = r >= 4 && r < 16;
+    constexpr int src = inB ? r : (r < 4 ? r : r - 12);
+    const float* Wr = S.ph.sub.W[r];
+    const float l0 = bcast_lane<src>(inB ? B.lam : A.lam, sub);
+    lam[r] = l0;
+    const float a = row_dot(A, Wr);
+    A.w += a * l0;
+    AcA[r] = (!inB && lane == src) ? 0.0f : -a * A.jdi;
+    if (r >= 16 && r < 20 && A.nrm_slot == r) A.lam_n = l0;
+    if (HAS_B) {
+      const float b = row_dot(B, Wr);
+      B.w += b * l0;
+      AcB[r] = (inB && lane == src) ? 0.0f : -b * B.jdi;
+    }
+    asm("" : "+v"(AcA[r]), "+v"(AcB[r]));  // keep the scaled value (do not re-derive it inside the sweeps); not volatile:
+                                           // a volatile asm would end the scheduling region and expose every LDS read
+  };
+  static_for<0, 4>(column);
+  if (HAS_B) {
+    static_for<4, 16>([&](auto rc) __attribute__((always_inline)) {
+      if ((mask >> decltype(rc)::value) & 1u) column(rc);
+    });
+  }
+  const unsigned int cm = (mask >> 16) & 0xFu;
+  static_for<0, 4>([&](auto gc) __attribute__((always_inline)) {
+    constexpr int g = decltype(gc)::value;
+    if ((cm >> g) & 1u) {
+      column(std::integral_constant<int, 16 + g>{});
+      column(std::integral_constant<int, 20 + 2 * g>{});
+      column(std::integral_constant<int, 21 + 2 * g>{});
+    }
+  });
+}
+
+// One physics sub-step.  Returns the fall-proxy flag (wave-uniform) when want_fall.
+__device__ static int physics_substep(const KParams& P, Shared& S, const LegConst& K, int lane, int sub, bool want_fall) {
+  const orr_config& cfg = P.cfg;
+  const float dt = cfg.sim_dt, inv_dt = 1.0f / cfg.sim_dt, erp_dt = cfg.contact_erp / cfg.sim_dt;
+  leg_dynamics(P, S, K, lane);  // -> link poses, leg solves, unconstrained velocities u*
+  WSYNC();
+  PT(3);
+  int fall = 0;
+  if (want_fall) {  // termination-only collision proxies (imitation_task.py:536-546)
+    bool hit = false;
+    if (lane < S.m.num_fall) {
+      const int b = S.m.fall_body[lane];
+      const float* Rw = b == 0 ? S.Rb : S.lc[b - 1].Rw;
+      const float oz = b == 0 ? S.s[O(POS) + 2] : S.lc[b - 1].ow[2];
+      const float wz = Rw[6] * S.m.fall_pos[lane][0] + Rw[7] * S.m.fall_pos[lane][1] + Rw[8] * S.m.fall_pos[lane][2];
+      hit = (oz + wz - S.m.fall_radius[lane]) < cfg.contact_margin;
+    }
+    fall = ((__ballot(hit) >> (sub * kLanes)) & ((1ull << (kLanes - 1)) * 2ull - 1ull)) != 0ull;
+  }
+  PT(4);
+
+  // ---------------- constraint rows ----------------
+  // 28 row slots, slot index = solve order:
+  //    0..3   knee joint-friction motors (minitaur.py:1063-1070)
+  //    4..15  joint limits (joint j = slot-4; at most one side can be within limit_activation)
+  //   16..19  toe contact normals, 20..27 pyramid friction (leg = (slot-20)/2, t1 = +x, t2 = +y)
+  // A robot has 16 row lanes holding two banks: bank A = slots 0..3 and 16..27 (lane l -> slot l < 4 ? l : l+12),
+  // bank B = the joint-limit slots 4..15 (lane l -> slot l).  Bank B is skipped unless some robot of the wave has
+  // a joint near its limit.
+  Row A, B;
+  const bool rowlane = lane < 16;
+  row_setup(S, cfg, rowlane ? (lane < 4 ? lane : lane + 12) : 0, rowlane, dt, inv_dt, erp_dt, A);
+  row_setup(S, cfg, (rowlane && lane >= 4) ? lane : 4, rowlane && lane >= 4, dt, inv_dt, erp_dt, B);
+  const unsigned long long balA = __ballot(A.active), balB = __ballot(B.active);
+  const bool anyB = balB != 0ull;  // wave-uniform
+  // union over the robots of this wave of the active slots (a slot visited for a robot where it is inactive is a no-op)
+  unsigned int mask = 0;
+#pragma unroll
+  for (int g = 0; g < kRPW; g++) {
+    const unsigned int a = (unsigned int)(balA >> (g * kLanes)) & 0xFFFFu, b2 = (unsigned int)(balB >> (g * kLanes)) & 0xFFF0u;
+    mask |= (a & 0xFu) | ((a >> 4) << 16) | b2;
+  }
+  PT(5);
+  // ---------------- impulse responses M^-1 J^T, diagonal, warm start ----------------
+  row_response(S, cfg, A, rowlane ? (lane < 4 ? lane : lane + 12) : 0);
+  if (anyB) row_response(S, cfg, B, (rowlane && lane >= 4) ? lane : 4);
+  WSYNC();
+  PT(6);
+  // Delassus columns, then the Gauss-Seidel sweeps; two instantiations: with and without the joint-limit bank
+  float AcA[kMaxRows], AcB[kMaxRows], lam[kMaxRows];
+  if (anyB) {
+    delassus_columns<true>(S, mask, lane, sub, A, B, AcA, AcB, lam);
+    PT(7);
+    pgs_sweeps<true>(cfg.solver_iters, mask, lane, sub, A, B, AcA, AcB, lam);
+  } else {
+    delassus_columns<false>(S, mask, lane, sub, A, B, AcA, AcB, lam);
+    PT(7);
+    pgs_sweeps<false>(cfg.solver_iters, mask, lane, sub, A, B, AcA, AcB, lam);
+  }
+  PT(8);
+  // contact impulses are remembered for the next sub-step's warm start (0 for open contacts)
+  if (lane == 0) {  // warm-start slot 3 leg + d: normal (slot 16 + leg), then the two friction rows (20 + 2 leg, 21 + 2 leg)
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      S.s[O(LAMBDA) + 3 * g] = lam[16 + g];
+      S.s[O(LAMBDA) + 3 * g + 1] = lam[20 + 2 * g];
+      S.s[O(LAMBDA) + 3 * g + 2] = lam[21 + 2 * g];
+    }
+  }
+  // ---------------- velocity update, Bullet coordinate-velocity clamp, semi-implicit Euler ----------------
+  // lane l owns DOF l (v0) and, for l < 2, DOF 16 + l (v1); the new coordinates are written by the owning lane
+  float v0, v1;
+  {
+    float du0 = 0.0f, du1 = 0.0f;
+    const int k1 = lane + 16 < 18 ? lane + 16 : 0;
+    const int k0 = lane < 18 ? lane : 0;
+    auto add_row = [&](auto rc) __attribute__((always_inline)) {
+      constexpr int r = decltype(rc)::value;
+      du0 += S.ph.sub.W[r][k0] * lam[r];
+      if (kLanes < 18) du1 += S.ph.sub.W[r][k1] * lam[r];
+    };
+    static_for<0, 4>(add_row);
+    if (anyB) {
+      static_for<4, 16>([&](auto rc) __attribute__((always_inline)) {
+        if ((mask >> decltype(rc)::value) & 1u) add_row(rc);
+      });
+    }
+    static_for<16, 28>(add_row);
+    const float vmax = cfg.max_coord_velocity;
+    v0 = __builtin_amdgcn_fmed3f(S.ustar[k0] + du0, -vmax, vmax);
+    v1 = __builtin_amdgcn_fmed3f(S.ustar[k1] + du1, -vmax, vmax);
+  }
+  if (kLanes == 16) {
+    // quaternion: exponential map of the world angular velocity (DOFs 0..2, broadcast from their lanes), then normalise
+    const float w0 = bcast_lane<0>(v0, sub), w1 = bcast_lane<1>(v0, sub), w2 = bcast_lane<2>(v0, sub);
+    const float ww = w0 * w0 + w1 * w1 + w2 * w2, h2 = 0.25f * dt * dt * ww;  // h = |w| dt / 2
+    float sc, ch;  // sin(h) / |w| and cos(h)
+    if (h2 < 0.04f) {  // always, unless max_coord_velocity is raised a lot: Taylor series exact to float precision
+      sc = 0.5f * dt * fmaf(h2, fmaf(h2, fmaf(h2, -1.0f / 5040.0f, 1.0f / 120.0f), -1.0f / 6.0f), 1.0f);
+      ch = fmaf(h2, fmaf(h2, fmaf(h2, fmaf(h2, 1.0f / 40320.0f, -1.0f / 720.0f), 1.0f / 24.0f), -0.5f), 1.0f);
+    } else {
+      const float wn = sqrtf(ww);
+      float sh;
+      sincosf(0.5f * wn * dt, &sh, &ch);
+      sc = sh / wn;
+    }
+    const float dq[4] = {w0 * sc, w1 * sc, w2 * sc, ch};
+    float qn[4];
+    qmul(dq, &S.s[O(QUAT)], qn);
+    const float nn = rsqrtf(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+    WSYNC();
+    if (lane < 3) {
+      S.s[O(ANGVEL) + lane] = v0;
+    } else if (lane < 6) {
+      S.s[O(LINVEL) + lane - 3] = v0;
+      S.s[O(POS) + lane - 3] += dt * v0;
+    } else {
+      const int j = lane - 6;
+      const float a = S.m.jdir[j] * (S.s[O(Q) + j] - S.m.joff[j]) + dt * v0;
+      S.s[O(Q) + j] = a * S.m.jdir[j] + S.m.joff[j];
+      S.s[O(QD) + j] = v0 * S.m.jdir[j];
+    }
+    if (lane < 2) {
+      const int j = 10 + lane;
+      const float a = S.m.jdir[j] * (S.s[O(Q) + j] - S.m.joff[j]) + dt * v1;
+      S.s[O(Q) + j] = a * S.m.jdir[j] + S.m.joff[j];
+      S.s[O(QD) + j] = v1 * S.m.jdir[j];
+    }
+    if (lane < 4) S.s[O(QUAT) + lane] = (lane == 0 ? qn[0] : (lane == 1 ? qn[1] : (lane == 2 ? qn[2] : qn[3]))) * nn;
+  } else {
+    // wider lane groups (tuning builds): through LDS
+    if (lane < 18) S.ustar[lane] = v0;
+    WSYNC();
+    const float w0 = S.ustar[0], w1 = S.ustar[1], w2 = S.ustar[2];
+    const float wn = sqrtf(w0 * w0 + w1 * w1 + w2 * w2), half = 0.5f * wn * dt;
+    float sc, ch;
+    if (wn < 1e-12f) { sc = 0.5f * dt; ch = 1.0f; }
+    else { float sh; sincosf(half, &sh, &ch); sc = sh / wn; }
+    float dq[4] = {w0 * sc, w1 * sc, w2 * sc, ch}, qn[4];
+    qmul(dq, &S.s[O(QUAT)], qn);
+    const float nn = rsqrtf(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+    WSYNC();
+    for (int i = lane; i < 22; i += kLanes) {
+      if (i < 3) S.s[O(ANGVEL) + i] = S.ustar[i];
+      else if (i < 6) { S.s[O(LINVEL) + i - 3] = S.ustar[i]; S.s[O(POS) + i - 3] += dt * S.ustar[i]; }
+      else if (i < 18) {
+        const int j = i - 6;
+        const float a = S.m.jdir[j] * (S.s[O(Q) + j] - S.m.joff[j]) + dt * S.ustar[i];
+        S.s[O(Q) + j] = a * S.m.jdir[j] + S.m.joff[j];
+        S.s[O(QD) + j] = S.ustar[i] * S.m.jdir[j];
+      } else {
+        const int q = i - 18;
+        S.s[O(QUAT) + q] = (q == 0 ? qn[0] : (q == 1 ? qn[1] : (q == 2 ? qn[2] : qn[3]))) * nn;
+      }
+    }
+  }
+  WSYNC();
+  PT(9);
+  return fall;
+}

@@ -1,0 +1,159 @@
+// orr_robot_io.h -- per-robot record load / store and the latency ring (Minitaur.receive_obs / _get_delay_obs)
+// (device code of libopenroborl_hip.so, included by orr_kernels.hip after orr_device.h; see DESIGN.md sections 3-5)
+#pragma once
+
+// ================================================================================================
+// load / store of the per-robot record
+// ================================================================================================
+__device__ static void refresh_mass(const DevModel& gm, Shared& S, int lane) {
+  // randomised mass properties (controllable_env_randomizer_from_config.py:193-222,309-335)
+  if (lane < 13) {
+    const int g = gm.group[lane];
+    const float mr = S.s[O(MASS_RATIO) + g], ir = S.s[O(INERTIA_RATIO) + g];
+    S.mass[lane] = gm.mass[lane] * mr;
+#pragma unroll
+    for (int k = 0; k < 6; k++) S.Ic[lane][k] = gm.inertia[lane][k] * ir + gm.inertia_pa[lane][k] * mr;
+  }
+}
+
+__device__ static void load_robot(const KParams& P, const float* rec, Shared& S, int lane) {
+  for (int i = lane; i < kHead; i += kLanes) S.s[i] = rec[i];
+  WSYNC();
+  const DevModel& gm = P.tab->model[geti(S, O(ROBOT_TYPE))];
+  const float* mp = reinterpret_cast<const float*>(&gm.hot);
+  float* dst = reinterpret_cast<float*>(&S.m);
+  for (int i = lane; i < kModelLdsWords; i += kLanes) dst[i] = mp[i];
+  refresh_mass(gm, S, lane);
+  WSYNC();
+}
+
+__device__ static void store_robot(float* rec, const Shared& S, int lane, bool valid) {
+  if (valid)
+    for (int i = lane; i < O(RING); i += kLanes) rec[i] = S.s[i];
+}
+
+// ================================================================================================
+// latency ring (minitaur.py:127,313-357) -- lives in global memory, lane k owns word k of an entry
+// ================================================================================================
+__device__ static void ctrl_obs(const KParams& P, const float* rec, Shared& S, int lane) {
+  const float lat = S.s[O(LATENCY)], dt = P.cfg.sim_dt;
+  const int len = geti(S, O(RING_LEN)), head = geti(S, O(RING_HEAD));
+  int k0 = 0, k1 = 0;
+  float al = 0.0f;
+  if (!(lat <= 0.0f || len == 1)) {  // Minitaur._get_delay_obs (minitaur.py:336-357)
+    int n = (int)(lat / dt);
+    if (n + 1 >= len) { k0 = k1 = len - 1; }
+    else { k0 = n; k1 = n + 1; al = (lat - n * dt) / dt; }
+  }
+  const int i0 = (head - k0 + 2 * ORR_RING_DEPTH) % ORR_RING_DEPTH, i1 = (head - k1 + 2 * ORR_RING_DEPTH) % ORR_RING_DEPTH;
+  for (int i = lane; i < 19; i += kLanes) {
+    float e0 = rec[O(RING) + i0 * ORR_RING_ENTRY + i], e1 = rec[O(RING) + i1 * ORR_RING_ENTRY + i];
+    S.co[i] = (k0 == k1) ? e0 : (1.0f - al) * e0 + al * e1;
+  }
+  WSYNC();
+}
+
+// Orientation relative to the initial one (minitaur.py:325-331) and its rotation matrix (kinematic base frame -> world)
+// -> Shared::Rb.  Called after every change of the base quaternion; the caller syncs.
+__device__ __forceinline__ void base_rotation(Shared& S, int lane, float rel[4], float Rb[9]) {
+  float qi[4];
+  qinv(S.m.init_quat, qi);
+  qmul(&S.s[O(QUAT)], qi, rel);
+  q_to_mat(rel, Rb);
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) S.Rb[i] = Rb[i];
+  }
+}
+
+// Minitaur.receive_obs + get_true_obs (minitaur.py:304-334): push the true observation
+__device__ static void receive_obs(float* rec, Shared& S, int lane, bool valid) {
+  const int head = (geti(S, O(RING_HEAD)) + 1) % ORR_RING_DEPTH, len = geti(S, O(RING_LEN));
+  float rel[4], Rb[9], rate[3];
+  base_rotation(S, lane, rel, Rb);
+  mtv3(Rb, &S.s[O(ANGVEL)], rate);  // get_true_base_rpy_rate (minitaur.py:640-672): angular velocity in the base frame
+  for (int i = lane; i < ORR_RING_ENTRY; i += kLanes) {
+    float val = 0.0f;
+    if (i < 12) {
+      int j = S.m.joint_of_motor[i];
+      val = (S.s[O(Q) + j] - S.m.motor_offset[i]) * S.m.motor_dir[i];  // get_true_motor_angles (:543-553)
+    } else if (i < 16) {
+      val = i == 12 ? rel[0] : (i == 13 ? rel[1] : (i == 14 ? rel[2] : rel[3]));
+    } else if (i < 19) {
+      val = i == 16 ? rate[0] : (i == 17 ? rate[1] : rate[2]);
+    }
+    if (valid) rec[O(RING) + head * ORR_RING_ENTRY + i] = val;
+  }
+  WSYNC();
+  if (lane == 0) {
+    seti(S, O(RING_HEAD), head);
+    seti(S, O(RING_LEN), len + 1 > ORR_RING_DEPTH ? ORR_RING_DEPTH : len + 1);
+  }
+  WSYNC();
+}
+
+// Sub-step fast path of (receive_obs; ctrl_obs): the ring entries that the control observation after the next push will
+// need are already in the ring before the physics sub-step (all but the pushed one), so their loads are issued early
+// (ring_prefetch) and consumed after the sub-step (ring_push_and_ctrl_obs); the global-memory latency is hidden.
+struct RingFetch {
+  float e0[2], e1[2];  // words lane and 16 + lane of the two entries being blended
+  float al;
+  bool new0, new1, same;  // entry k is the one about to be pushed
+};
+struct RingLatency {  // per-episode constants of Minitaur._get_delay_obs (minitaur.py:336-357)
+  int n;       // whole sub-steps of latency
+  float al;    // fraction towards entry n + 1
+  bool none;   // latency <= 0: newest entry
+};
+__device__ __forceinline__ RingLatency ring_latency(const KParams& P, const Shared& S) {
+  const float lat = S.s[O(LATENCY)], dt = P.cfg.sim_dt;
+  RingLatency L;
+  L.none = lat <= 0.0f;
+  L.n = (int)(lat / dt);
+  L.al = (lat - L.n * dt) / dt;
+  return L;
+}
+struct RingCursor { int head, len; };  // RING_HEAD / RING_LEN carried in registers over the sub-steps
+__device__ __forceinline__ int ring_wrap_up(int i) { return i >= ORR_RING_DEPTH ? i - ORR_RING_DEPTH : i; }   // i < 2 depth
+__device__ __forceinline__ int ring_wrap_down(int i) { return i < 0 ? i + ORR_RING_DEPTH : i; }                 // i >= -depth
+__device__ __forceinline__ void ring_prefetch(const RingLatency& L, const float* rec, const RingCursor& C, int lane, RingFetch& F) {
+  const int head = ring_wrap_up(C.head + 1);  // after the push
+  const int len = C.len + 1 > ORR_RING_DEPTH ? ORR_RING_DEPTH : C.len + 1;
+  int k0 = 0, k1 = 0;
+  F.al = 0.0f;
+  if (!(L.none || len == 1)) {
+    if (L.n + 1 >= len) { k0 = k1 = len - 1; }
+    else { k0 = L.n; k1 = L.n + 1; F.al = L.al; }
+  }
+  F.same = k0 == k1; F.new0 = k0 == 0; F.new1 = k1 == 0;
+  const int i0 = ring_wrap_down(head - k0), i1 = ring_wrap_down(head - k1);   // k < len <= depth
+  const float* p0 = rec + O(RING) + i0 * ORR_RING_ENTRY;
+  const float* p1 = rec + O(RING) + i1 * ORR_RING_ENTRY;
+  const int hi = lane < 3 ? 16 + lane : lane;  // lanes >= 3: harmless duplicate of word `lane`
+  F.e0[0] = p0[lane]; F.e0[1] = p0[hi];
+  F.e1[0] = p1[lane]; F.e1[1] = p1[hi];
+}
+// mang: this lane's true motor angle (lane < 12), computed by the caller from its register copy of the motor constants
+__device__ __forceinline__ void ring_push_and_ctrl_obs(float* rec, Shared& S, int lane, bool valid, const RingFetch& F, RingCursor& C,
+                                                       float mang) {
+  static_assert(ORR_RING_ENTRY == 20, "lane mapping below assumes 20-word entries");
+  C.head = ring_wrap_up(C.head + 1);
+  C.len = C.len + 1 > ORR_RING_DEPTH ? ORR_RING_DEPTH : C.len + 1;
+  float rel[4], Rb[9], rate[3];
+  base_rotation(S, lane, rel, Rb);
+  mtv3(Rb, &S.s[O(ANGVEL)], rate);  // get_true_base_rpy_rate (minitaur.py:640-672): angular velocity in the base frame
+  // word `lane`: motor angles 0..11 (get_true_motor_angles, :543-553), relative quaternion 12..15;
+  // word 16 + lane (lanes 0..3): rate 16..18, pad 19
+  const float va = lane < 12 ? mang : (lane == 12 ? rel[0] : (lane == 13 ? rel[1] : (lane == 14 ? rel[2] : rel[3])));
+  const float vb = lane == 0 ? rate[0] : (lane == 1 ? rate[1] : (lane == 2 ? rate[2] : 0.0f));
+  float* dst = rec + O(RING) + C.head * ORR_RING_ENTRY;
+  if (valid) {
+    dst[lane] = va;
+    if (lane < 4) dst[16 + lane] = vb;
+  }
+  const float a0 = F.new0 ? va : F.e0[0], a1 = F.new1 ? va : F.e1[0];
+  const float b0 = F.new0 ? vb : F.e0[1], b1 = F.new1 ? vb : F.e1[1];
+  S.co[lane] = F.same ? a0 : (1.0f - F.al) * a0 + F.al * a1;
+  if (lane < 3) S.co[16 + lane] = F.same ? b0 : (1.0f - F.al) * b0 + F.al * b1;
+  WSYNC();
+}

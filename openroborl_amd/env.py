@@ -74,7 +74,7 @@ def action_space():
 
 
 class VecQuadrupedEnv(object):
-    """N independent quadrupeds on one GPU; one wavefront per robot (see csrc/orr_kernels.hip)."""
+    """N independent quadrupeds on one GPU; four robots per wavefront, 16 lanes each (see csrc/orr_kernels.hip, orr_physics.h)."""
 
     def __init__(self, task_name=None, training_yaml=None, sim_yaml=None, device="cuda", num_robot=None, seed=None,
                  robot=None, motion_file=None, mode=None, enable_randomizer=None, auto_reset=True, num_procs=1,

@@ -1,5 +1,5 @@
 """The kernel solves the forward dynamics by composite inertias + Newton-Euler bias forces + leg-wise block elimination
-(openroborl_amd/csrc/orr_kernels.hip, leg_dynamics / row_response), the oracle by the articulated-body algorithm.
+(openroborl_amd/csrc/orr_physics.h, leg_dynamics / row_response), the oracle by the articulated-body algorithm.
 tools/crba_proto.py is the numpy statement of the kernel's formulation; here it is checked against the oracle
 (accelerations and the full inverse mass matrix) on random states of both robots.  CPU only."""
 import os
