@@ -130,3 +130,10 @@ def test_motion_clip_validator():
     rep, problems = motion.validate(f.name)
     assert any("joint rate" in p for p in problems)
     os.unlink(f.name)
+
+
+def test_headers_are_plain_c():
+    """The drop-in boundary is a C ABI: both headers must compile as C99 on their own."""
+    import subprocess
+    for h in ("openroborl_hip.h", "openroborl_policy.h"):
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", h)])
