@@ -137,3 +137,18 @@ def test_headers_are_plain_c():
     import subprocess
     for h in ("openroborl_hip.h", "openroborl_policy.h"):
         subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", h)])
+
+
+def test_policy_abi_argument_checks_without_gpu():
+    """Host-side argument validation of include/openroborl_policy.h (no launch happens on these paths)."""
+    L = _lib.load()
+    assert L.orr_policy_packed_size(160, 512) == 32 * 10 * 256
+    assert L.orr_policy_packed_size(256, 12) == 1 * 16 * 256          # 12 columns padded to one 16-column tile
+    assert L.orr_policy_packed_size(100, 12) == -1                    # K must be a multiple of 16
+    assert L.orr_policy_pack(None, 160, 512, None, None) == -1
+    assert b"orr_policy_pack" in L.orr_last_error()
+    net = _abi.OrrPolicyNet()
+    assert L.orr_policy_forward(C.byref(net), None, 4, None, 0.125, 6.28, None, None, None, None, None) == -1
+    assert b"orr_policy_forward" in L.orr_last_error()
+    assert L.orr_gae(None, None, None, None, 4, 4, 0.95, 0.95, 1, 0.0, None, None, None) == -1
+    assert b"orr_gae" in L.orr_last_error()
