@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--log", default="")
     ap.add_argument("--save", default="", help="write the trained weights as a stable-baselines style zip")
     ap.add_argument("--torch-policy", action="store_true", help="rollout policy through plain torch instead of the fused HIP kernel")
+    ap.add_argument("--eval", default="", help="evaluate a policy zip instead of training: deterministic actions, test mode "
+                                                 "(no randomiser, full-length episodes), like `run.py --mode test`")
     ap.add_argument("--tune-gemms", action="store_true", help="let PyTorch's TunableOp pick the learner's GEMM kernels (+7 %% samples/s after ~10 s of tuning)")
     args = ap.parse_args()
 
@@ -39,6 +41,8 @@ def main():
 
     if args.tune_gemms:
         torch.cuda.tunable.enable(True)
+    if args.eval:
+        return evaluate(args, torch, pol, ppo, VecQuadrupedEnv)
     rank, world, local = odist.init_from_env()
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
@@ -85,6 +89,34 @@ def main():
     env.close()
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def evaluate(args, torch, pol, ppo, VecQuadrupedEnv):
+    """run.py:151-183 (test): one full episode per robot with the policy mean; prints return / length statistics."""
+    dev = torch.device("cuda", 0)
+    n = min(args.num_robot, 1024)
+    env = VecQuadrupedEnv(task_name=args.task, num_robot=n, mode="test", auto_reset=False, seed=args.seed, device=dev)
+    model = ppo.ActorCritic(dev, params=pol.load_parameters(args.eval))
+    if not args.torch_policy:
+        model.enable_fused()
+    obs = env.reset()
+    alive = torch.ones(n, dtype=torch.bool, device=dev)
+    ret = torch.zeros(n, device=dev)
+    length = torch.zeros(n, device=dev)
+    limit = int(env.field_int("MAX_EP_STEPS").max())
+    for _ in range(limit):
+        act, _, _ = model.act(obs, deterministic=True)
+        obs, rew, done, _ = env.step(act)
+        ret += rew * alive
+        length += alive.float()
+        alive &= ~done.bool()
+        if not bool(alive.any()):
+            break
+    print(json.dumps({"policy": args.eval, "task": args.task, "robots": n, "episode_limit": limit,
+                      "return_mean": round(float(ret.mean()), 2), "return_min": round(float(ret.min()), 2),
+                      "length_mean": round(float(length.mean()), 1), "full_length_fraction": round(float((length >= limit).float().mean()), 3),
+                      "reward_per_step": round(float((ret / length).mean()), 3)}))
+    env.close()
 
 
 if __name__ == "__main__":
