@@ -133,8 +133,13 @@ struct LegSolve {   // per leg, written by the leg lanes, read by the row lanes 
   float Hi[6];      // H^-1 of the leg's 3x3 joint-space inertia (00 11 22 01 02 12)
 };
 
-struct SubstepBuf {           // live only inside a physics sub-step
-  float W[kMaxRows][18];      // M^-1 J^T per row slot
+struct DynamicsBuf {           // leg dynamics -> row setup hand-over (dead once the impulse responses are written)
+  LinkCache lc[12];
+  LegExchange legx[4];
+};
+union SubstepBuf {            // live only inside a physics sub-step
+  float W[kMaxRows][18];      // M^-1 J^T per row slot: written by the impulse responses, read until the velocity update
+  DynamicsBuf dyn;            // shares its space: written by the next sub-step's dynamics, last read by the row setup
 };
 struct StepEndBuf {           // live only at reset / end of step
   float frames[11][19];       // staged clip frames: 5 sample times x (f0, f1) + frame 0
@@ -143,6 +148,7 @@ struct StepEndBuf {           // live only at reset / end of step
   float vel[18];
   float ee[2][8][3];          // end-effector world positions, [0] sim [1] ref
   float obs[ORR_OBS_DIM];
+  float red[64];              // small cross-lane reductions of the step-end code
 };
 union PhaseBuf {
   SubstepBuf sub;
@@ -154,15 +160,12 @@ struct Shared {
   ModelHot m;                 // robot model (hot part)
   float mass[13];             // after randomisation ratios
   float Ic[13][6];
-  LinkCache lc[12];
   LegSolve leg[4];
-  LegExchange legx[4];
   float Rb[9];                // kinematic base frame -> world
   float IA0inv[36];           // inverse of the base's effective 6x6 inertia (world axes, about the base COM)
   float tau[12];              // joint torques (internal sign convention), joint order
   float ustar[18];
   float co[20];               // control (latency-delayed) observation
-  float red[64];
   PhaseBuf ph;
 #ifdef ORR_PHASE_TIMERS
   long long pt_acc[16], pt_last;  // development aid, see PT() in orr_kernels.hip

@@ -188,7 +188,7 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
   }
   const float ado = part == 0 ? ad0 : (part == 1 ? ad1 : ad2);
   if (lane < 12) {  // pose and joint axis of the own link for the constraint rows
-    LinkCache& L = S.lc[3 * leg + part];
+    LinkCache& L = S.ph.sub.dyn.lc[3 * leg + part];
 #pragma unroll
     for (int i = 0; i < 9; i++) L.Rw[i] = Rw[i];
 #pragma unroll
@@ -228,7 +228,7 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
     const float hc0 = dot3(s0, &Fo[0]) + dot3(sv0, &Fo[3]), hc1 = dot3(s1, &Fo[0]) + dot3(sv1, &Fo[3]);
     const float hc2 = dot3(s2, &Fo[0]) + dot3(sv2, &Fo[3]);
     if (lane < 12) {
-      LegExchange& X = S.legx[leg];
+      LegExchange& X = S.ph.sub.dyn.legx[leg];
 #pragma unroll
       for (int i = 0; i < 6; i++) X.F[part][i] = Fo[i];
       X.b[part] = bo;
@@ -247,7 +247,7 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
   float F[3][6], b[3], GI[6], Gh[3], Gm, Gf[6];
   float H00, H01, H02, H11, H12, H22;
   {
-    const LegExchange& X = S.legx[leg];
+    const LegExchange& X = S.ph.sub.dyn.legx[leg];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
 #pragma unroll
@@ -418,7 +418,7 @@ __device__ __forceinline__ void row_setup(const Shared& S, const orr_config& cfg
     if (slot < 20) { R.leg = slot - 16; d = 0; }
     else { R.leg = (slot - 20) >> 1; d = 1 + ((slot - 20) & 1); }
     const int leg = R.leg;
-    const LinkCache& Lb = S.lc[3 * leg + 2];
+    const LinkCache& Lb = S.ph.sub.dyn.lc[3 * leg + 2];
     float cw[3];
     mv3(Lb.Rw, S.m.toe_pos[leg], cw);
     cw[0] += Lb.ow[0]; cw[1] += Lb.ow[1]; cw[2] += Lb.ow[2];
@@ -433,7 +433,7 @@ __device__ __forceinline__ void row_setup(const Shared& S, const orr_config& cfg
 #pragma unroll
     for (int k = 0; k < 3; k++) {
       // velocity of the contact point per unit joint rate: s x (P - o) = s x rr + (d x s), rr and d relative to the base COM
-      const LinkCache& L = S.lc[3 * leg + k];
+      const LinkCache& L = S.ph.sub.dyn.lc[3 * leg + k];
       float cr[3];
       cross3(L.s, rr, cr);
       R.jl[k] = dir[0] * (cr[0] + L.sv[0]) + dir[1] * (cr[1] + L.sv[1]) + dir[2] * (cr[2] + L.sv[2]);
@@ -619,8 +619,8 @@ __device__ static int physics_substep(const KParams& P, Shared& S, const LegCons
     bool hit = false;
     if (lane < S.m.num_fall) {
       const int b = S.m.fall_body[lane];
-      const float* Rw = b == 0 ? S.Rb : S.lc[b - 1].Rw;
-      const float oz = b == 0 ? S.s[O(POS) + 2] : S.lc[b - 1].ow[2];
+      const float* Rw = b == 0 ? S.Rb : S.ph.sub.dyn.lc[b - 1].Rw;
+      const float oz = b == 0 ? S.s[O(POS) + 2] : S.ph.sub.dyn.lc[b - 1].ow[2];
       const float wz = Rw[6] * S.m.fall_pos[lane][0] + Rw[7] * S.m.fall_pos[lane][1] + Rw[8] * S.m.fall_pos[lane][2];
       hit = (oz + wz - S.m.fall_radius[lane]) < cfg.contact_margin;
     }

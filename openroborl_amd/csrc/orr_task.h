@@ -58,14 +58,14 @@ __device__ static void sample_poses(const KParams& P, Shared& S, int lane, int n
   const DevClip& c = P.tab->clip[geti(S, O(CLIP_ID))];
   const bool warm_ep = geti(S, O(WARMUP)) != 0;
   Sample sm = clip_index(c, lane < nt ? t_lane : 0.0f);
-  if (lane < nt) { S.red[2 * lane] = __int_as_float(sm.f0); S.red[2 * lane + 1] = __int_as_float(sm.f1); }
+  if (lane < nt) { S.ph.end.red[2 * lane] = __int_as_float(sm.f0); S.ph.end.red[2 * lane + 1] = __int_as_float(sm.f1); }
   WSYNC();
   for (int e = 0; e < 2 * nt; e++) {
-    const int f = __float_as_int(S.red[e]);
+    const int f = __float_as_int(S.ph.end.red[e]);
     for (int i = lane; i < 19; i += kLanes) S.ph.end.frames[e][i] = c.frames[f * 19 + i];
   }
   if (with_vel) {
-    const int f0 = __float_as_int(S.red[0]), f1 = __float_as_int(S.red[1]);
+    const int f0 = __float_as_int(S.ph.end.red[0]), f1 = __float_as_int(S.ph.end.red[1]);
     for (int i = lane; i < 18; i += kLanes) { S.ph.end.fvel[0][i] = c.vels[f0 * 18 + i]; S.ph.end.fvel[1][i] = c.vels[f1 * 18 + i]; }
   }
   for (int i = lane; i < 19; i += kLanes) S.ph.end.frames[10][i] = c.frames[i];  // frame 0 (warm-up heading)
@@ -244,10 +244,10 @@ __device__ static float calc_reward(const KParams& P, Shared& S, int lane) {
       const float dh = S.ph.end.ee[1][lane][2] - S.ph.end.ee[0][lane][2];
       e = (ar[0] - br[0]) * (ar[0] - br[0]) + (ar[1] - br[1]) * (ar[1] - br[1]) + c.reward_scale[3] * dh * dh;
     }
-    S.red[lane] = e;
+    S.ph.end.red[lane] = e;
     WSYNC();
 #pragma unroll
-    for (int k = 0; k < 8; k++) ee_err += S.red[k];
+    for (int k = 0; k < 8; k++) ee_err += S.ph.end.red[k];
   }
   float root_pose_err, root_vel_err;
   {
