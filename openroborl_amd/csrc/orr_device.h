@@ -117,31 +117,34 @@ struct KParams {
 // ------------------------------------------------------------------------------------------------
 // LDS image of one robot (one wave): ~1.9 K words (7.6 KB) -> 16 waves per CU (4 per SIMD) fit in 160 KB
 // ------------------------------------------------------------------------------------------------
-struct LinkCache {  // per movable link, written by the leg lanes (0..3), read by the row lanes
+// The LDS structures are 16-byte aligned and sized in multiples of 16 bytes so that runs of consecutive words are moved
+// with ds_read_b128 / ds_write_b128 (a quarter of the LDS instructions of the 4-byte-aligned layout).
+struct alignas(16) LinkCache {  // per movable link, written by the leg lanes (0..3), read by the row lanes
   float Rw[9];      // link -> world
   float ow[3];      // link origin, world
   float s[3], sv[3];  // motion axis of the joint in front of the link, about the base COM: (axis; (origin - base) x axis)
 };
-struct LegExchange {  // per leg, hand-over between the lanes (parts) of a leg inside leg_dynamics
+struct alignas(16) LegExchange {  // per leg, hand-over between the lanes (parts) of a leg inside leg_dynamics
   float F[3][6];      // F_k = Ic_k S_k of joint k, written by part k
   float Hc[3][4];     // Hc[k][i] = S_i . F_k (valid for i <= k)
   float b[4];         // tau_k - C_k
   float I[6], h[3], m, f[6];  // composite of the whole leg about O (part 0) and its bias force
 };
-struct LegSolve {   // per leg, written by the leg lanes, read by the row lanes (see leg_dynamics in orr_physics.h)
+struct alignas(16) LegSolve {   // per leg, written by the leg lanes, read by the row lanes (see leg_dynamics in orr_physics.h)
   float T[3][6];    // F H^-1: column k = base wrench (angular; linear, world axes, about the base COM) per unit of joint k
   float Hi[6];      // H^-1 of the leg's 3x3 joint-space inertia (00 11 22 01 02 12)
 };
 
-struct DynamicsBuf {           // leg dynamics -> row setup hand-over (dead once the impulse responses are written)
+constexpr int kWStride = 20;   // 18 DOFs, padded to a multiple of 16 bytes
+struct alignas(16) DynamicsBuf {           // leg dynamics -> row setup hand-over (dead once the impulse responses are written)
   LinkCache lc[12];
   LegExchange legx[4];
 };
-union SubstepBuf {            // live only inside a physics sub-step
-  float W[kMaxRows][18];      // M^-1 J^T per row slot: written by the impulse responses, read until the velocity update
+union alignas(16) SubstepBuf {            // live only inside a physics sub-step
+  float W[kMaxRows][kWStride];  // M^-1 J^T per row slot (18 used): written by the impulse responses, read until the velocity update
   DynamicsBuf dyn;            // shares its space: written by the next sub-step's dynamics, last read by the row setup
 };
-struct StepEndBuf {           // live only at reset / end of step
+struct alignas(16) StepEndBuf {           // live only at reset / end of step
   float frames[11][19];       // staged clip frames: 5 sample times x (f0, f1) + frame 0
   float fvel[2][18];
   float pose[5][19];          // sampled reference poses (update time + 4 target times)
@@ -155,18 +158,18 @@ union PhaseBuf {
   StepEndBuf end;
 };
 
-struct Shared {
-  float s[kHead];             // state head (float / int bit patterns)
-  ModelHot m;                 // robot model (hot part)
-  float mass[13];             // after randomisation ratios
-  float Ic[13][6];
+struct alignas(16) Shared {
+  alignas(16) float s[kHead];  // state head (float / int bit patterns)
+  alignas(16) ModelHot m;      // robot model (hot part)
+  alignas(16) float mass[13];  // after randomisation ratios
+  alignas(16) float Ic[13][6];
   LegSolve leg[4];
-  float Rb[9];                // kinematic base frame -> world
-  float IA0inv[36];           // inverse of the base's effective 6x6 inertia (world axes, about the base COM)
-  float tau[12];              // joint torques (internal sign convention), joint order
-  float ustar[18];
-  float co[20];               // control (latency-delayed) observation
-  PhaseBuf ph;
+  alignas(16) float Rb[9];     // kinematic base frame -> world
+  alignas(16) float IA0inv[36];  // inverse of the base's effective 6x6 inertia (world axes, about the base COM)
+  alignas(16) float tau[12];   // joint torques (internal sign convention), joint order
+  alignas(16) float ustar[18];
+  alignas(16) float co[20];    // control (latency-delayed) observation
+  alignas(16) PhaseBuf ph;
 #ifdef ORR_PHASE_TIMERS
   long long pt_acc[16], pt_last;  // development aid, see PT() in orr_kernels.hip
 #endif

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
   PT_INIT();
   load_robot(P, rec, S, lane);
   // impulse-response table: stale rows are multiplied by zero impulses, so they only have to be finite
-  for (int i = lane; i < kMaxRows * 18; i += kLanes) (&S.ph.sub.W[0][0])[i] = 0.0f;
+  for (int i = lane; i < kMaxRows * kWStride; i += kLanes) (&S.ph.sub.W[0][0])[i] = 0.0f;
   WSYNC();
   LegConst K;
   load_leg_const(S, lane, K);
