@@ -115,7 +115,7 @@ struct KParams {
 };
 
 // ------------------------------------------------------------------------------------------------
-// LDS image of one robot (one wave): ~1.9 K words (7.6 KB) -> 16 waves per CU (4 per SIMD) fit in 160 KB
+// LDS image of one robot: ~6.3 KB, four per wave
 // ------------------------------------------------------------------------------------------------
 // The LDS structures are 16-byte aligned and sized in multiples of 16 bytes so that runs of consecutive words are moved
 // with ds_read_b128 / ds_write_b128 (a quarter of the LDS instructions of the 4-byte-aligned layout).
