@@ -379,3 +379,30 @@ def test_checkpoint_resume_is_bitwise():
     assert st["total_timesteps"] > 0
     assert set(st["last_done_reason"]) == {"contact_fall", "root_pos", "root_rot", "time_limit", "non_finite"}
     env.close()
+
+
+def test_latency_ring_wraps_with_random_latency():
+    """Three env steps (99 pushes into the 44-deep ring: it wraps twice) with the randomiser on, i.e. per-robot latencies
+    of 0-40 ms: ring cursor, ring contents and the delayed observations still follow the oracle."""
+    import torch
+    n = 64
+    env, orc = make_pair("laikago", n=n, randomizer=True, mode="train", seed=11)
+    env.reset(); orc.reset()
+    orc.state[:] = gpu_state64(env)
+    rng = np.random.RandomState(3)
+    for k in range(3):
+        a = rng.uniform(-0.15, 0.15, (n, 12)).astype(np.float32)
+        og, rg, dg, _ = env.step(torch.from_numpy(a).to(env.device))
+        oo, ro, do = orc.step(a.astype(np.float64))
+    lat = env.field("LATENCY")[:, 0].cpu().numpy()
+    assert lat.max() > 0.03 and lat.min() < 0.01          # the sample really spans short and long latencies
+    compare_fields(env, orc, ["RING_LEN", "RING_HEAD"], atol=0, what="ring cursor")
+    g = gpu_state64(env)
+    sl = env.layout.sl("RING")
+    alive = ~(dg.cpu().numpy().astype(bool) | do)
+    assert alive.mean() > 0.9
+    rg_, ro_ = g[alive][:, sl].reshape(-1, _abi.RING_DEPTH, _abi.RING_ENTRY), orc.state[alive][:, sl].reshape(-1, _abi.RING_DEPTH, _abi.RING_ENTRY)
+    np.testing.assert_allclose(rg_[:, :, :16], ro_[:, :, :16], atol=1e-2)          # motor angles + relative quaternion of every entry
+    assert np.median(np.abs(rg_[:, :, 16:19] - ro_[:, :, 16:19])) < 2e-3           # base rates: contact dynamics amplify rounding
+    assert np.abs(rg_[:, :, 16:19] - ro_[:, :, 16:19]).max() < 0.3
+    np.testing.assert_allclose(og.cpu().numpy()[alive][:, 12:84], oo[alive][:, 12:84], atol=1e-2)   # last actions + delayed motor angles
