@@ -406,3 +406,46 @@ def test_latency_ring_wraps_with_random_latency():
     assert np.median(np.abs(rg_[:, :, 16:19] - ro_[:, :, 16:19])) < 2e-3           # base rates: contact dynamics amplify rounding
     assert np.abs(rg_[:, :, 16:19] - ro_[:, :, 16:19]).max() < 0.3
     np.testing.assert_allclose(og.cpu().numpy()[alive][:, 12:84], oo[alive][:, 12:84], atol=1e-2)   # last actions + delayed motor angles
+
+
+def test_auto_reset_inside_step_matches_oracle():
+    """Train mode: an episode that survives hits the 20-step time limit, and the auto-reset inside the step launch then
+    happens on both sides at the same env step.  What a reset produces depends only on the RNG stream and the clip (not on
+    the chaotic physics before it), so the post-reset state of those robots must match tightly."""
+    import torch
+    n = 64
+    env, orc = make_pair("laikago", n=n, randomizer=True, auto_reset=True, mode="train", seed=17)
+    env.reset(); orc.reset()
+    orc.state[:] = gpu_state64(env)
+    limit = int(env.field_int("MAX_EP_STEPS").max())
+    assert limit == 20
+    rng = np.random.RandomState(1)
+    clean = np.ones(n, dtype=bool)                   # no reset so far on either side
+    checked = 0
+    for k in range(limit + 1):
+        a = rng.uniform(-0.05, 0.05, (n, 12)).astype(np.float32)
+        og, rg, dg, _ = env.step(torch.from_numpy(a).to(env.device))
+        oo, ro, do = orc.step(a.astype(np.float64))
+        dgn = dg.cpu().numpy().astype(bool)
+        if k == limit - 1:
+            sel = clean & dgn & do
+            assert sel.sum() > n // 2 and (dgn[clean] == do[clean]).all()
+            g = gpu_state64(env)
+            for name, tol in [(f, 0) for f in ("EPISODE_IDX", "EP_STEP", "RING_LEN", "RING_HEAD", "STEP_COUNTER", "STATE_ACTION_COUNTER",
+                                                "FILTER_VALID", "WARMUP", "MAX_EP_STEPS")] + \
+                             [(f, 2e-5) for f in ("TIME_OFFSET", "LATENCY", "FOOT_MU", "KNEE_FRICTION", "MASS_RATIO", "INERTIA_RATIO",
+                                                   "STRENGTH", "ORIGIN_POS", "ORIGIN_ROT", "REF_POSE", "REF_VEL", "POS", "QUAT", "Q", "QD",
+                                                   "LINVEL", "ANGVEL")]:
+                sl = env.layout.sl(name)
+                np.testing.assert_allclose(g[sel][:, sl], orc.state[sel][:, sl], atol=tol, rtol=0, err_msg=name)
+            np.testing.assert_allclose(og.cpu().numpy()[sel], oo[sel], atol=2e-4)   # the observation returned is the reset observation
+            checked = int(sel.sum())
+            kept = sel
+        clean &= ~(dgn | do)
+    assert checked > 0
+    # one step into the next episode the robots that reset together still track each other
+    g = gpu_state64(env)
+    for name in ("POS", "QUAT", "Q"):
+        sl = env.layout.sl(name)
+        assert np.median(np.abs(g[kept][:, sl] - orc.state[kept][:, sl])) < 1e-4, name
+    env.close(); orc.close()
