@@ -303,25 +303,30 @@ class LegacyListEnv(object):
 
     def step(self, action):
         t = self._env.torch
-        a = np.stack([np.asarray(action[i], dtype=np.float32) for i in range(self.num_robot)])
-        obs, rew, done, _ = self._env.step(t.from_numpy(a).to(self._env.device))
+        try:
+            a = np.asarray(action, dtype=np.float32)              # list of equal-length arrays: one conversion
+        except (ValueError, TypeError):
+            a = np.stack([np.asarray(action[i], dtype=np.float32) for i in range(self.num_robot)])
+        if a.shape != (self.num_robot, _abi.NUM_MOTORS):
+            a = np.stack([np.asarray(action[i], dtype=np.float32).reshape(_abi.NUM_MOTORS) for i in range(self.num_robot)])
+        obs, rew, done, _ = self._env.step(t.from_numpy(np.ascontiguousarray(a)).to(self._env.device))
         if self._mutate:
+            init = self._init_angles
             for i in range(self.num_robot):
-                try:
-                    action[i] += self._init_angles[i]
-                except Exception:
-                    pass
+                ai = action[i]
+                if isinstance(ai, np.ndarray):
+                    ai += init[i]
         obs = obs.detach().cpu().numpy().astype(np.float64)
-        rew = rew.detach().cpu().numpy().astype(np.float64)
-        done = done.detach().cpu().numpy().astype(bool)
-        ndone = int(done.sum())
+        rew_list = rew.detach().cpu().numpy().astype(np.float64).tolist()
+        done_np = done.detach().cpu().numpy().astype(bool)
+        ndone = int(done_np.sum())
         if ndone > 0:
             # wrapper_env.py:82-83: the curriculum counter advances by num_robot per step in which ANY robot finished
             # (the kernel already added one per finished robot)
             self._env.counters[_abi.CNT_TOTAL_STEP_COUNT] += self.num_robot - ndone
-        done_list = [bool(d) for d in done]
+        done_list = done_np.tolist()
         info = [{"terminated": done_list} for _ in range(self.num_robot)]
-        return [obs[i] for i in range(self.num_robot)], [float(r) for r in rew], done_list, info
+        return list(obs), rew_list, done_list, info
 
 
 def build_env(task_name, num_robot=None, mode=None, enable_randomizer=None, legacy=False, **kw):
