@@ -119,7 +119,7 @@ struct KParams {
 // ------------------------------------------------------------------------------------------------
 // The LDS structures are 16-byte aligned and sized in multiples of 16 bytes so that runs of consecutive words are moved
 // with ds_read_b128 / ds_write_b128 (a quarter of the LDS instructions of the 4-byte-aligned layout).
-struct alignas(16) LinkCache {  // per movable link, written by the leg lanes (0..3), read by the row lanes
+struct alignas(16) LinkCache {  // per movable link, written by the lane that owns the link (leg, part), read by the row lanes
   float Rw[9];      // link -> world
   float ow[3];      // link origin, world
   float s[3], sv[3];  // motion axis of the joint in front of the link, about the base COM: (axis; (origin - base) x axis)
@@ -130,7 +130,7 @@ struct alignas(16) LegExchange {  // per leg, hand-over between the lanes (parts
   float b[4];         // tau_k - C_k
   float I[6], h[3], m, f[6];  // composite of the whole leg about O (part 0) and its bias force
 };
-struct alignas(16) LegSolve {   // per leg, written by the leg lanes, read by the row lanes (see leg_dynamics in orr_physics.h)
+struct alignas(16) LegSolve {   // per leg, written by its part-0 lane, read by the row lanes (see leg_dynamics in orr_physics.h)
   float T[3][6];    // F H^-1: column k = base wrench (angular; linear, world axes, about the base COM) per unit of joint k
   float Hi[6];      // H^-1 of the leg's 3x3 joint-space inertia (00 11 22 01 02 12)
 };
