@@ -1,79 +1,125 @@
 #!/usr/bin/env python3
 """Headline benchmark: env steps/sec at N parallel robots (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--config laikago4096|minicheetah4096|mixed8192]
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-Workload (BASELINE.json configs[1]): imitation_learning_laikago, 4096 robots per GPU, laikago_pace clip,
-train semantics (domain randomiser on, 20->600 step curriculum, per-robot auto-reset).  A "step" is one
-env.step() of all robots of a GPU = one launch of the fused HIP kernel = 33 physics sub-steps +
-observation + reward + termination (+ auto-reset) per robot.  Actions are the policy-free stress input of
-SURVEY.md section 8d: reference joint pose one control step ahead (taken from the observation), in
-motor space, plus N(0, 0.125^2) noise, generated on the device.  N > 1: independent shards, one process
-per GPU, and the rollout-boundary all_gather of episode returns (RCCL) every 256 steps and at the end.
+Workload (default = BASELINE.json configs[1]): imitation_learning_laikago, 4096 robots per GPU, laikago_pace clip,
+train semantics (domain randomiser on, 20->600 step curriculum, per-robot auto-reset).  --config selects configs[2]
+(mini-cheetah, trot clip, 4096 robots) or configs[4] (8192 robots, Laikago and mini-cheetah interleaved in every wave).
+A "step" is one env.step() of all robots of a GPU = one launch of the fused HIP kernel = 33 physics sub-steps +
+observation + reward + termination (+ auto-reset) per robot.  Actions are the policy-free stress input of SURVEY.md
+section 8d: reference joint pose one control step ahead (taken from the observation), in motor space, plus
+N(0, 0.125^2) noise, generated on the device (one GEMM launch per step, inside the timed region).  N > 1: independent
+shards, one process per GPU, and the rollout-boundary all_gather of episode returns (RCCL) every 256 steps and at the
+end of the timed region.
+
+Timing protocol.  Untimed: `warmup_internal` env steps (a floor that does not depend on --warmup: a fresh box needs
+~2 s of work before its clocks and code objects are in steady state) + one rollout-boundary gather (its first call
+loads code objects) + the W steps of --warmup.  Timed: EXACTLY K steps incl. the action GEMMs and the gathers a real
+rollout performs, bracketed by barrier + synchronize.  Each timed step's kernel is additionally bracketed by HIP events
+on the launch stream; their sum is `timed_breakdown.kernel_ms_total` and their mean is the roofline's kernel time.
 
 Prints ONE JSON line (rank 0).  The roofline object prices the step kernel against HBM bandwidth as the
-north star asks; DESIGN.md section 6 explains why the kernel is VALU-latency bound and nowhere near it.
+north star asks; DESIGN.md section 6 explains why the kernel is VALU-issue bound and nowhere near it.
 """
 import argparse
 import json
 import os
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ROBOTS_PER_GPU = 4096
 ROLLOUT = 256
-GRAPH_LEN = 64      # env steps per hipGraph replay (divides ROLLOUT; the action-noise pool has 64 entries)
+WARMUP_FLOOR = 6000   # untimed env steps before anything else (~2 s of kernel time at 4096 robots)
 # algorithmic HBM bytes per robot-step of the step kernel: actions 48 + obs 640 +
 # reward 4 + done 1 = 693; state head 307 words read + written = 2456; latency ring 33 entries written
 # (2640) + 35 distinct entries read (2660).  Model tables and clip frames are shared and L2-resident.
 B_ALG = 693 + 2456 + 2640 + 2660
 HBM_PEAK_GBS = 8000.0
 
+CONFIGS = {
+    # name: (VecQuadrupedEnv keyword arguments, robots per GPU, description for config.workload)
+    "laikago4096": (dict(task_name="imitation_learning_laikago"), 4096,
+                    "imitation_learning_laikago, %d parallel robots per GPU, laikago_pace motion_file (BASELINE configs[1]; configs[3] when n_gpus=8)"),
+    "minicheetah4096": (dict(task_name="imitation_learning_minicheetah"), 4096,
+                        "imitation_learning_minicheetah, %d parallel robots per GPU, minicheetah_trot motion_file (BASELINE configs[2])"),
+    "mixed8192": (dict(task_name="imitation_learning_laikago", mixed_robots=["laikago", "mini_cheetah"],
+                       motion_file=["laikago_pace.txt", "minicheetah_trot.txt"]), 8192,
+                  "mixed Laikago + mini-cheetah batch (robot_type = i & 1: both models in every wavefront), %d robots per GPU (BASELINE configs[4])"),
+}
 
-def cpu_baseline(env, seconds_target=12.0):
-    """Time the CPU oracle (kind "port") on the host cores on a bounded sample of the same workload."""
+
+def _oracle_rate(ol, env, n, threads, seconds, f32, build_dir):
     import numpy as np
-    from tests import oracle_lib as ol
-    # a one-GPU box owns a 16-core share of the host (more threads only oversubscribe it)
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    cores = max(1, min(avail, int(os.environ.get("ORR_CPU_BASELINE_THREADS", "16"))))
-    n = 32 * cores
-    orc = ol.OracleEnv(env.cfg, env.models, env.clips, n, robot_type=0, clip_id=0, threads=cores)
+    orc = ol.OracleEnv(env.cfg, env.models, env.clips, n, robot_type=env.robot_type[:n], clip_id=env.clip_id[:n], threads=threads,
+                       f32=f32, build_dir=build_dir)
     obs = orc.reset()
-    jom = env.models[0]["joint_of_motor"]
-    m = env.models[0]
     rng = np.random.RandomState(0)
+    jom = np.stack([env.models[t]["joint_of_motor"] for t in env.robot_type[:n]])
+    off = np.stack([env.models[t]["motor_offset"] for t in env.robot_type[:n]])
+    mdir = np.stack([env.models[t]["motor_dir"] for t in env.robot_type[:n]])
+    init = np.stack([env.models[t]["init_motor_angles"] for t in env.robot_type[:n]])
 
     def act(o):
-        tar = o[:, 84 + 7:84 + 19]
-        a = (tar[:, jom] - m["motor_offset"]) * m["motor_dir"] - m["init_motor_angles"] + rng.randn(n, 12) * 0.125
-        return np.clip(a, -2 * np.pi, 2 * np.pi)
+        tar = np.take_along_axis(o[:, 84 + 7:84 + 19], jom, axis=1)
+        return np.clip((tar - off) * mdir - init + rng.randn(n, 12) * 0.125, -2 * np.pi, 2 * np.pi)
     for _ in range(2):
         obs, _, _ = orc.step(act(obs))
     t0 = time.time()
     steps = 0
-    while time.time() - t0 < seconds_target:
+    while time.time() - t0 < seconds:
         obs, _, _ = orc.step(act(obs))
         steps += 1
     dt = time.time() - t0
     orc.close()
-    return {"value": n * steps / dt, "unit": "env steps/s", "cores": cores, "kind": "port",
-            "sample": "%d robots x %d env steps of the same workload, oracle/orr_oracle.c with %d OpenMP threads" % (n, steps, cores)}
+    return n * steps / dt, steps
+
+
+def cpu_baseline(env):
+    """Time the CPU oracle (kind "port": PyBullet is not installed) on the host cores on bounded
+    samples of the same workload.  Rows: float64 -O2 (the parity oracle) and float32 -O3 -march=native builds of the same
+    source, at 1 thread x 1 robot (BASELINE configs[0]), 1 thread x 512 robots, 16 threads and all available cores.  ~30 s in total."""
+    from tests import oracle_lib as ol
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    build_dir = None if os.access(os.path.join(ROOT, "oracle"), os.W_OK) else tempfile.mkdtemp()   # None = in oracle/
+    rows = []
+    # a one-GPU box is a 16-core share of a bigger host: rows at 16 threads and at every core the process may run on
+    share = min(16, avail)
+    f64, f32 = "f64 -O2 -ffp-contract=off", "f32 -O3 -march=native"
+    plan = [(f64, False, 1, 1, 3.0), (f64, False, 512, 1, 3.0), (f64, False, 32 * share, share, 4.0),
+            (f32, True, 1, 1, 3.0), (f32, True, 512, 1, 3.0), (f32, True, 32 * share, share, 4.0)]
+    if avail > share:
+        plan += [(f64, False, 16 * avail, avail, 4.0), (f32, True, 16 * avail, avail, 4.0)]
+    for build, f32, n, threads, secs in plan:
+        try:
+            rate, steps = _oracle_rate(ol, env, min(n, env.num_robot), threads, secs, f32, build_dir)
+            rows.append({"value": rate, "unit": "env steps/s", "cores": threads, "robots": min(n, env.num_robot), "build": build,
+                         "sample": "%d robots x %d env steps" % (min(n, env.num_robot), steps)})
+        except Exception as e:      # noqa: BLE001  (e.g. no compiler on the box for the f32 build): report, keep the other rows
+            rows.append({"build": build, "cores": threads, "robots": n, "error": repr(e)})
+    best = max((r for r in rows if "value" in r), key=lambda r: r["value"])
+    return {"value": best["value"], "unit": "env steps/s", "cores": best["cores"], "kind": "port",
+            "sample": "%s of the same workload, oracle/orr_oracle.c (%s), %d OpenMP threads; the fastest of the rows below"
+                      % (best["sample"], best["build"], best["cores"]),
+            "host_cpu_count": os.cpu_count(), "host_cores_available": avail,
+            "note": "a restatement of the same algorithm (un-tuned articulated-body + PGS code), not PyBullet; never the target",
+            "rows": rows}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3000)
-    ap.add_argument("--warmup", type=int, default=6000)   # the first process on a fresh box runs ~6 % slower for its first seconds
-    ap.add_argument("--robots-per-gpu", type=int, default=ROBOTS_PER_GPU)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="laikago4096")
+    ap.add_argument("--robots-per-gpu", type=int, default=0, help="override the config's robots per GPU (experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -89,89 +135,76 @@ def main():
     # ORR_BENCH_SINGLE_DEVICE=1 (+ ORR_DIST_BACKEND=gloo): multi-rank rehearsal on a one-GPU box, never a measurement
     dev = torch.device("cuda", 0 if os.environ.get("ORR_BENCH_SINGLE_DEVICE") else local)
     torch.cuda.set_device(dev)
-    n = args.robots_per_gpu
-    env = VecQuadrupedEnv(task_name="imitation_learning_laikago", num_robot=n, mode="train", enable_randomizer=True,
-                          auto_reset=True, seed=0, device=dev, num_procs=world, robot_index_offset=rank * n)
-    m = env.models[0]
-    jom = torch.tensor(m["joint_of_motor"], dtype=torch.long, device=dev)
-    off = torch.tensor(m["motor_offset"], dtype=torch.float32, device=dev)
-    mdir = torch.tensor(m["motor_dir"], dtype=torch.float32, device=dev)
-    init = torch.tensor(m["init_motor_angles"], dtype=torch.float32, device=dev)
+    env_kw, n, workload = CONFIGS[args.config]
+    n = args.robots_per_gpu or n
+    env = VecQuadrupedEnv(num_robot=n, mode="train", enable_randomizer=True, auto_reset=True, seed=0, device=dev,
+                          num_procs=world, robot_index_offset=rank * n, **env_kw)
+    # action = (target joint pose -> motor space) - init + noise; the joint -> motor permutation and direction signs are one
+    # 12x12 matrix per robot type, noise and constant terms are pre-combined: one (batched) GEMM launch per step
+    types = sorted(set(int(t) for t in env.robot_type))
+    perm = torch.zeros(len(types), 12, 12, dtype=torch.float32, device=dev)
+    const = torch.zeros(len(types), 12, dtype=torch.float32, device=dev)
+    for k, t in enumerate(types):
+        m = env.models[t]
+        jom = torch.tensor(m["joint_of_motor"], dtype=torch.long, device=dev)
+        mdir = torch.tensor(m["motor_dir"], dtype=torch.float32, device=dev)
+        perm[k, jom, torch.arange(12, device=dev)] = mdir
+        const[k] = torch.tensor(m["motor_offset"], dtype=torch.float32, device=dev) * mdir + torch.tensor(m["init_motor_angles"], dtype=torch.float32, device=dev)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
-    # action = clip((target motor pose - offset) * dir - init + noise): noise and the constant terms are pre-combined
-    noise_pool = torch.randn(64, n, 12, generator=gen, device=dev) * 0.125 - (off * mdir + init)
-    two_pi = 2.0 * 3.141592653589793
-
-    # the joint -> motor permutation and the motor direction signs as one 12x12 matrix: two kernels per step (GEMM, clamp)
-    perm = torch.zeros(12, 12, dtype=torch.float32, device=dev)
-    perm[jom, torch.arange(12, device=dev)] = mdir
+    nt = len(types)
+    # robots are interleaved by type (robot i has type i % nt): viewing [n, 12] as [n/nt, nt, 12] groups them for a bmm
+    noise_pool = torch.randn(64, n // nt, nt, 12, generator=gen, device=dev) * 0.125 - const
+    if nt > 1:
+        noise_pool = noise_pool.permute(0, 2, 1, 3).contiguous()   # [64, nt, n/nt, 12]
 
     def make_action(obs, k):
-        tar = obs[:, 84 + 7:84 + 19]
-        if os.environ.get("ORR_BENCH_INDEX_SELECT"):
-            return torch.addcmul(noise_pool[k & 63], tar.index_select(1, jom), mdir).clamp_(-two_pi, two_pi)
         # |reference pose - init + noise| stays far below the 2 pi action bound, so the runner's clip
-        # (imitation_runners.py:140-143) is a no-op here and is left out: one GEMM launch per step
-        return torch.addmm(noise_pool[k & 63], tar, perm)
+        # (imitation_runners.py:140-143) is a no-op here and is left out
+        tar = obs[:, 84 + 7:84 + 19]
+        if nt == 1:
+            return torch.addmm(noise_pool[k & 63].view(n, 12), tar, perm[0])
+        tar_t = tar.view(n // nt, nt, 12).transpose(0, 1)                      # [nt, n/nt, 12], strided view
+        return torch.baddbmm(noise_pool[k & 63], tar_t, perm).transpose(0, 1).reshape(n, 12)
 
     def sync_all():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
 
-    # Default: eager launches (three small torch kernels for the synthetic actions + one step launch per env step; the
-    # host keeps ahead of a 0.46 ms kernel).  ORR_BENCH_GRAPH=1 captures GRAPH_LEN consecutive env steps in a hipGraph and
-    # replays it (remainder eagerly); measured slower on ROCm 7.2 (0.548 vs 0.498 ms per step), kept for comparison.
     def eager_steps(k0, count):
         for k in range(k0, k0 + count):
             env.step(make_action(env.obs, k))
 
-    obs = env.reset()
-    graph = None
-    pre = min(args.warmup, 8)
-    eager_steps(0, pre)                      # allocator / clocks before the capture
-    if os.environ.get("ORR_BENCH_GRAPH"):
-        try:
-            torch.cuda.synchronize(dev)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                eager_steps(0, GRAPH_LEN)    # recorded, not executed
-            env._env_step_counter -= GRAPH_LEN
-        except Exception as e:               # noqa: BLE001  (report and measure eagerly)
-            sys.stderr.write("bench: hipGraph capture failed (%r), running eagerly\n" % (e,))
-            graph = None
-
-    def run_steps(count, on_block=None):
-        """Exactly `count` env steps: graph replays of GRAPH_LEN steps, then an eager remainder."""
-        done_steps = 0
-        while graph is not None and count - done_steps >= GRAPH_LEN:
-            graph.replay()
-            env._env_step_counter += GRAPH_LEN
-            done_steps += GRAPH_LEN
-            if on_block:
-                on_block(GRAPH_LEN, done_steps == count)
-        while done_steps < count:
-            eager_steps(done_steps, 1)
-            done_steps += 1
-            if on_block:
-                on_block(1, done_steps == count)
-
-    run_steps(args.warmup - pre)
-    env.episode_log()
+    # ---- untimed: warm-up floor, one gather (first-call code-object loads, allocations), then the caller's --warmup ----
+    env.reset()
+    eager_steps(0, WARMUP_FLOOR)
+    odist.gather_env_episodes(env, WARMUP_FLOOR)
+    eager_steps(0, args.warmup)
+    odist.gather_env_episodes(env, args.warmup)
+    dist_info = odist.describe()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    stream = torch.cuda.current_stream(dev)
     sync_all()
-    t0 = time.perf_counter()
-    acc = {"since": 0, "n_eps": 0}
 
-    def on_block(nsteps, last):
-        acc["since"] += nsteps
-        if acc["since"] >= ROLLOUT or last:
-            rets, lens, ts, dropped = odist.gather_env_episodes(env, acc["since"])
-            acc["n_eps"] += int(rets.numel())
-            acc["since"] = 0
-    run_steps(args.steps, on_block)
-    n_eps = acc["n_eps"]
-    obs = env.obs
+    # ---- timed region: exactly args.steps env steps (action GEMM + step kernel) + the rollout-boundary gathers ----
+    t0 = time.perf_counter()
+    gather_s, since, n_eps = 0.0, 0, 0
+    for k in range(args.steps):
+        act = make_action(env.obs, k)
+        ev[k][0].record(stream)
+        env.step(act)
+        ev[k][1].record(stream)
+        since += 1
+        if since >= ROLLOUT or k == args.steps - 1:
+            torch.cuda.synchronize(dev)                         # drain the queued steps first: that wait is kernel time, not gather time
+            g0 = time.perf_counter()
+            stats = odist.gather_env_episodes(env, since)
+            torch.cuda.synchronize(dev)
+            q0 = time.perf_counter()
+            n_eps += stats.sums[0]
+            since = 0
+            gather_s += q0 - g0
     sync_all()
     elapsed = time.perf_counter() - t0
     gloo = world > 1 and torch.distributed.get_backend() == "gloo"
@@ -180,41 +213,53 @@ def main():
         torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(el.item())
 
-    # dominant kernel: average launch duration with hipEvents on the launch stream (same workload state)
-    act = make_action(obs, 0).contiguous()
+    # dominant kernel: HIP events on the launch stream around every timed launch
+    kern_total_ms = sum(a.elapsed_time(b) for a, b in ev)
+    kern_ms = kern_total_ms / args.steps
+    # cross-check: back-to-back launches without the action kernels in between (C-ABI helper, same stream)
+    act = make_action(env.obs, 0).contiguous()
     torch.cuda.synchronize(dev)
-    kern_ms = env.time_steps(act, 50) / 50.0
+    kern_b2b_ms = env.time_steps(act, 50) / 50.0
     achieved = B_ALG * n / (kern_ms * 1e-3) / 1e9
 
     if rank == 0:
-        # PMC numbers come from a separate rocprofv3 --pmc run of this same command (tools/profile_gpu.sh), committed
-        # under profiles/; FETCH_SIZE is taken as reported (4-byte-per-lane rows, the x2 wide-read correction does not apply)
+        # PMC numbers come from separate rocprofv3 --pmc passes over this same command (tools/profile_gpu.sh), committed under
+        # profiles/.  FETCH_SIZE x2: gfx950 tallies 128-B read requests at 64 B (MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact.
         traffic, valu = None, {}
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-        if os.path.exists(pmc):
+        for name in ("r02_%s_pmc_summary.json" % args.config,):
+            pmc = os.path.join(ROOT, "profiles", name)
+            if not os.path.exists(pmc) or n != CONFIGS[args.config][1]:
+                continue
             try:
                 d = json.load(open(pmc))
-                traffic = d.get("hbm_bytes_per_launch")
-                waves = d["SQ_WAVES"]["mean_per_launch"]
-                valu = {"valu_insts_per_robot_step": d["SQ_INSTS_VALU"]["mean_per_launch"] / n,
+                traffic = d.get("hbm_bytes_per_launch_fetch_x2")
+                valu = {"source": "profiles/" + name,
+                        "valu_insts_per_robot_step": d["SQ_INSTS_VALU"]["mean_per_launch"] / n,
                         "valu_active_frac_of_wave_cycles": d["SQ_ACTIVE_INST_VALU"]["mean_per_launch"] / d["SQ_WAVE_CYCLES"]["mean_per_launch"],
-                        "waves_per_simd": waves / 1024.0}
-            except Exception:
+                        "waves_per_simd": d["SQ_WAVES"]["mean_per_launch"] / 1024.0}
+                break
+            except Exception:       # noqa: BLE001
                 traffic, valu = None, {}
         out = {
             "metric": "env steps/sec at N parallel robots", "value": world * n * args.steps / elapsed, "unit": "env steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "imitation_learning_laikago, %d parallel robots per GPU, laikago_pace motion_file "
-                                   "(BASELINE configs[1]; configs[3] when n_gpus=8)" % n,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_internal": WARMUP_FLOOR,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "dtype_ref": "f64", "data": "synthetic",
+            "config": {"workload": workload % n, "name": args.config,
                        "robots_per_gpu": n, "total_robots": world * n, "substeps_per_step": 33, "solver_iters": 9,
-                       "randomizer": True, "auto_reset": True, "actions": "reference pose + N(0,0.125^2), on device (one GEMM launch per step)",
-                       "launch": ("hipGraph of %d env steps per replay" % GRAPH_LEN) if graph is not None else "eager",
-                       "collective": "all_gather of episode returns every %d steps" % ROLLOUT,
+                       "randomizer": True, "auto_reset": True, "actions": "reference pose + N(0,0.125^2), on device (one GEMM launch per step, timed)",
+                       "launch": "eager", "collective": "all_gather of episode returns every %d steps and at the end" % ROLLOUT,
                        "episodes_gathered": n_eps},
+            "timed_breakdown": {"kernel_ms_total": kern_total_ms, "gather_ms": 1e3 * gather_s,
+                                "other_ms": 1e3 * elapsed - kern_total_ms - 1e3 * gather_s,
+                                "note": "rank 0; kernel = sum of per-launch HIP-event durations of orr_step_kernel; gather = host time "
+                                        "from the last queued kernel's end to the end of each rollout-boundary gather; other = action "
+                                        "GEMMs, launch gaps, barriers"},
+            "dist": dist_info,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "orr_step_kernel<0>", "kernel_ms": kern_ms, "alg_bytes_per_robot_step": B_ALG,
+                         "kernel": "orr_step_kernel<0>", "kernel_ms": kern_ms, "kernel_ms_back_to_back": kern_b2b_ms,
+                         "alg_bytes_per_robot_step": B_ALG, "alg_bytes_per_launch": B_ALG * n,
                          "pmc": valu,
                          "note": "instruction-issue-bound serial chain of a lone wave (33 x (leg dynamics + rows + 9 PGS sweeps)); HBM fraction is reported "
                                  "because the north star asks for it, see DESIGN.md section 6"},

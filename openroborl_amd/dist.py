@@ -7,12 +7,17 @@ reset/step.  The only exchange is the rollout-boundary gather that replaces
   lrlocal = (seg["ep_lens"], seg["ep_rets"]); MPI.COMM_WORLD.allgather(lrlocal)     (agents/ppo_imitation.py:405-408)
   MPI.COMM_WORLD.allreduce(seg["total_timestep"])                                   (agents/ppo_imitation.py:421)
 with ONE fixed-size all_gather (RCCL over xGMI when the backend is "nccl"; gloo on CPU in tests) of
-  [n_episodes, total_timesteps, n_dropped, ret_0..ret_{K-1}, len_0..len_{K-1}]  (float32, K = capacity).
-The payload is a few KB per rank: latency-bound, ring vs tree does not matter.
+  [n_listed, total_timesteps, n_dropped, n_episodes, sum_ret, sum_len, ret_0..ret_{K-1}, len_0..len_{K-1}]
+(float64: counts stay exact up to 2^53; K = capacity).  n_episodes / sum_ret / sum_len cover EVERY episode the rank
+logged, so the means are exact even when more than K episodes finished; only the per-episode list is truncated
+(n_dropped says by how much).  The payload is KBs per rank: latency-bound, ring vs tree does not matter.
+
+The pack runs on the device without a host sync (counts stay device scalars); the one sync of a rollout
+boundary is the copy of the gathered buffer to the host in unpack_episode_stats.
 """
 import os
 
-HEADER = 3
+HEADER = 6
 
 
 def init_from_env(backend=None):
@@ -29,9 +34,24 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
-            torch.cuda.set_device(local)
+            torch.cuda.set_device(local)       # before any other GPU call of this process
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+def describe():
+    """What torch.distributed actually set up (bench.py prints it, so a scaling run proves RCCL saw N ranks)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"backend": None, "world": 1, "device_of_rank": [torch.cuda.current_device() if torch.cuda.is_available() else None]}
+    world = dist.get_world_size()
+    backend = dist.get_backend()
+    mine = torch.tensor([torch.cuda.current_device() if torch.cuda.is_available() else -1], dtype=torch.int64,
+                        device="cuda" if backend == "nccl" else "cpu")
+    out = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine)
+    return {"backend": backend, "world": world, "device_of_rank": [int(o.item()) for o in out]}
 
 
 def shard_range(total_robots, rank, world):
@@ -42,48 +62,81 @@ def shard_range(total_robots, rank, world):
     return rank * per, (rank + 1) * per
 
 
-def pack_episode_stats(returns, lengths, total_timesteps, dropped, capacity):
-    """[count, total_timesteps, dropped, ret..., len...] padded to capacity (float32, same device as returns)."""
+def pack_episode_stats(returns, lengths, total_timesteps, dropped, capacity, count=None):
+    """One rank's payload (float64, on the device of `returns`).  `returns` / `lengths` hold the logged episodes in
+    their first `count` rows (count: python int or a 0-d integer tensor = no host sync; default: all rows);
+    `dropped` (int or 0-d tensor) = episodes the producer could not even log."""
     import torch
-    k = min(int(returns.numel()), capacity)
-    buf = torch.zeros(HEADER + 2 * capacity, dtype=torch.float32, device=returns.device)
-    buf[0] = float(k)
+    dev = returns.device
+    f64 = torch.float64
+    rows = int(returns.shape[0])
+    cnt = torch.as_tensor(rows if count is None else count, device=dev).to(f64).clamp(max=float(rows))
+    idx = torch.arange(rows, device=dev, dtype=f64)
+    live = idx < cnt
+    r = torch.where(live, returns.to(f64), torch.zeros((), dtype=f64, device=dev))
+    ln = torch.where(live, lengths.to(f64), torch.zeros((), dtype=f64, device=dev))
+    listed = cnt.clamp(max=float(capacity))
+    buf = torch.zeros(HEADER + 2 * capacity, dtype=f64, device=dev)
+    k = min(rows, capacity)
+    buf[0] = listed
     buf[1] = float(total_timesteps)
-    buf[2] = float(dropped) + float(max(int(returns.numel()) - capacity, 0))
-    buf[HEADER:HEADER + k] = returns[:k]
-    buf[HEADER + capacity:HEADER + capacity + k] = lengths[:k]
+    buf[2] = torch.as_tensor(dropped, device=dev).to(f64) + (cnt - listed)
+    buf[3] = cnt
+    buf[4] = r.sum()
+    buf[5] = ln.sum()
+    buf[HEADER:HEADER + k] = r[:k]
+    buf[HEADER + capacity:HEADER + capacity + k] = ln[:k]
     return buf
 
 
 def unpack_episode_stats(gathered, capacity):
-    """list of per-rank buffers -> (all_returns, all_lengths, total_timesteps, dropped)."""
+    """Per-rank payloads -> (all_returns, all_lengths, total_timesteps, dropped); .sums = (n_episodes, sum_ret, sum_len)
+    over every logged episode of every rank.  ONE device->host copy (the rollout boundary's only sync)."""
     import torch
-    rets, lens, ts, dr = [], [], 0, 0
-    for buf in gathered:
-        k = int(buf[0].item())
-        ts += int(buf[1].item())
-        dr += int(buf[2].item())
+    host = torch.stack([g.reshape(-1) for g in gathered]).cpu()
+    rets, lens, ts, dr, n, sr, sl = [], [], 0, 0, 0, 0.0, 0.0
+    for buf in host:
+        k = int(buf[0])
+        ts += int(buf[1])
+        dr += int(buf[2])
+        n += int(buf[3])
+        sr += float(buf[4])
+        sl += float(buf[5])
         rets.append(buf[HEADER:HEADER + k])
         lens.append(buf[HEADER + capacity:HEADER + capacity + k])
-    return torch.cat(rets), torch.cat(lens), ts, dr
+    out = EpisodeStats((torch.cat(rets).float(), torch.cat(lens).float(), ts, dr))
+    out.sums = (n, sr, sl)
+    return out
 
 
-def allgather_episode_stats(returns, lengths, total_timesteps, dropped=0, capacity=4096, group=None):
+class EpisodeStats(tuple):
+    """(returns, lengths, total_timesteps, dropped) + .sums; mean_return / mean_length use the exact sums."""
+    sums = (0, 0.0, 0.0)
+
+    @property
+    def mean_return(self):
+        return self.sums[1] / max(self.sums[0], 1)
+
+    @property
+    def mean_length(self):
+        return self.sums[2] / max(self.sums[0], 1)
+
+
+def allgather_episode_stats(returns, lengths, total_timesteps, dropped=0, capacity=4096, group=None, count=None):
     """The rollout-boundary collective.  Works without a process group (world size 1)."""
     import torch
     import torch.distributed as dist
-    buf = pack_episode_stats(returns, lengths, total_timesteps, dropped, capacity)
+    buf = pack_episode_stats(returns, lengths, total_timesteps, dropped, capacity, count)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return unpack_episode_stats([buf], capacity)
-    dev = buf.device
     if dist.get_backend(group) == "gloo" and buf.is_cuda:   # rehearsal on a one-GPU box: stage through the host
         buf = buf.cpu()
     out = [torch.empty_like(buf) for _ in range(dist.get_world_size(group))]
     dist.all_gather(out, buf, group=group)
-    return unpack_episode_stats([o.to(dev) for o in out], capacity)
+    return unpack_episode_stats(out, capacity)
 
 
 def gather_env_episodes(env, steps_since_last, capacity=4096, group=None):
-    """Drain the env's device-side episode log and all-gather it across ranks."""
-    rets, lens = env.episode_log()
-    return allgather_episode_stats(rets, lens, steps_since_last * env.num_robot, 0, capacity, group)
+    """Drain the env's device-side episode log and all-gather it across ranks (no host sync before the collective)."""
+    log, count, dropped = env.episode_log_device()
+    return allgather_episode_stats(log[:, 0], log[:, 1], steps_since_last * env.num_robot, dropped, capacity, group, count)

@@ -263,14 +263,24 @@ class VecQuadrupedEnv(object):
                 "last_done_reason": {k: int(((reasons & bit) != 0).sum()) for k, bit in names},
                 "max_episode_steps": int(self.field_int("MAX_EP_STEPS").max().item())}
 
-    def episode_log(self):
-        """(returns[K], lengths[K]) of the episodes finished since the last call; clears the log.  Syncs."""
-        n = int(self.counters[_abi.CNT_EPISODES].item())
-        k = min(n, self.ep_log.shape[0])
-        log = self.ep_log[:k].clone()
-        self.counters[_abi.CNT_EPISODES] = 0
-        self.counters[_abi.CNT_EPLOG_DROPPED] = 0
-        return log[:, 0], log[:, 1]
+    def episode_log_device(self):
+        """(log[K,2] snapshot, count, dropped) of the episodes finished since the last call, all on the device and
+        without a host sync (count / dropped are 0-d int64 tensors; rows >= count are stale); clears the log."""
+        t = self.torch
+        log = self.ep_log.clone()
+        cnt = self.counters[_abi.CNT_EPISODES].clone()
+        dropped = self.counters[_abi.CNT_EPLOG_DROPPED].clone()
+        self.counters[_abi.CNT_EPISODES:_abi.CNT_EPLOG_DROPPED + 1] = 0
+        return log, t.clamp(cnt, max=log.shape[0]), dropped
+
+    def episode_log(self, with_dropped=False):
+        """(returns[K], lengths[K]) of the episodes finished since the last call (+ the number of episodes that did not fit
+        the device log when with_dropped); clears the log.  Syncs."""
+        log, cnt, dropped = self.episode_log_device()
+        k = int(cnt.item())
+        if with_dropped:
+            return log[:k, 0], log[:k, 1], int(dropped.item())
+        return log[:k, 0], log[:k, 1]
 
 
 class LegacyListEnv(object):

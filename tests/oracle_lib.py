@@ -71,6 +71,32 @@ def lib():
     return _lib
 
 
+_lib_f32 = None
+
+
+def lib_f32(build_dir=None):
+    """The float32 -O3 -march=native build of the same source (make f32native): bench.py's CPU timing rows only.
+    Built on the box it runs on (-march=native), into build_dir when the tree is read-only."""
+    global _lib_f32
+    if _lib_f32 is None:
+        so = os.path.join(build_dir or ORACLE_DIR, "liborr_oracle_f32.so")
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s", "-B", "f32native", "OUT=" + so])
+        L = C.CDLL(so)
+        assert L.orc_sizeof_real() == 4
+        fp = C.POINTER(C.c_float)
+        L.orc_create.restype = C.c_void_p
+        L.orc_create.argtypes = [C.POINTER(_abi.OrrConfig)]
+        L.orc_destroy.argtypes = [C.c_void_p]
+        L.orc_set_threads.argtypes = [C.c_void_p, C.c_int]
+        L.orc_set_model.argtypes = [C.c_void_p, C.c_int, C.POINTER(_abi.OrrModel)]
+        L.orc_set_motion.argtypes = [C.c_void_p, C.c_int, fp, fp, C.c_int, C.c_float, C.c_int, fp]
+        L.orc_bind.argtypes = [C.c_void_p, C.POINTER(C.c_int64), fp, C.c_int]
+        L.orc_reset.argtypes = [C.c_void_p, fp, C.c_int, C.c_void_p, fp]
+        L.orc_step.argtypes = [C.c_void_p, fp, C.c_int, fp, fp, fp, C.c_void_p, fp]
+        _lib_f32 = L
+    return _lib_f32
+
+
 _layout = None
 
 
@@ -85,8 +111,14 @@ class OracleEnv(object):
     """Thin object wrapper over the oracle: same semantics as the product's C-ABI, float64, host memory."""
 
     def __init__(self, cfg, models, clips, n, robot_type=0, clip_id=0, robot_index=None, threads=1,
-                 ep_log_capacity=0):
-        self.L = lib()
+                 ep_log_capacity=0, f32=False, build_dir=None):
+        self.L = lib_f32(build_dir) if f32 else lib()
+        dt = self.dt = np.float32 if f32 else np.float64
+        ptr = C.POINTER(C.c_float if f32 else C.c_double)
+
+        def P(a):
+            return a.ctypes.data_as(ptr)
+        self.P = P
         self.cfg = cfg
         self.h = C.c_void_p(self.L.orc_create(C.byref(cfg)))
         self.L.orc_set_threads(self.h, threads)
@@ -96,9 +128,9 @@ class OracleEnv(object):
                 self.L.orc_set_model(self.h, t, C.byref(robots.to_struct(m)))
         self.clips = clips
         for i, c in enumerate(clips):
-            fr = np.ascontiguousarray(c.frames, dtype=np.float64)
-            fv = np.ascontiguousarray(c.frame_vels, dtype=np.float64)
-            cd = np.ascontiguousarray(c.cycle_delta, dtype=np.float64)
+            fr = np.ascontiguousarray(c.frames, dtype=dt)
+            fv = np.ascontiguousarray(c.frame_vels, dtype=dt)
+            cd = np.ascontiguousarray(c.cycle_delta, dtype=dt)
             self.L.orc_set_motion(self.h, i, P(fr), P(fv), c.num_frames, c.frame_duration, c.flags, P(cd))
         self.n = n
         self.lay = layout()
@@ -107,21 +139,25 @@ class OracleEnv(object):
         st32 = state.default_state(self.lay, n, models, robot_type, clip_id, robot_index,
                                    legacy_grid=bool(cfg.flags & _abi.FLAG_LEGACY_GRID),
                                    max_ep_steps=cfg.ep_len_end)
-        self.state = state.to_float64(self.lay, st32)
+        self.state = state.to_float64(self.lay, st32).astype(dt)
         self.counters = np.zeros(_abi.NUM_COUNTERS, dtype=np.int64)
-        self.L.orc_bind(self.h, self.counters.ctypes.data_as(C.POINTER(C.c_int64)), None, 0)
-        self.obs = np.zeros((n, _abi.OBS_DIM))
-        self.reward = np.zeros(n)
+        self.ep_log = np.zeros((max(int(ep_log_capacity), 1), 2), dtype=dt)
+        self.L.orc_bind(self.h, self.counters.ctypes.data_as(C.POINTER(C.c_int64)),
+                        P(self.ep_log) if ep_log_capacity else None, int(ep_log_capacity))
+        self.obs = np.zeros((n, _abi.OBS_DIM), dtype=dt)
+        self.reward = np.zeros(n, dtype=dt)
         self.done = np.zeros(n, dtype=np.uint8)
-        self.terms = np.zeros((n, 5))
+        self.terms = np.zeros((n, 5), dtype=dt)
 
     def reset(self, mask=None):
+        P = self.P
         mp = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8).ctypes.data_as(C.c_void_p)
         self.L.orc_reset(self.h, P(self.state), self.n, mp, P(self.obs))
         return self.obs.copy()
 
     def step(self, actions):
-        a = np.ascontiguousarray(actions, dtype=np.float64)
+        P = self.P
+        a = np.ascontiguousarray(actions, dtype=self.dt)
         self.L.orc_step(self.h, P(self.state), self.n, P(a), P(self.obs), P(self.reward),
                         self.done.ctypes.data_as(C.c_void_p), P(self.terms))
         return self.obs.copy(), self.reward.copy(), self.done.copy().astype(bool)

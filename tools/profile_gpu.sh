@@ -1,14 +1,15 @@
 #!/bin/bash
 # Run on the GPU box (through gpurun): kernel-trace stats + separate PMC passes for the step kernel.
-# usage: tools/profile_gpu.sh <tag>      outputs under gpurun_out/<tag>/
+# usage: tools/profile_gpu.sh <tag> [bench.py config]      outputs under gpurun_out/<tag>/
 set -u
 TAG=${1:-prof}
+CFG=${2:-laikago4096}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 40 --warmup 10 --no-cpu-baseline"
-BENCH_TRACE="python3 $ROOT/bench.py --no-cpu-baseline"   # = the default bench.py run
+BENCH="python3 $ROOT/bench.py --config $CFG --steps 40 --warmup 10 --no-cpu-baseline"
+BENCH_TRACE="python3 $ROOT/bench.py --config $CFG --no-cpu-baseline"   # = the default bench.py run
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH_TRACE > $OUT/trace.log 2>&1
 for P in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
          "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM" \

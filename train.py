@@ -72,12 +72,12 @@ def main():
                                   ret.reshape(-1), old_logp=buf["logp"].reshape(-1) if "logp" in buf else None,
                                   epochs=args.epochs, generator=gen)
         samples += T * n * world
-        rets, lens, ts, dropped = odist.gather_env_episodes(env, args.horizon)
+        stats = odist.gather_env_episodes(env, args.horizon)   # means come from the exact per-rank sums, not the truncated list
         if rank == 0 and (it % 10 == 0 or it == args.iters - 1):
             rec = {"iter": it, "samples": samples, "sec": round(time.time() - t0, 2),
                    "mean_step_reward": round(float(buf["rewards"].mean()), 4),
-                   "ep_len_mean": round(float(lens.mean()) if lens.numel() else 0.0, 1),
-                   "ep_ret_mean": round(float(rets.mean()) if rets.numel() else 0.0, 2),
+                   "ep_len_mean": round(stats.mean_length, 1), "ep_ret_mean": round(stats.mean_return, 2),
+                   "episodes": stats.sums[0], "episodes_unlogged": stats[3] - max(stats.sums[0] - int(stats[0].numel()), 0),
                    "max_ep_steps": int(env.field_int("MAX_EP_STEPS").max()), "surr": round(float(surr), 4), "vf": round(float(vf), 4)}
             log.append(rec)
             print(json.dumps(rec), flush=True)
