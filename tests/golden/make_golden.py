@@ -15,8 +15,8 @@ and what is only *read as data*: task/motions/*.txt (JSON) and task/policies/*.z
 
 Two import shims live in tests/golden/_shims (absl.logging -> stdlib logging, and a restatement
 of pybullet_utils.transformations; see the caveat in that file and in DESIGN.md).  Everything
-that needs a live pybullet client (quadruped_gym_env, minitaur, imitation_task) cannot be
-imported here; those parts of the oracle are pinned by hand-derived known answers instead.
+that needs a pybullet client object (quadruped_gym_env, wrapper_env, minitaur, imitation_task, the
+randomiser) is driven by make_golden_task.py with a scripted client instead.
 
 Outputs (committed):
   clips.npz        per clip: raw frames, processed frames, frame velocities, scalars, and

@@ -1,0 +1,189 @@
+"""The oracle against the reference's OWN task / robot / env / wrapper / randomiser code (CPU, no GPU).
+
+Fixtures: tests/golden/task_*.npz, written by tests/golden/make_golden_task.py, which drives the reference's
+WrapperEnv(LocomotionGymEnv([Minitaur...], [ImitationTask...])) end to end with a scripted pybullet client
+(tests/golden/fake_bullet.py).  Here the oracle runs in replay mode: the scripted client's per-sub-step rigid states,
+its link positions and its contact flags are injected (orc_set_replay), the reference's random draws replace the
+oracle's Philox stream, and EVERYTHING else must come out of the oracle's own restatement:
+
+  reset   observation (160), teleported state, time offset / warm-up flag, origin offset, phase, reference pose + velocity,
+          latency, motor strengths, ring length, time limit, randomiser -> link mapping        (A2, A4, F1, F6-order, H)
+  step    33 x 12 motor torques (Butterworth filter, lerp, +-0.2 clip around the delayed angles, PD), observation (160:
+          sensor histories + target frames), reward and its five terms, done, filtered action, delayed control
+          observation, origin re-anchoring on phase wrap, phase, reference pose + velocity     (A1, A3, A5, B1-B6, D1-D3, F2-F5)
+
+Tolerance 1e-9 absolute (values are O(1); torques O(100): rtol 1e-12 on top).  What stays OUT of these pins: the physics
+engine (row C) and the link-COM forward kinematics (both live in third-party pybullet / URDF data).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from openroborl_amd import _abi, config, motion, robots, state as statemod
+from tests import oracle_lib as ol
+
+GOLD = ol.GOLDEN
+TOL = 1e-9
+CLIP = {"laikago": "laikago_pace", "mini_cheetah": "minicheetah_trot"}
+dp = ol.dp
+
+
+def _setup(name):
+    path = os.path.join(GOLD, name)
+    if not os.path.exists(path):
+        pytest.skip("fixture %s missing" % name)
+    g = np.load(path)
+    robot = str(g["robot"])
+    n = int(g["num_robot"])
+    cfg = config.make_config(n, mode="train", enable_randomizer=bool(g["randomizer"]), auto_reset=False, legacy_grid=True)
+    cfg.ep_len_start = int(g["ep_start"])
+    cfg.ep_len_end = int(g["ep_end"])
+    cfg.curriculum_steps = int(g["curriculum_steps"])
+    models = [None] * _abi.MAX_ROBOT_TYPES
+    t = robots.ROBOT_TYPE_ID[robot]
+    models[t] = robots.ROBOTS[robot]()
+    orc = ol.OracleEnv(cfg, models, [motion.MotionClip(CLIP[robot])], n, robot_type=t, clip_id=0)
+    if not bool(g["randomizer"]):
+        orc.state[:, orc.lay.sl("LATENCY")] = config.CTRL_LATENCY     # the decimal 0.002 (laikago.py:27), not its float32 rounding
+    L = orc.L
+    L.orc_set_replay.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, C.c_int, dp]
+    return g, orc, L, models[t], n, cfg
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(dp)
+
+
+def _close(a, b, what, atol=TOL, rtol=0.0):
+    np.testing.assert_allclose(np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64), atol=atol, rtol=rtol, err_msg=what)
+
+
+def _replay(name):
+    g, orc, L, m, n, cfg = _setup(name)
+    lay = orc.lay
+    jom = g["joint_of_motor"].astype(int)
+    assert list(jom) == list(m["joint_of_motor"]), "motor -> URDF joint map of the model table vs the reference's name lookup"
+    # world constants the reference handed to the engine (A4)
+    assert int(g["engine_numSolverIterations"]) == cfg.solver_iters == 9
+    assert int(g["engine_enableConeFriction"]) == 0
+    _close(g["gravity"], [0, 0, cfg.gravity_z], "gravity")
+    assert np.float32(g["time_step"]) == np.float32(cfg.sim_dt)      # the ABI carries float32; the oracle recovers the decimal
+    traj = g["step/traj_f32"].astype(np.float64)
+    traj[..., 3:7] = g["step/traj_quat"]
+    count = 0                  # WrapperEnv._total_step_count (wrapper_env.py:47,82-83)
+    ep_step = 0
+    seen = {"wrap": 0, "warmup": 0, "done_fall": 0, "done_time": 0, "done_other": 0, "oldest": 0}
+    one = lambda i: orc.state[i:i + 1]
+    for kind, idx in g["marks"]:
+        idx = int(idx)
+        if kind == 0.0:        # ---------------- WrapperEnv.reset() ----------------
+            ep_step = 0
+            for i in range(n):
+                R = lambda key: g["reset/" + key][idx, i]
+                uni = np.ascontiguousarray(R("uniforms"))
+                L.orc_set_replay(orc.h, 1, None, None, None, None, 0, _p(uni))
+                orc.counters[_abi.CNT_TOTAL_STEP_COUNT] = count
+                obs = np.zeros((1, _abi.OBS_DIM))
+                L.orc_reset(orc.h, _p(one(i)), 1, None, _p(obs))
+                s = orc.state[i]
+                what = "reset %d robot %d " % (idx, i)
+                assert count == int(R("total_step_count")), what + "curriculum counter"
+                assert int(s[lay.sl("MAX_EP_STEPS")][0]) == int(R("max_episode_steps")), what + "time limit (wrapper_env.py:151-159)"
+                _close(obs[0], R("obs"), what + "observation")
+                _close(s[0:37], R("state37"), what + "teleported state (imitation_task.py:778-829)")
+                _close(s[lay.sl("TIME_OFFSET")], R("time_offset"), what + "time offset")
+                assert int(s[lay.sl("WARMUP")][0]) == int(R("warmup")), what + "warm-up flag"
+                _close(s[lay.sl("ORIGIN_POS")], R("origin_pos"), what + "origin pos")
+                _close(s[lay.sl("ORIGIN_ROT")], R("origin_rot"), what + "origin rot")
+                _close(s[lay.sl("PREV_PHASE")], R("prev_phase"), what + "phase")
+                _close(s[lay.sl("REF_POSE")], R("ref_pose"), what + "ref pose")
+                _close(s[lay.sl("REF_VEL")], R("ref_vel"), what + "ref vel")
+                _close(s[lay.sl("LATENCY")], R("latency"), what + "latency", atol=1e-12)
+                _close(s[lay.sl("STRENGTH")], R("strength"), what + "motor strength")
+                assert int(s[lay.sl("RING_LEN")][0]) == int(R("ring_len")) == 2, what + "ring length after reset (SURVEY 8a quirk 3)"
+                seen["warmup"] += int(R("warmup"))
+                if cfg.flags & _abi.FLAG_RANDOMIZER:
+                    # randomiser -> link mapping (controllable_env_randomizer_from_config.py:92-122, minitaur.py:812-851,951-1070)
+                    mr, ir = R("mass_ratio"), R("inertia_ratio")          # per URDF link -1..15
+                    grp = np.zeros(17, dtype=int)                         # group of link l at index l + 1
+                    for leg in range(4):
+                        for k in range(3):
+                            grp[1 + 4 * leg + k] = m["link_group"][3 * leg + k]
+                        grp[1 + 4 * leg + 3] = m["link_group"][3 * leg + 2]       # toe: merged with the lower leg
+                    _close(mr, s[lay.sl("MASS_RATIO")][grp], what + "mass ratio per link")
+                    _close(ir, s[lay.sl("INERTIA_RATIO")][grp], what + "inertia ratio per link")
+                    lf = R("lateral_friction")
+                    feet = g["foot_link_ids"].astype(int)
+                    _close(lf[feet + 1], s[lay.sl("FOOT_MU")][0] * np.ones(len(feet)), what + "foot friction")
+                    assert np.all(np.delete(lf, feet + 1) == -1.0), what + "friction set on a non-foot link"
+                    jf = R("joint_friction_force")
+                    _close(jf[[2, 6, 10, 14]], s[lay.sl("KNEE_FRICTION")], what + "knee joint friction")
+                    assert np.all(jf[[0, 1, 4, 5, 8, 9, 12, 13]] == 0.0), what + "friction motor on a hip / upper-leg joint"
+        else:                  # ---------------- WrapperEnv.step() ----------------
+            any_done = False
+            ep_step += 1
+            for i in range(n):
+                S = lambda key: g["step/" + key][idx, i]
+                tr = np.ascontiguousarray(traj[idx, i])
+                tau = np.zeros((33, 12))
+                es, er = np.ascontiguousarray(S("eff_sim")), np.ascontiguousarray(S("eff_ref"))
+                L.orc_set_replay(orc.h, 1, _p(tr), _p(tau), _p(es), _p(er), int(S("fall")), None)
+                s = orc.state[i]
+                lat, rl0 = s[lay.sl("LATENCY")][0], int(s[lay.sl("RING_LEN")][0])
+                if lat > 0 and int(lat / 0.001) + 1 >= rl0 + 1:
+                    seen["oldest"] += 1       # the "oldest entry" branch of _get_delay_obs is live during this step
+                ph0 = s[lay.sl("PREV_PHASE")][0]
+                act = np.ascontiguousarray(S("action")[None, :])
+                obs, rew, done, terms = np.zeros((1, _abi.OBS_DIM)), np.zeros(1), np.zeros(1, dtype=np.uint8), np.zeros((1, 5))
+                L.orc_step(orc.h, _p(one(i)), 1, _p(act), _p(obs), _p(rew), done.ctypes.data_as(C.c_void_p), _p(terms))
+                what = "step %d robot %d " % (idx, i)
+                _close(S("action_mutated"), S("action") + m["init_motor_angles"], what + "in-place action offset (minitaur.py:281)", atol=1e-15)
+                # torques: oracle motor order, before the direction factor; reference: URDF joint order, after it (minitaur.py:755-769)
+                _close(tau * m["motor_dir"][None, :], S("tau_urdf")[:, jom], what + "motor torques", rtol=1e-12)
+                _close(s[lay.sl("ACTION")], S("filtered_action"), what + "filtered action")
+                _close(obs[0, :84], S("obs")[:84], what + "sensor observation")
+                _close(obs[0, 84:], S("obs")[84:], what + "target observation")
+                _close(terms[0], S("terms"), what + "reward terms")
+                _close(rew[0], S("reward"), what + "reward")
+                assert bool(done[0]) == bool(S("done")), what + "done (reasons %d)" % int(s[lay.sl("DONE_REASON")][0])
+                assert int(s[lay.sl("EP_STEP")][0]) == int(S("env_step_counter")) == ep_step
+                _close(s[lay.sl("ORIGIN_POS")], S("origin_pos"), what + "origin pos (cycle sync)")
+                _close(s[lay.sl("PREV_PHASE")], S("prev_phase"), what + "phase")
+                _close(s[lay.sl("REF_POSE")], S("ref_pose"), what + "ref pose")
+                _close(s[lay.sl("REF_VEL")], S("ref_vel"), what + "ref vel")
+                # delayed control observation: the 19 floats the oracle keeps of the reference's 43 (q 12 | qd 12 | tau 12 | quat 4 | rate 3)
+                co = np.zeros(19)
+                L.orc_ctrl_obs_probe(orc.h, _p(s), _p(co))
+                ref_co = S("ctrl_obs")
+                _close(co, np.concatenate([ref_co[0:12], ref_co[36:43]]), what + "delayed control observation")
+                reason = int(s[lay.sl("DONE_REASON")][0])
+                seen["wrap"] += int(S("prev_phase") < ph0)
+                seen["done_fall"] += int(bool(reason & _abi.DONE_CONTACT_FALL))
+                seen["done_time"] += int(bool(reason & _abi.DONE_TIME_LIMIT))
+                seen["done_other"] += int(bool(reason & (_abi.DONE_ROOT_POS | _abi.DONE_ROOT_ROT)))
+                any_done = any_done or bool(done[0])
+            if any_done:
+                count += n     # wrapper_env.py:82-83 (LegacyListEnv mirrors this on the device counter)
+            assert count == int(g["step/total_step_count"][idx, 0])
+    L.orc_set_replay(orc.h, 0, None, None, None, None, 0, None)
+    orc.close()
+    return seen
+
+
+def test_laikago_train_mode_replay():
+    seen = _replay("task_laikago.npz")
+    # the fixture must actually exercise the branches it claims to pin
+    assert seen["wrap"] >= 3 and seen["done_fall"] >= 2 and seen["done_time"] >= 2 and seen["done_other"] >= 2, seen
+    assert seen["oldest"] >= 5 and seen["warmup"] >= 1, seen
+
+
+def test_mini_cheetah_train_mode_replay():
+    seen = _replay("task_mini_cheetah.npz")
+    assert seen["wrap"] >= 2 and seen["done_fall"] >= 1 and seen["done_other"] >= 2, seen
+
+
+def test_laikago_test_mode_replay():
+    seen = _replay("task_laikago_testmode.npz")
+    assert seen["wrap"] >= 1 and seen["done_time"] == 0 and seen["oldest"] >= 1, seen
