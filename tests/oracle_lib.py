@@ -20,6 +20,17 @@ def P(a):
     return a.ctypes.data_as(dp)
 
 
+def dec32(v):
+    """What the oracle makes of a float32 ABI value (orr_oracle.c dec()): the shortest decimal (<= 7 significant digits)
+    that rounds to the same float32 -- i.e. the constant as the reference's Python source spells it -- else the exact value."""
+    a = np.asarray(v, dtype=np.float32)
+    out = np.empty(a.shape, dtype=np.float64)
+    for idx in np.ndindex(a.shape):
+        d = float("%.7g" % float(a[idx]))
+        out[idx] = d if np.float32(d) == a[idx] else float(a[idx])
+    return out if out.shape else float(out)
+
+
 def lib():
     global _lib
     if _lib is None:

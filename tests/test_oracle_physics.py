@@ -14,12 +14,12 @@ from tests.oracle_lib import P
 def make_env(robot="laikago", n=1, **kw):
     cfg = config.make_config(n, mode="test", enable_randomizer=False, auto_reset=False, **kw)
     model = robots.ROBOTS[robot]()
-    # the C-ABI model table is float32: round the independent reference's copy identically
+    # the C-ABI model table is float32 and the oracle recovers decimal constants from it: same for the independent reference's copy
     for k, v in list(model.items()):
         if isinstance(v, np.ndarray) and v.dtype == np.float64:
-            model[k] = v.astype(np.float32).astype(np.float64)
+            model[k] = ol.dec32(v)
         elif isinstance(v, float):
-            model[k] = float(np.float32(v))
+            model[k] = ol.dec32(v)
     clip = motion.MotionClip("laikago_pace" if robot == "laikago" else "minicheetah_trot")
     models = [None, None]
     t = robots.ROBOT_TYPE_ID[robot]
