@@ -198,39 +198,6 @@ def test_shipped_policy_on_gpu():
     env.close()
 
 
-def test_full_size_properties():
-    """BASELINE config 2 size (4096 Laikago robots, randomiser on, auto-reset): size-independent properties."""
-    import torch
-    n = 4096
-    outs = []
-    for rep in range(2):
-        env, orc = make_pair("laikago", n=n, randomizer=True, auto_reset=True, mode="train", seed=21)
-        orc.close()
-        obs = env.reset()
-        g = torch.Generator(device="cpu"); g.manual_seed(0)
-        total_done = 0
-        for k in range(40):
-            a = (torch.randn(n, 12, generator=g) * 0.125).to(env.device)
-            obs, rew, done, _ = env.step(a)
-            assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
-            assert (rew >= 0).all() and (rew <= 1.0 + 1e-6).all()
-            total_done += int(done.sum().item())
-        torch.cuda.synchronize()
-        cnt = env.counters.cpu().numpy()
-        assert cnt[_abi.CNT_TOTAL_STEP_COUNT] == total_done          # wrapper_env.py:82-83 per reset robot
-        assert cnt[_abi.CNT_TOTAL_TIMESTEPS] == 40 * n
-        assert cnt[_abi.CNT_TICKET] == 0 and cnt[_abi.CNT_DONE_ACCUM] == 0
-        assert total_done > 0                                          # curriculum start: 20-step episodes
-        ep = env.field_int("EP_STEP")[:, 0].cpu().numpy()
-        assert ep.max() < 20 and ep.min() >= 0
-        low = torch.tensor(env.observation_space.low[48:84], device=env.device)
-        assert (obs[:, 48:84] >= low - 1e-5).all()
-        outs.append((obs.cpu().numpy().copy(), env.state.cpu().numpy().copy()))
-        env.close()
-    np.testing.assert_array_equal(outs[0][0], outs[1][0])              # bitwise reproducible for a fixed seed
-    np.testing.assert_array_equal(outs[0][1], outs[1][1])
-
-
 def test_masked_reset_and_legacy_protocol():
     import torch
     from openroborl_amd.env import VecQuadrupedEnv, LegacyListEnv
