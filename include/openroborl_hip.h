@@ -96,6 +96,7 @@ enum orr_state_offset_e {
 #define ORR_DONE_ROOT_ROT 4     /* imitation_task.py:558-565 */
 #define ORR_DONE_TIME_LIMIT 8   /* wrapper_env.py:79 */
 #define ORR_DONE_NAN 16         /* new: non-finite state guard */
+#define ORR_DONE_MOTION_OVER 32 /* imitation_task.py:532,567 + motion_data.py:265-276: a non-looping clip played to its end */
 
 /* orr_config.flags */
 #define ORR_FLAG_AUTO_RESET 1        /* per-robot masked auto-reset inside orr_step (native mode) */
@@ -190,6 +191,7 @@ typedef struct orr_handle orr_handle;
 
 const char* orr_last_error(void);
 int32_t orr_abi_version(void);
+const char* orr_source_hash(void);              /* hash of the sources this library was built from (host loader: stale-build check) */
 int32_t orr_state_stride(void);                 /* ORR_STATE_STRIDE */
 int32_t orr_layout_count(void);                 /* number of fields in ORR_STATE_FIELDS */
 const char* orr_layout_name(int32_t i);
@@ -202,6 +204,9 @@ int32_t orr_sizeof_model(void);
 /* replaces LocomotionGymEnv._init world setup (quadruped_gym_env.py:158-211) */
 int32_t orr_create(const orr_config* cfg, orr_handle** out);
 int32_t orr_destroy(orr_handle* h);
+
+/* replaces LocomotionGymEnv.seed (quadruped_gym_env.py:59-61): new key of the counter-based RNG, used from the next reset on */
+int32_t orr_set_seed(orr_handle* h, uint64_t seed);
 
 /* replaces loadURDF + _build_urdf_ids + _record_*_from_urdf (minitaur.py:201-230,812-851,897-903) */
 int32_t orr_set_model(orr_handle* h, int32_t robot_type, const orr_model* model_host);

@@ -15,7 +15,7 @@ RING_DEPTH = 44
 RING_ENTRY = 20
 STATE_STRIDE = 1216
 
-DONE_CONTACT_FALL, DONE_ROOT_POS, DONE_ROOT_ROT, DONE_TIME_LIMIT, DONE_NAN = 1, 2, 4, 8, 16
+DONE_CONTACT_FALL, DONE_ROOT_POS, DONE_ROOT_ROT, DONE_TIME_LIMIT, DONE_NAN, DONE_MOTION_OVER = 1, 2, 4, 8, 16, 32
 
 FLAG_AUTO_RESET = 1
 FLAG_RANDOMIZER = 2

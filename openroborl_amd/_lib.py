@@ -27,50 +27,85 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O2", "-fPIC", "-shared", "-std=c++17",
                "-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
 
 EXPORTS = [
-    "orr_last_error", "orr_abi_version", "orr_state_stride", "orr_layout_count", "orr_layout_name",
+    "orr_last_error", "orr_abi_version", "orr_source_hash", "orr_state_stride", "orr_layout_count", "orr_layout_name",
     "orr_layout_offset", "orr_layout_size", "orr_layout_is_int", "orr_sizeof_config", "orr_sizeof_model",
-    "orr_create", "orr_destroy", "orr_set_model", "orr_set_motion", "orr_bind", "orr_reset", "orr_step",
+    "orr_create", "orr_destroy", "orr_set_seed", "orr_set_model", "orr_set_motion", "orr_bind", "orr_reset", "orr_step",
     "orr_time_steps",
     "orr_policy_packed_size", "orr_policy_pack", "orr_policy_forward", "orr_gae",
 ]
 
 
+def source_hash():
+    """sha256 over the sources the library is built from (file names + contents) and the compiler flags."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in sorted(DEPS):
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(HIPCC_FLAGS).encode())
+    return h.hexdigest()[:32]
+
+
+def library_hash(path=LIB_PATH):
+    """The source hash embedded in a built library (orr_source_hash()), or None."""
+    if not os.path.exists(path):
+        return None
+    try:
+        L = C.CDLL(path)
+        L.orr_source_hash.restype = C.c_char_p
+        return L.orr_source_hash().decode()
+    except (OSError, AttributeError):
+        return None
+
+
 def needs_build():
-    if not os.path.exists(LIB_PATH):
-        return True
-    t = os.path.getmtime(LIB_PATH)
-    return any(os.path.getmtime(d) > t for d in DEPS if os.path.exists(d))
+    """True when the in-tree library is missing or was not built from the sources on disk (content hash, not mtimes:
+    a snapshot copied to another box keeps its .so but not necessarily its timestamps)."""
+    return library_hash() != source_hash()
 
 
 def build(force=False, verbose=False, out_path=None, extra_flags=()):
     """Compile the HIP kernels + C-ABI for gfx950 into the in-tree shared library (or `out_path`, with `extra_flags`
-    for the env kernels: development builds such as tools/phase_cycles.py)."""
+    for the env kernels: development builds such as tools/phase_cycles.py).  Concurrent callers (one per rank under
+    torchrun) are serialised by a file lock; objects and the library are written under process-unique names and the
+    library is moved into place atomically, so nobody can dlopen a half-written file."""
+    import fcntl
+    dev_build = out_path is not None
     if out_path is None:
-        if not force and not needs_build():
-            return LIB_PATH
         out_path = LIB_PATH
-    flags = [f for f in HIPCC_FLAGS if f != "-shared"] + ["-c"]
-    for var in ("ORR_WAVES_PER_EU", "ORR_LANES_PER_ROBOT"):      # tuning experiments only
-        if os.environ.get(var):
-            flags.append("-D%s=%d" % (var, int(os.environ[var])))
-    for d in os.environ.get("ORR_EXTRA_DEFS", "").split():
-        flags.append("-D" + d)
-    flags += list(extra_flags)
-    tag = "" if out_path == LIB_PATH else "." + os.path.basename(out_path)
-    obj_env = os.path.join(PKG_DIR, "csrc", "orr_kernels%s.o" % tag)
-    obj_pol = os.path.join(PKG_DIR, "csrc", "orr_policy%s.o" % tag)
-    cmds = [[HIPCC] + flags + ["-o", obj_env, SRC],
-            # the policy forward pass (matrix cores) is its own translation unit with the compiler's default scheduling
-            [HIPCC, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-c", "-o", obj_pol, SRC_POLICY],
-            [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out_path, obj_env, obj_pol]]
-    for cmd in cmds:
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
-    if tag:   # development builds leave no objects behind
-        for o in (obj_env, obj_pol):
-            if os.path.exists(o):
-                os.remove(o)
+    with open(os.path.join(PKG_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not dev_build and not force and not needs_build():
+                return LIB_PATH              # another rank built it while this one waited for the lock
+            flags = [f for f in HIPCC_FLAGS if f != "-shared"] + ["-c", '-DORR_SOURCE_HASH="%s"' % source_hash()]
+            for var in ("ORR_WAVES_PER_EU", "ORR_LANES_PER_ROBOT"):      # tuning experiments only
+                if os.environ.get(var):
+                    flags.append("-D%s=%d" % (var, int(os.environ[var])))
+            for d in os.environ.get("ORR_EXTRA_DEFS", "").split():
+                flags.append("-D" + d)
+            flags += list(extra_flags)
+            tag = ".%d" % os.getpid()
+            obj_env = os.path.join(PKG_DIR, "csrc", "orr_kernels%s.o" % tag)
+            obj_pol = os.path.join(PKG_DIR, "csrc", "orr_policy%s.o" % tag)
+            tmp_so = out_path + tag + ".tmp"
+            cmds = [[HIPCC] + flags + ["-o", obj_env, SRC],
+                    # the policy forward pass (matrix cores) is its own translation unit with the compiler's default scheduling
+                    [HIPCC, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-c", "-o", obj_pol, SRC_POLICY],
+                    [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp_so, obj_env, obj_pol]]
+            try:
+                for cmd in cmds:
+                    if verbose:
+                        print(" ".join(cmd))
+                    subprocess.check_call(cmd)
+                os.replace(tmp_so, out_path)
+            finally:
+                for o in (obj_env, obj_pol, tmp_so):
+                    if os.path.exists(o):
+                        os.remove(o)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return out_path
 
 
@@ -81,19 +116,29 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if needs_build() and not os.environ.get("ORR_LIB_PATH"):
+    path = os.environ.get("ORR_LIB_PATH", LIB_PATH)   # override = tuning experiments (A/B of two builds)
+    if path == LIB_PATH and needs_build():
         try:
             build()
-        except Exception as e:  # stale library on a box without hipcc is still usable
-            if not os.path.exists(LIB_PATH):
-                raise RuntimeError("libopenroborl_hip.so is missing and could not be built: %r" % (e,))
-    L = C.CDLL(os.environ.get("ORR_LIB_PATH", LIB_PATH))   # override = tuning experiments (A/B of two builds)
+        except Exception as e:
+            # never run kernels that do not match the sources silently: a stale library is an error unless explicitly allowed
+            if os.path.exists(LIB_PATH) and os.environ.get("ORR_ALLOW_STALE_LIB"):
+                import warnings
+                warnings.warn("libopenroborl_hip.so does NOT match the sources (built from %s, sources are %s) and could not be "
+                              "rebuilt (%r); using it because ORR_ALLOW_STALE_LIB is set" % (library_hash(), source_hash(), e))
+            else:
+                raise RuntimeError("libopenroborl_hip.so is missing or stale and could not be built: %r "
+                                   "(set ORR_ALLOW_STALE_LIB=1 to use a stale library anyway)" % (e,))
+    L = C.CDLL(path)
     vp = C.c_void_p
     L.orr_last_error.restype = C.c_char_p
     L.orr_abi_version.restype = C.c_int32
+    L.orr_source_hash.restype = C.c_char_p
     L.orr_create.restype = C.c_int32
     L.orr_create.argtypes = [C.POINTER(_abi.OrrConfig), C.POINTER(vp)]
     L.orr_destroy.argtypes = [vp]
+    L.orr_set_seed.restype = C.c_int32
+    L.orr_set_seed.argtypes = [vp, C.c_uint64]
     L.orr_set_model.restype = C.c_int32
     L.orr_set_model.argtypes = [vp, C.c_int32, C.POINTER(_abi.OrrModel)]
     L.orr_set_motion.restype = C.c_int32

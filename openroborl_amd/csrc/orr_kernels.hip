@@ -216,6 +216,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
     if (geti(S, O(STEP_COUNTER)) > 0 && fall) reason |= ORR_DONE_CONTACT_FALL;
     if (pe > c.dist_fail_threshold * c.dist_fail_threshold) reason |= ORR_DONE_ROOT_POS;
     if (fabsf(ang) > c.rot_fail_threshold) reason |= ORR_DONE_ROOT_ROT;
+    if (!(clip.flags & ORR_CLIP_WRAP) && t >= clip.dur) reason |= ORR_DONE_MOTION_OVER;  // is_motion_over (:224-233)
     bool bad = false;
     for (int i = lane; i < 37; i += kLanes) bad = bad || !(fabsf(S.s[O(POS) + i]) < 1e30f);
     if (((__ballot(bad) >> (sub * kLanes)) & ((1ull << (kLanes - 1)) * 2ull - 1ull)) != 0ull) reason |= ORR_DONE_NAN;
@@ -268,6 +269,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
   PT_FLUSH();
   // the last wave to finish folds this launch's done count into the curriculum counter (wrapper_env.py:82-83)
   if (P.counters && valid && lane == 0) {
+    __threadfence();  // this wave's DONE_ACCUM / episode-log writes are visible before its ticket is
     const unsigned long long ticket = atomicAdd((unsigned long long*)&P.counters[ORR_CNT_TICKET], 1ull);
     if (ticket == (unsigned long long)P.cfg.num_robots - 1ull) {
       const unsigned long long nd = atomicExch((unsigned long long*)&P.counters[ORR_CNT_DONE_ACCUM], 0ull);
@@ -316,8 +318,12 @@ static const field_t g_fields[] = {
 
 extern "C" {
 
+#ifndef ORR_SOURCE_HASH
+#define ORR_SOURCE_HASH "unknown"
+#endif
 const char* orr_last_error(void) { return g_err; }
 int32_t orr_abi_version(void) { return ORR_ABI_VERSION; }
+const char* orr_source_hash(void) { return ORR_SOURCE_HASH; }
 int32_t orr_state_stride(void) { return ORR_STATE_STRIDE; }
 int32_t orr_layout_count(void) { return (int32_t)(sizeof(g_fields) / sizeof(g_fields[0])); }
 const char* orr_layout_name(int32_t i) { return g_fields[i].name; }
@@ -352,6 +358,12 @@ int32_t orr_create(const orr_config* cfg, orr_handle** out) {
   hipEventCreate(&h->ev0);
   hipEventCreate(&h->ev1);
   *out = h;
+  return 0;
+}
+
+int32_t orr_set_seed(orr_handle* h, uint64_t seed) {
+  if (!h) return fail(-1, "orr_set_seed: null handle");
+  h->cfg.seed = seed;  // read by the next launch: the RNG is counter-based, keyed by (seed, robot index, episode index)
   return 0;
 }
 

@@ -175,10 +175,11 @@ class VecQuadrupedEnv(object):
         return self.cfg.action_repeat * self.cfg.sim_dt
 
     def seed(self, seed=None):
-        """quadruped_gym_env.py:59-61.  The RNG is counter-based (Philox keyed by seed, robot, episode); the
-        seed is fixed at construction (pass seed= to the constructor), so this only reports it."""
+        """quadruped_gym_env.py:59-61.  The RNG is counter-based (Philox keyed by seed, global robot index, episode index):
+        a new seed takes effect for every episode that starts after this call.  Returns [seed] like gym."""
         if seed is not None and (int(seed) & 0xFFFFFFFFFFFFFFFF) != int(self.cfg.seed):
-            raise ValueError("the env seed is fixed at construction; build a new env with seed=%r" % (seed,))
+            self.cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+            _lib.check(self.L.orr_set_seed(self.h, self.cfg.seed), self.L)
         return [int(self.cfg.seed)]
 
     def close(self):
@@ -257,7 +258,7 @@ class VecQuadrupedEnv(object):
         c = self.counters.cpu().numpy()
         reasons = self.field_int("DONE_REASON")[:, 0].cpu().numpy()
         names = (("contact_fall", _abi.DONE_CONTACT_FALL), ("root_pos", _abi.DONE_ROOT_POS), ("root_rot", _abi.DONE_ROOT_ROT),
-                 ("time_limit", _abi.DONE_TIME_LIMIT), ("non_finite", _abi.DONE_NAN))
+                 ("time_limit", _abi.DONE_TIME_LIMIT), ("non_finite", _abi.DONE_NAN), ("motion_over", _abi.DONE_MOTION_OVER))
         return {"total_timesteps": int(c[_abi.CNT_TOTAL_TIMESTEPS]), "curriculum_counter": int(c[_abi.CNT_TOTAL_STEP_COUNT]),
                 "episodes_logged": int(c[_abi.CNT_EPISODES]), "episodes_dropped": int(c[_abi.CNT_EPLOG_DROPPED]),
                 "last_done_reason": {k: int(((reasons & bit) != 0).sum()) for k, bit in names},

@@ -33,14 +33,38 @@ def load_parameters(path):
     return {_norm_key(k): params[k].astype(np.float32) for k in params.files}
 
 
+# variables of the reference's ImitationPolicy graph in the order stable-baselines saves them (parameter_list of the shipped
+# zips; tests/golden/policy_parameter_list.json).  `model/q/*` is the action-value head stable-baselines attaches to every
+# feed-forward policy (common/policies.py proba_distribution_from_latent); PPO1 never trains or reads it, but
+# BaseRLModel.load_parameters(exact_match=True) (common/base_class.py:437-500) refuses a zip without it.
+SB_PARAMETER_LIST = (("model/pi_fc0/w:0", (160, 512)), ("model/pi_fc0/b:0", (512,)), ("model/vf_fc0/w:0", (160, 512)),
+                     ("model/vf_fc0/b:0", (512,)), ("model/pi_fc1/w:0", (512, 256)), ("model/pi_fc1/b:0", (256,)),
+                     ("model/vf_fc1/w:0", (512, 256)), ("model/vf_fc1/b:0", (256,)), ("model/vf/w:0", (256, 1)),
+                     ("model/vf/b:0", (1,)), ("model/pi/w:0", (256, 12)), ("model/pi/b:0", (12,)), ("model/q/w:0", (256, 12)),
+                     ("model/q/b:0", (12,)))
+
+
 def save_parameters_zip(path, params, data=None):
     """Write weights in the stable-baselines zip layout (`data` JSON, `parameter_list` JSON, `parameters` npz;
     stable_baselines/common/base_class.py:552-590) so that the reference's `agent.load_parameters(model_file)`
-    (run.py:220-221) can read a policy trained here.  `data` carries no pickled objects (load_parameters ignores it)."""
+    (run.py:220-221, exact_match=True) can read a policy trained here: the FULL variable set of the reference graph in its
+    saved order.  The unused q head is carried over when `params` holds one (a policy warm-started from a reference zip) and
+    zero-filled otherwise.  `data` carries no pickled objects (load_parameters ignores it)."""
     import json
-    names = sorted(params)
+    out = {}
+    for name, shape in SB_PARAMETER_LIST:
+        if name in params:
+            v = np.asarray(params[name], dtype=np.float32)
+            if v.shape != shape:
+                raise ValueError("%s has shape %s, the reference graph expects %s" % (name, v.shape, shape))
+        elif name.startswith("model/q/"):
+            v = np.zeros(shape, dtype=np.float32)
+        else:
+            raise ValueError("missing variable %s" % name)
+        out[name] = v
+    names = [n for n, _ in SB_PARAMETER_LIST]
     buf = io.BytesIO()
-    np.savez(buf, **{k: np.asarray(params[k], dtype=np.float32) for k in names})
+    np.savez(buf, **out)
     with zipfile.ZipFile(path, "w") as z:
         z.writestr("data", json.dumps(data or {}))
         z.writestr("parameter_list", json.dumps(names))

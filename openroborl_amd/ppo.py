@@ -64,10 +64,13 @@ class ActorCritic(object):
             for i in range(len(hidden)):
                 self._init("model/%s_fc%d" % (net, i), dims[i], dims[i + 1], g, math.sqrt(2.0))
             self._init("model/%s" % net, dims[-1], out, g, 0.01 if net == "pi" else 1.0)
+        self.extra = {}            # variables of a loaded zip that this learner does not train (model/q/*): re-emitted by state_dict()
         if params is not None:
             for k, v in params.items():
                 if k in self.p:
                     self.p[k].data.copy_(torch.as_tensor(np.asarray(v), dtype=torch.float32))
+                else:
+                    self.extra[k] = np.asarray(v, dtype=np.float32).copy()
         for v in self.p.values():
             v.requires_grad_(True)
         self.fused = None          # policy_hip.FusedActorCritic once enable_fused() was called
@@ -130,7 +133,9 @@ class ActorCritic(object):
         return (-0.5 * ((actions - mu) ** 2) / var - 0.5 * math.log(2.0 * math.pi * var)).sum(dim=1)
 
     def state_dict(self):
-        return {k: v.detach().cpu().numpy() for k, v in self.p.items()}
+        d = {k: v.detach().cpu().numpy() for k, v in self.p.items()}
+        d.update(self.extra)
+        return d
 
 
 class PPO(object):

@@ -27,6 +27,7 @@ Outputs (committed):
   sensors.npz      3-deep history layout of the flattened 84-d proprioceptive observation
   spaces.npz       160-d observation-space bounds + action bounds pickled inside the policy zips
   policy_*.npz     shipped MLP weights (data) for the behavioural probe
+  policy_parameter_list.json   variable names + shapes of a shipped policy zip, in saved order
 """
 import base64
 import io
@@ -257,6 +258,12 @@ def gen_spaces_and_policies():
                 out["%s/%s/low" % (pol, key)] = np.asarray(obj.__dict__["low"])
                 out["%s/%s/high" % (pol, key)] = np.asarray(obj.__dict__["high"])
             params = np.load(io.BytesIO(z.read("parameters")))
+            if pol == "laikago_pace":
+                # variable names, in the order stable-baselines saved them, with shapes (data): what a zip must contain for
+                # BaseRLModel.load_parameters(exact_match=True) (stable_baselines/common/base_class.py:437-500) to accept it
+                plist = json.loads(z.read("parameter_list"))
+                with open(os.path.join(HERE, "policy_parameter_list.json"), "w") as f:
+                    json.dump([[k, list(params[k].shape)] for k in plist], f, indent=0)
             w = {k.replace("/", "__").replace(":", "_"): params[k].astype(np.float32) for k in params.files
                  if k.startswith("model/pi") }
             np.savez_compressed(os.path.join(HERE, "policy_%s.npz" % pol), **w)

@@ -344,7 +344,7 @@ def test_checkpoint_resume_is_bitwise():
         assert torch.equal(o, o0) and torch.equal(r, r0) and torch.equal(d, d0)
     st = env.stats()
     assert st["total_timesteps"] > 0
-    assert set(st["last_done_reason"]) == {"contact_fall", "root_pos", "root_rot", "time_limit", "non_finite"}
+    assert set(st["last_done_reason"]) == {"contact_fall", "root_pos", "root_rot", "time_limit", "non_finite", "motion_over"}
     env.close()
 
 
@@ -415,4 +415,27 @@ def test_auto_reset_inside_step_matches_oracle():
     for name in ("POS", "QUAT", "Q"):
         sl = env.layout.sl(name)
         assert np.median(np.abs(g[kept][:, sl] - orc.state[kept][:, sl])) < 1e-4, name
+    env.close(); orc.close()
+
+
+def test_motion_over_on_a_non_looping_clip(tmp_path):
+    """ORR_DONE_MOTION_OVER (imitation_task.py:224-233,532,567) on the device, against the oracle, for a Clamp clip."""
+    import torch
+    from openroborl_amd.env import VecQuadrupedEnv
+    from tests.test_oracle_env import clamp_clip
+    clip = clamp_clip(tmp_path)
+    n = 32
+    env = VecQuadrupedEnv(num_robot=n, seed=3, robot="laikago", motion_file=clip.path, mode="test", enable_randomizer=False, auto_reset=False)
+    orc = ol.OracleEnv(env.cfg, env.models, env.clips, n, robot_type=env.robot_type, clip_id=env.clip_id, threads=4)
+    env.reset(); orc.reset()
+    orc.state[:] = gpu_state64(env)
+    seen = np.zeros(n, dtype=bool)
+    for k in range(30):          # duration 0.63 s = 19.2 steps, + 0.25 s = 7.6 steps for a warm-up episode
+        a = np.zeros((n, 12), dtype=np.float32)
+        env.step(torch.from_numpy(a).to(env.device)); orc.step(a.astype(np.float64))
+        rg = env.field_int("DONE_REASON")[:, 0].cpu().numpy() & _abi.DONE_MOTION_OVER
+        ro = orc.field("DONE_REASON")[:, 0].astype(int) & _abi.DONE_MOTION_OVER
+        np.testing.assert_array_equal(rg, ro)
+        seen |= rg != 0
+    assert seen.all()
     env.close(); orc.close()

@@ -293,3 +293,37 @@ def test_shipped_policy_tracks_the_clip():
     assert np.all(env.field("DONE_REASON")[:, 0] == _abi.DONE_TIME_LIMIT)
     assert ret.min() > 350.0, ret
     env.close()
+
+
+def clamp_clip(tmp_path):
+    """laikago_pace re-saved as a non-looping clip (LoopMode "Clamp", motion_data.py:83-97)."""
+    import json
+    js = json.load(open(motion.resolve_path("laikago_pace")))
+    js["LoopMode"] = "Clamp"
+    path = str(tmp_path / "pace_clamp.txt")
+    json.dump(js, open(path, "w"))
+    return motion.MotionClip(path)
+
+
+def test_motion_over_ends_a_non_looping_clip(tmp_path):
+    """_terminal_condition ORs in is_motion_over (imitation_task.py:224-233,532,567; motion_data.py:265-276): a Clamp clip
+    ends the episode once the motion time reaches its duration; a Wrap clip never does."""
+    clip = clamp_clip(tmp_path)
+    assert not clip.loop_wrap and not (clip.flags & _abi.CLIP_WRAP)
+    cfg = config.make_config(8, mode="test", enable_randomizer=False, auto_reset=False, seed=3)
+    models = [robots.ROBOTS["laikago"](), None]
+    env = ol.OracleEnv(cfg, models, [clip], 8, robot_type=0)
+    env.reset()
+    lay = env.lay
+    toff = env.field("TIME_OFFSET")[:, 0].copy()
+    warm = env.field("WARMUP")[:, 0] > 0
+    steps_to_end = np.ceil((clip.duration - toff + 0.25 * warm) / 0.033 - 1e-9).astype(int)
+    seen = np.zeros(8, dtype=bool)
+    for k in range(1, 30):
+        _, _, done = env.step(np.zeros((8, 12)))
+        reason = env.field("DONE_REASON")[:, 0].astype(int)
+        over = (reason & _abi.DONE_MOTION_OVER) != 0
+        np.testing.assert_array_equal(over, k >= steps_to_end)
+        assert done[over].all()
+        seen |= over
+    assert seen.all()

@@ -79,7 +79,14 @@ def test_stable_baselines_zip_round_trip(tmp_path):
     import json, zipfile
     with zipfile.ZipFile(path) as z:
         assert set(z.namelist()) == {"data", "parameter_list", "parameters"}
-        assert json.loads(z.read("parameter_list"))[0].startswith("model/")
+        # the reference's load_parameters(exact_match=True) needs every variable of its graph: same names, order and shapes
+        # as the shipped laikago_pace.zip (fixture from tests/golden/make_golden.py), including the unused q head
+        want = json.load(open(os.path.join(ol.GOLDEN, "policy_parameter_list.json")))
+        assert json.loads(z.read("parameter_list")) == [k for k, _ in want]
+        import io
+        saved = np.load(io.BytesIO(z.read("parameters")))
+        assert [list(saved[k].shape) for k, _ in want] == [shape for _, shape in want]
+        assert not saved["model/q/w:0"].any()            # synthesised: this learner has no q head
     w = pol.load_parameters(path)
     for k, v in m.state_dict().items():
         np.testing.assert_array_equal(w[k], v)
@@ -87,3 +94,9 @@ def test_stable_baselines_zip_round_trip(tmp_path):
     obs = torch.randn(4, 160)
     np.testing.assert_allclose(p.mean(obs).numpy(), m.mean(obs).detach().numpy(), atol=1e-6)
     np.testing.assert_allclose(p.value(obs).numpy(), m.value(obs).detach().numpy(), atol=1e-6)
+    # a policy warm-started from a reference-style zip keeps that zip's q head when it is saved again
+    w["model/q/w:0"] = np.full((256, 12), 0.25, dtype=np.float32)
+    m2 = ppo.ActorCritic("cpu", params=w)
+    path2 = str(tmp_path / "model2.zip")
+    pol.save_parameters_zip(path2, m2.state_dict())
+    assert (pol.load_parameters(path2)["model/q/w:0"] == 0.25).all()
