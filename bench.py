@@ -104,11 +104,22 @@ def cpu_baseline(env):
                          "sample": "%d robots x %d env steps" % (min(n, env.num_robot), steps)})
         except Exception as e:      # noqa: BLE001  (e.g. no compiler on the box for the f32 build): report, keep the other rows
             rows.append({"build": build, "cores": threads, "robots": n, "error": repr(e)})
-    best = max((r for r in rows if "value" in r), key=lambda r: r["value"])
+    # the real reference physics, if this box happens to have it (it does not on this pool: SURVEY.md section 8c)
+    pyb = "unavailable: neither pybullet nor pybullet_data is installed; the rows above time the CPU restatement instead"
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import pybullet_ref
+        if pybullet_ref.available():
+            name = "mini_cheetah" if int(env.robot_type[0]) == 1 else "laikago"
+            rows += [pybullet_ref.time_path(name, k, seconds=5.0) for k in (1, 16)]
+            pyb = "available: rows of kind 'reference' are real PyBullet through tools/pybullet_ref.py"
+    except Exception as e:          # noqa: BLE001
+        pyb = "probe failed: %r" % (e,)
+    best = max((r for r in rows if "value" in r and r.get("kind", "port") == "port"), key=lambda r: r["value"])
     return {"value": best["value"], "unit": "env steps/s", "cores": best["cores"], "kind": "port",
             "sample": "%s of the same workload, oracle/orr_oracle.c (%s), %d OpenMP threads; the fastest of the rows below"
                       % (best["sample"], best["build"], best["cores"]),
-            "host_cpu_count": os.cpu_count(), "host_cores_available": avail,
+            "host_cpu_count": os.cpu_count(), "host_cores_available": avail, "pybullet": pyb,
             "note": "a restatement of the same algorithm (un-tuned articulated-body + PGS code), not PyBullet; never the target",
             "rows": rows}
 

@@ -54,25 +54,13 @@ RIGID = ["POS", "QUAT", "LINVEL", "ANGVEL", "Q", "QD"]
 def test_physics_substep_parity(robot):
     """Row C in isolation: ABA + contact/limit/friction rows + PGS + integration, fixed torques."""
     import torch
+    from tests.parity_inputs import substep_parity_inputs
     n = 64
     env, orc = make_pair(robot, n=n)
     env.reset(); orc.reset()
-    rng = np.random.RandomState(0)
-    st = gpu_state64(env)
-    lay = env.layout
-    # spread the robots over airborne / touching / penetrating configurations with random velocities
-    st[:, lay.sl("POS")][:, 2] += rng.uniform(-0.03, 0.15, n)
-    st[:, lay.sl("LINVEL")] += rng.randn(n, 3) * 0.3
-    st[:, lay.sl("ANGVEL")] += rng.randn(n, 3) * 0.5
-    st[:, lay.sl("QD")] += rng.randn(n, 12) * 1.0
-    st[:, lay.sl("KNEE_FRICTION")] = rng.uniform(0, 0.05, (n, 4)) * (rng.rand(n, 1) < 0.5)
-    st[:, lay.sl("FOOT_MU")] = rng.uniform(0.5, 1.25, (n, 1))
-    st[: n // 8, lay.sl("Q")][:, 2] = -2.2 if robot == "laikago" else st[: n // 8, lay.sl("Q")][:, 2]  # knee into its limit
-    st = statemod.to_float64(lay, statemod.from_float64(lay, st))   # both sides start from float32-representable numbers
+    _, _, _, st, tau = substep_parity_inputs(robot, n)       # the same seeded inputs tools/pybullet_ref.py feeds to PyBullet
     push_state(env, st); orc.state[:] = st
-    tau = rng.uniform(-15, 15, (n, 12))
     tg = torch.tensor(tau, dtype=torch.float32, device=env.device)
-    tau = tg.cpu().numpy().astype(np.float64)
     # one sub-step: positions agree to 2e-6 (they move by dt * velocity), velocities (up to ~20 rad/s, through the
     # articulated-body solve in float32) to 1.5e-4; after 8 sub-steps with contacts 1e-3
     for nsub, ptol, vtol in ((1, 2e-6, 1.5e-4), (8, 1e-4, 1e-3)):

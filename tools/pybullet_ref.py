@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""PyBullet harness: the real reference physics, for whoever has a machine with `pybullet` + `pybullet_data`.
+
+Neither package is installed in the build container or on the GPU boxes, so row C of the scope
+table -- `pybullet.stepSimulation` -- is the one piece of the path whose parity stays unpinned.  This script is what closes
+it.  It is written from the reference's call semantics (quadruped_gym_env.py:158-239 world setup and sub-step loop,
+minitaur.py:201-230,465-483,725-769,853-917 robot setup / torque application / readback, imitation_task.py:341-572 reads),
+never from its files, and does three things when `import pybullet` succeeds:
+
+  --dump-urdf     per link of laikago/laikago_toes_limits.urdf and mini_cheetah/mini_cheetah.urdf: mass, local inertia
+                  diagonal, inertial frame, joint frame / axis / limits / parent -> tests/golden/pybullet_urdf_<robot>.json,
+                  and the same data printed in the layout of openroborl_amd/robots.py (the hand-authored table it replaces);
+  --dump-substeps the seeded inputs of tests/test_gpu_parity.py::test_physics_substep_parity (tests/parity_inputs.py) pushed
+                  through stepSimulation: state after 1 and after 8 sub-steps + contact impulses
+                  -> tests/golden/pybullet_substep_<robot>.npz (tests/test_pybullet_fixture.py compares the oracle with it
+                  and skips while the fixture is absent);
+  --time          env steps/s of the reference's call pattern (N robots in one world, 33 x {readback, PD torque, torque
+                  application} + one stepSimulation per sub-step, reward / termination reads per env step) at N = 1 and 16,
+                  printed as JSON rows for bench.py's cpu_baseline (kind "reference").
+
+Without pybullet it prints {"pybullet": "unavailable"} and exits 0, so bench.py can always probe it.
+"""
+import argparse
+import importlib.util
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+URDF = {"laikago": "laikago/laikago_toes_limits.urdf", "mini_cheetah": "mini_cheetah/mini_cheetah.urdf"}
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def available():
+    return importlib.util.find_spec("pybullet") is not None and importlib.util.find_spec("pybullet_data") is not None
+
+
+class World(object):
+    """One DIRECT world set up like LocomotionGymEnv._init (quadruped_gym_env.py:186-205) with n robots (minitaur.py:891-903)."""
+
+    def __init__(self, robot, n=1):
+        import pybullet as p
+        import pybullet_data
+        from openroborl_amd import robots as rb
+        self.p = p
+        self.model = rb.ROBOTS[robot]()
+        self.cid = p.connect(p.DIRECT)
+        p.setAdditionalSearchPath(pybullet_data.getDataPath())
+        p.resetSimulation()
+        p.setPhysicsEngineParameter(numSolverIterations=int(300 / 33))           # quadruped_gym_env.py:177-178,193-195
+        p.setTimeStep(0.001)
+        p.setGravity(0, 0, -10)                                                   # :200
+        self.plane = p.loadURDF("plane_implicit.urdf")                            # :204
+        self.robots = []
+        for i in range(n):
+            pos = [self.model["init_pos"][0] - 2 * (i // 4), self.model["init_pos"][1] + 2 * (i % 4), self.model["init_pos"][2]]
+            self.robots.append(p.loadURDF(URDF[robot], pos, list(self.model["init_quat"])))
+        p.setPhysicsEngineParameter(enableConeFriction=0)                          # :87
+        b = self.robots[0]
+        self.num_joints = p.getNumJoints(b)
+        self.info = [p.getJointInfo(b, j) for j in range(self.num_joints)]
+        self.revolute = [j for j in range(self.num_joints) if self.info[j][2] == p.JOINT_REVOLUTE]
+        assert len(self.revolute) == 12, "expected 12 actuated joints, got %d" % len(self.revolute)
+        # URDF joint id of motor m: the model table's joint_of_motor indexes the 12 revolute joints in URDF order
+        self.motor_ids = [self.revolute[j] for j in self.model["joint_of_motor"]]
+        self.knees = [self.revolute[3 * leg + 2] for leg in range(4)]
+        fixed = [j for j in range(self.num_joints) if j not in self.revolute]
+        self.toes = fixed[-4:] if len(fixed) >= 4 else []
+        for b in self.robots:
+            p.changeDynamics(b, -1, linearDamping=0, angularDamping=0)            # intent of minitaur.py:853-858
+            for j in range(self.num_joints):                                       # reset_pose: default velocity motors off (:472-479)
+                p.setJointMotorControl2(b, j, p.VELOCITY_CONTROL, targetVelocity=0, force=0)
+
+    def close(self):
+        self.p.disconnect(self.cid)
+
+    def set_state(self, b, s37):
+        p = self.p
+        p.resetBasePositionAndOrientation(b, list(s37[0:3]), list(s37[3:7]))
+        p.resetBaseVelocity(b, list(s37[7:10]), list(s37[10:13]))
+        for k, j in enumerate(self.revolute):
+            p.resetJointState(b, j, float(s37[13 + k]), targetVelocity=float(s37[25 + k]))
+
+    def get_state(self, b):
+        p = self.p
+        pos, orn = p.getBasePositionAndOrientation(b)
+        lin, ang = p.getBaseVelocity(b)
+        js = p.getJointStates(b, self.revolute)
+        return np.concatenate([pos, orn, lin, ang, [x[0] for x in js], [x[1] for x in js]])
+
+    def apply_motor_torques(self, b, tau_motor):
+        """tau_urdf = tau_motor * JOINT_DIRECTIONS on the motor's joint (minitaur.py:755-769,912-917)."""
+        p = self.p
+        p.setJointMotorControlArray(b, self.motor_ids, p.TORQUE_CONTROL, forces=list(np.asarray(tau_motor) * self.model["motor_dir"]))
+
+
+def dump_urdf(robot):
+    w = World(robot)
+    p = w.p
+    b = w.robots[0]
+    links = []
+    for link in range(-1, w.num_joints):
+        d = p.getDynamicsInfo(b, link)
+        rec = {"link": link, "mass": d[0], "lateral_friction": d[1], "inertia_diag": list(d[2]), "inertial_pos": list(d[3]),
+               "inertial_orn": list(d[4])}
+        if link >= 0:
+            ji = w.info[link]
+            rec.update(joint_name=ji[1].decode(), joint_type=ji[2], lower=ji[8], upper=ji[9], link_name=ji[12].decode(),
+                       axis=list(ji[13]), parent_frame_pos=list(ji[14]), parent_frame_orn=list(ji[15]), parent=ji[16])
+        links.append(rec)
+    w.close()
+    path = os.path.join(GOLD, "pybullet_urdf_%s.json" % robot)
+    with open(path, "w") as f:
+        json.dump({"urdf": URDF[robot], "links": links}, f, indent=1)
+    # the same data in the shape of openroborl_amd/robots.py (_build arguments that are hand-authored today)
+    print("# %s: values to replace the hand-authored entries of openroborl_amd/robots.py" % robot)
+    print("base_mass=%.6g, base_inertia=%s" % (links[0]["mass"], [round(x, 9) for x in links[0]["inertia_diag"]]))
+    for rec in links[1:5]:
+        print("%-34s m=%.6g I=%s com=%s joint_at=%s axis=%s limits=(%.6g, %.6g)" % (
+            rec["joint_name"], rec["mass"], [round(x, 9) for x in rec["inertia_diag"]], [round(x, 6) for x in rec["inertial_pos"]],
+            [round(x, 6) for x in rec["parent_frame_pos"]], rec["axis"], rec["lower"], rec["upper"]))
+    print("written", path)
+
+
+def dump_substeps(robot):
+    from tests.parity_inputs import substep_parity_inputs
+    from tests import oracle_lib as ol
+    cfg, models, clips, st, tau = substep_parity_inputs(robot)
+    lay = ol.layout()
+    n = st.shape[0]
+    w = World(robot)
+    p = w.p
+    b = w.robots[0]
+    out1, out8 = np.zeros((n, 37)), np.zeros((n, 37))
+    imp1 = np.zeros((n, 4, 3))            # per leg (URDF order): normal, lateral 1, lateral 2 impulses of the toe contact, sub-step 1
+    nonfoot = np.zeros(n, dtype=np.uint8)
+    feet = set(w.toes) | set(w.knees)     # foot links = toes + lower legs (minitaur.py:842-844)
+    for i in range(n):
+        w.set_state(b, st[i, 0:37])
+        mu = float(st[i, lay.sl("FOOT_MU")][0])
+        for link in feet:
+            p.changeDynamics(b, link, lateralFriction=mu)                           # minitaur.py:1029-1038
+        for leg, j in enumerate(w.knees):                                           # set_joint_friction (:1063-1070)
+            p.setJointMotorControl2(b, j, p.VELOCITY_CONTROL, targetVelocity=0, force=float(st[i, lay.sl("KNEE_FRICTION")][leg]))
+        for k in range(8):
+            w.apply_motor_torques(b, tau[i])
+            p.stepSimulation()
+            if k == 0:
+                out1[i] = w.get_state(b)
+                for c in p.getContactPoints(bodyA=b, bodyB=w.plane):
+                    if c[3] in w.toes:
+                        leg = w.toes.index(c[3])
+                        imp1[i, leg] += np.array([c[9], c[10], c[12]]) * 0.001      # forces -> impulses over dt
+                    elif c[3] not in feet:
+                        nonfoot[i] = 1
+        out8[i] = w.get_state(b)
+    w.close()
+    path = os.path.join(GOLD, "pybullet_substep_%s.npz" % robot)
+    np.savez_compressed(path, state_in=st[:, 0:37], tau=tau, state_1=out1, state_8=out8, impulses_1=imp1, nonfoot_contact_1=nonfoot,
+                        knee_friction=st[:, lay.sl("KNEE_FRICTION")], foot_mu=st[:, lay.sl("FOOT_MU")])
+    print("written", path)
+
+
+def time_path(robot, n, seconds=8.0):
+    """The reference's call pattern per env step: for each of 33 sub-steps, per robot: readback (getJointStates,
+    getBasePositionAndOrientation, getBaseVelocity), PD torque, setJointMotorControlArray; one stepSimulation for the world;
+    per env step and robot the reward / termination reads (32 getJointStateMultiDof, 16 getLinkState, getContactPoints)."""
+    w = World(robot, n)
+    p = w.p
+    m = w.model
+    kp, kd, init = np.array(m["kp"]), np.array(m["kd"]), np.array(m["init_motor_angles"])
+    for b in w.robots:
+        for k, j in enumerate(w.motor_ids):
+            p.resetJointState(b, j, float(init[k] + m["motor_offset"][k]), targetVelocity=0.0)
+    rng = np.random.RandomState(0)
+    steps = 0
+    t0 = time.time()
+    while time.time() - t0 < seconds:
+        target = init + rng.randn(n, 12) * 0.05
+        for sub in range(33):
+            for i, b in enumerate(w.robots):
+                js = p.getJointStates(b, w.motor_ids)
+                p.getBasePositionAndOrientation(b)
+                p.getBaseVelocity(b)
+                q = (np.array([x[0] for x in js]) - m["motor_offset"]) * m["motor_dir"]
+                qd = np.array([x[1] for x in js]) * m["motor_dir"]
+                w.apply_motor_torques(b, -kp * (q - target[i]) - kd * qd)
+            p.stepSimulation()
+        for b in w.robots:
+            for j in range(w.num_joints):
+                p.getJointStateMultiDof(b, j)
+                p.getJointStateMultiDof(b, j)
+            for j in sorted(set(w.toes) | set(w.knees)):
+                p.getLinkState(b, j)
+                p.getLinkState(b, j)
+            p.getContactPoints(bodyA=b, bodyB=w.plane)
+        steps += 1
+    dt = time.time() - t0
+    w.close()
+    return {"value": n * steps / dt, "unit": "env steps/s", "cores": 1, "robots": n, "kind": "reference",
+            "build": "pybullet %s" % getattr(p, "__version__", "?"),
+            "sample": "%d robots x %d env steps of the reference's call pattern through real PyBullet (tools/pybullet_ref.py)" % (n, steps)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dump-urdf", action="store_true")
+    ap.add_argument("--dump-substeps", action="store_true")
+    ap.add_argument("--time", action="store_true")
+    ap.add_argument("--robot", default="both", choices=["laikago", "mini_cheetah", "both"])
+    args = ap.parse_args()
+    if not available():
+        print(json.dumps({"pybullet": "unavailable"}))
+        return 0
+    robots = ["laikago", "mini_cheetah"] if args.robot == "both" else [args.robot]
+    for r in robots:
+        if args.dump_urdf:
+            dump_urdf(r)
+        if args.dump_substeps:
+            dump_substeps(r)
+    if args.time:
+        print(json.dumps({"pybullet": "available", "rows": [time_path(robots[0], n) for n in (1, 16)]}))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
