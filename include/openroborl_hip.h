@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ORR_ABI_VERSION 1
+#define ORR_ABI_VERSION 2
 
 #define ORR_NUM_MOTORS 12 /* laikago.py:29, mini_cheetah.py:29 */
 #define ORR_NUM_LEGS 4
@@ -169,6 +169,9 @@ typedef struct orr_model {
   float toe_pos[4][3];                  /* toe sphere centre in the lower-leg link frame (= toe link COM) */
   float lower_com[4][3];                /* lower leg's own COM (end-effector reward, imitation_task.py:441-446) */
   float toe_radius;
+  float shank_pos[4][3];                /* second contact sphere of the lower leg ("shank"; lower legs are feet: minitaur.py:842-844), */
+  float shank_radius;                   /* in the lower-leg link frame; radius 0 = none.  A leg touches the ground with whichever of its
+                                           two spheres (toe, shank) is lower: one contact point per leg and sub-step */
   float foot_friction;                  /* default lateral friction of toe / lower leg */
   int32_t num_fall_proxies;             /* termination-only collision spheres on non-foot links */
   int32_t fall_body[ORR_MAX_FALL_PROXIES];

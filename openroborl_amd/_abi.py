@@ -1,7 +1,7 @@
 """ctypes mirror of include/openroborl_hip.h (struct layouts and constants only)."""
 import ctypes as C
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 NUM_MOTORS = 12
 POSE_DIM = 19
 VEL_DIM = 18
@@ -88,6 +88,8 @@ class OrrModel(C.Structure):
         ("toe_pos", (C.c_float * 3) * 4),
         ("lower_com", (C.c_float * 3) * 4),
         ("toe_radius", C.c_float),
+        ("shank_pos", (C.c_float * 3) * 4),
+        ("shank_radius", C.c_float),
         ("foot_friction", C.c_float),
         ("num_fall_proxies", C.c_int32),
         ("fall_body", C.c_int32 * MAX_FALL_PROXIES),

@@ -81,9 +81,10 @@ struct ModelHot {
   float joint_pos[12][3];
   float joint_lo[12], joint_hi[12];  // limits of the internal angle
   float toe_pos[4][3];
+  float shank_pos[4][3];      // second contact sphere of the lower leg (see orr_model)
   float lower_com[4][3];
   float default_joints[12];   // (INIT_MOTOR_ANGLES + OFFSET) * DIR, motor order (imitation_task.py:1245-1252)
-  float toe_radius, foot_friction;
+  float toe_radius, shank_radius, foot_friction;
   int num_fall;
   int fall_body[ORR_MAX_FALL_PROXIES];
   float fall_pos[ORR_MAX_FALL_PROXIES][3];

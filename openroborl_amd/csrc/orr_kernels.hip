@@ -424,8 +424,10 @@ int32_t orr_set_model(orr_handle* h, int32_t robot_type, const orr_model* m) {
       return fail(-1, "orr_set_model: joint range must be at least 2 * limit_activation");
   }
   for (int l = 0; l < 4; l++)
-    for (int k = 0; k < 3; k++) { H.toe_pos[l][k] = m->toe_pos[l][k]; H.lower_com[l][k] = m->lower_com[l][k]; }
+    for (int k = 0; k < 3; k++) { H.toe_pos[l][k] = m->toe_pos[l][k]; H.lower_com[l][k] = m->lower_com[l][k]; H.shank_pos[l][k] = m->shank_pos[l][k]; }
+  if (!(m->shank_radius >= 0.0f)) return fail(-1, "orr_set_model: shank_radius must be >= 0");
   H.toe_radius = m->toe_radius;
+  H.shank_radius = m->shank_radius;
   H.foot_friction = m->foot_friction;
   H.num_fall = m->num_fall_proxies;
   for (int i = 0; i < ORR_MAX_FALL_PROXIES; i++) {

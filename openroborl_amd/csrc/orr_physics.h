@@ -419,12 +419,16 @@ __device__ __forceinline__ void row_setup(const Shared& S, const orr_config& cfg
     else { R.leg = (slot - 20) >> 1; d = 1 + ((slot - 20) & 1); }
     const int leg = R.leg;
     const LinkCache& Lb = S.ph.sub.dyn.lc[3 * leg + 2];
-    float cw[3];
+    // lower legs are feet (minitaur.py:842-844): the leg touches the ground with its toe sphere or its shank sphere, whichever is
+    // lower (one contact point per leg and sub-step; shank_radius 0 = toe only)
+    float cw[3], cs[3];
     mv3(Lb.Rw, S.m.toe_pos[leg], cw);
-    cw[0] += Lb.ow[0]; cw[1] += Lb.ow[1]; cw[2] += Lb.ow[2];
-    const float dist = cw[2] - S.m.toe_radius;
+    mv3(Lb.Rw, S.m.shank_pos[leg], cs);
+    const float dist_t = cw[2] + Lb.ow[2] - S.m.toe_radius, dist_s = cs[2] + Lb.ow[2] - S.m.shank_radius;
+    const bool shank = S.m.shank_radius > 0.0f && dist_s < dist_t;
+    const float dist = shank ? dist_s : dist_t;
     R.active = dist < cfg.contact_margin;
-    const float Pw[3] = {cw[0], cw[1], cw[2] - S.m.toe_radius};
+    const float Pw[3] = {(shank ? cs[0] : cw[0]) + Lb.ow[0], (shank ? cs[1] : cw[1]) + Lb.ow[1], dist};
     const float dir[3] = {d == 1 ? 1.0f : 0.0f, d == 2 ? 1.0f : 0.0f, d == 0 ? 1.0f : 0.0f};
     float rr[3] = {Pw[0] - S.s[O(POS)], Pw[1] - S.s[O(POS) + 1], Pw[2] - S.s[O(POS) + 2]};
     cross3(rr, dir, &R.Jb[0]);

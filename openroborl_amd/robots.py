@@ -48,7 +48,7 @@ def _pa(m, d):
 def _build(name, init_pos, init_quat, init_motor_angles, motor_dir, motor_offset, joint_of_motor, kp, kd,
            base_mass, base_inertia, hip_xy, hip_z, coxa, femur, tibia, pitch_axis,
            hip_m, hip_com, hip_I, up_m, up_com, up_I, lo_m, lo_com, lo_I, toe_m, toe_r,
-           limits, chassis_half, hip_r, knee_r, foot_friction):
+           limits, chassis_half, hip_r, knee_r, foot_friction, shank_r=0.0, shank_at=0.0):
     m = {
         "name": name,
         "init_pos": np.array(init_pos, dtype=np.float64),
@@ -62,6 +62,7 @@ def _build(name, init_pos, init_quat, init_motor_angles, motor_dir, motor_offset
         "base_mass": float(base_mass),
         "base_inertia": np.array(list(base_inertia) + [0.0, 0.0, 0.0]),
         "toe_radius": float(toe_r),
+        "shank_radius": float(shank_r),
         "foot_friction": float(foot_friction),
     }
     link_mass = np.zeros(12)
@@ -74,6 +75,7 @@ def _build(name, init_pos, init_quat, init_motor_angles, motor_dir, motor_offset
     jlo = np.zeros(12)
     jhi = np.zeros(12)
     toe_pos = np.zeros((4, 3))
+    shank_pos = np.zeros((4, 3))
     lower_com = np.zeros((4, 3))
     fall_body, fall_pos, fall_radius = [], [], []
     for sx in (1, -1):
@@ -112,6 +114,7 @@ def _build(name, init_pos, init_quat, init_motor_angles, motor_dir, motor_offset
         link_Ipa[j0 + 2] = _pa(lo_m, c_l - c) + _pa(toe_m, c_t - c)
         link_group[j0 + 2] = 1
         toe_pos[leg] = c_t
+        shank_pos[leg] = [0.0, 0.0, -shank_at]     # on the shank axis, `shank_at` below the knee
         lower_com[leg] = c_l
         for k in range(3):
             jlo[j0 + k], jhi[j0 + k] = limits[k]
@@ -124,7 +127,7 @@ def _build(name, init_pos, init_quat, init_motor_angles, motor_dir, motor_offset
         fall_radius.append(knee_r)
     m.update(link_mass=link_mass, link_com=link_com, link_inertia=link_I, link_inertia_pa=link_Ipa,
              link_group=link_group, joint_pos=jpos, joint_axis=jaxis, joint_lo=jlo, joint_hi=jhi,
-             toe_pos=toe_pos, lower_com=lower_com, num_fall_proxies=len(fall_body),
+             toe_pos=toe_pos, shank_pos=shank_pos, lower_com=lower_com, num_fall_proxies=len(fall_body),
              fall_body=np.array(fall_body, dtype=np.int32), fall_pos=np.array(fall_pos),
              fall_radius=np.array(fall_radius))
     assert m["num_fall_proxies"] <= _abi.MAX_FALL_PROXIES
@@ -155,7 +158,9 @@ def laikago():
         toe_m=0.06, toe_r=0.0265,
         # Unitree Laikago spec in motor convention: hip +-60 deg, thigh -30..225 deg, calf -159..-35 deg
         limits=[(-1.0471975512, 1.0471975512), (-0.5235987756, 3.9269908170), (-2.7750735107, -0.6108652382)],
-        chassis_half=[0.27, 0.09, 0.055], hip_r=0.045, knee_r=0.035, foot_friction=1.0)
+        # lower legs are feet too (minitaur.py:842-844): a second contact sphere at the upper end of the shank (hand-authored, as the
+        # URDF's collision shapes are unavailable); the thigh's knee proxy (knee_r, termination only) is the larger of the two
+        chassis_half=[0.27, 0.09, 0.055], hip_r=0.045, knee_r=0.035, foot_friction=1.0, shank_r=0.02, shank_at=0.03)
 
 
 def mini_cheetah():
@@ -181,7 +186,7 @@ def mini_cheetah():
         limits=[(-1e9, 1e9)] * 3,                                            # continuous joints
         # knee proxy radius 0: with a finite knee sphere the shipped minicheetah_trot policy is stopped by knee
         # "contacts" within ~10 steps while still upright; the thigh/shank of this robot are thin plates
-        chassis_half=[0.19, 0.049, 0.05], hip_r=0.04, knee_r=0.0, foot_friction=1.0)
+        chassis_half=[0.19, 0.049, 0.05], hip_r=0.04, knee_r=0.0, foot_friction=1.0, shank_r=0.012, shank_at=0.02)
 
 
 ROBOTS = {"laikago": laikago, "mini_cheetah": mini_cheetah}

@@ -34,3 +34,48 @@ def substep_parity_inputs(robot, n=64, seed=3):
     st = statemod.to_float64(lay, statemod.from_float64(lay, st))   # float32-representable on both sides
     tau = rng.uniform(-15, 15, (n, 12)).astype(np.float32).astype(np.float64)
     return cfg, models, clips, st, tau
+
+
+def shank_contact_inputs(robot, n=32, seed=3):
+    """Robots resting on their SHANKS: thighs forward, lower legs folded back so far that the knee end of every shank is
+    lower than the toe (|upper + lower angle| > 90 deg), the base height chosen so that the lowest shank sphere penetrates
+    the plane by 0-4 mm.  Lower legs are feet (minitaur.py:842-844): this contact must carry the robot, not end the episode
+    by itself.  -> (cfg, models, clips, state64, tau)"""
+    from tests import phys_ref as pr
+    cfg, models, clips, st, tau = substep_parity_inputs(robot, n, seed)
+    t = robots.ROBOT_TYPE_ID[robot]
+    m = models[t]
+    lay = ol.layout()
+    rng = np.random.RandomState(5)
+    dirj, offj, moj = pr.joint_maps(m)
+    sgn = 1.0 if robot == "laikago" else -1.0              # the mini-cheetah's knees bend the other way
+    for i in range(n):
+        akin = np.tile([0.0, sgn * 0.3, -sgn * 2.4], 4) + rng.uniform(-0.05, 0.05, 12)
+        q = akin * dirj + offj
+        yaw = rng.uniform(-3, 3)
+        quat = _qmul_z(yaw, m["init_quat"])
+        bodies, _ = pr.kinematics(m, np.zeros(3), quat, q)
+        low_s, low_t = 1e9, 1e9
+        for leg in range(4):
+            b = bodies[1 + 3 * leg + 2]
+            low_s = min(low_s, (b["o"] + b["R"] @ m["shank_pos"][leg])[2] - m["shank_radius"])
+            low_t = min(low_t, (b["o"] + b["R"] @ m["toe_pos"][leg])[2] - m["toe_radius"])
+        assert low_s < low_t - 0.02, (low_s, low_t)           # the shank is the contact, by a clear margin
+        st[i, lay.sl("POS")] = [rng.uniform(-1, 1), rng.uniform(-1, 1), -low_s - rng.uniform(0.0, 0.004)]
+        st[i, lay.sl("QUAT")] = quat
+        st[i, lay.sl("Q")] = q
+        st[i, lay.sl("QD")] = rng.randn(12) * 0.3
+        st[i, lay.sl("LINVEL")] = rng.randn(3) * 0.1
+        st[i, lay.sl("ANGVEL")] = rng.randn(3) * 0.2
+    st[:, lay.sl("LAMBDA")] = 0.0
+    st = statemod.to_float64(lay, statemod.from_float64(lay, st))
+    tau = (rng.uniform(-3, 3, (n, 12))).astype(np.float32).astype(np.float64)
+    return cfg, models, clips, st, tau
+
+
+def _qmul_z(yaw, q):
+    a = np.array([0.0, 0.0, np.sin(yaw / 2), np.cos(yaw / 2)])
+    x1, y1, z1, w1 = a
+    x0, y0, z0, w0 = np.asarray(q, dtype=np.float64)
+    return np.array([x1 * w0 + y1 * z0 - z1 * y0 + w1 * x0, -x1 * z0 + y1 * w0 + z1 * x0 + w1 * y0,
+                     x1 * y0 - y1 * x0 + z1 * w0 + w1 * z0, -x1 * x0 - y1 * y0 - z1 * z0 + w1 * w0])

@@ -427,3 +427,60 @@ def test_motion_over_on_a_non_looping_clip(tmp_path):
         seen |= rg != 0
     assert seen.all()
     env.close(); orc.close()
+
+
+@pytest.mark.parametrize("robot", ["laikago", "mini_cheetah"])
+def test_shank_contact_parity(robot):
+    """Row C with robots laid on their shanks (lower legs are feet, minitaur.py:842-844): the per-leg contact is the shank
+    sphere, not the toe; HIP vs oracle like test_physics_substep_parity."""
+    import torch
+    from tests.parity_inputs import shank_contact_inputs
+    n = 32
+    env, orc = make_pair(robot, n=n)
+    env.reset(); orc.reset()
+    _, _, _, st, tau = shank_contact_inputs(robot, n)
+    push_state(env, st); orc.state[:] = st
+    tg = torch.tensor(tau, dtype=torch.float32, device=env.device)
+    for nsub, ptol, vtol in ((1, 2e-6, 2e-4), (8, 1e-4, 2e-3)):
+        env.debug_physics(tg, nsub)
+        for i in range(n):
+            for _ in range(nsub):
+                orc.L.orc_physics_substep(orc.h, ol.P(orc.state[i]), ol.P(np.ascontiguousarray(tau[i])))
+        compare_fields(env, orc, ["POS", "QUAT", "Q"], atol=ptol, rtol=ptol, what="shank nsub=%d" % nsub)
+        compare_fields(env, orc, ["LINVEL", "ANGVEL", "QD"], atol=vtol, rtol=vtol, what="shank nsub=%d" % nsub)
+        compare_fields(env, orc, ["LAMBDA"], atol=5e-4 if nsub == 1 else 5e-3, what="shank nsub=%d" % nsub)
+        if nsub == 1:   # the robots start with a penetrating shank sphere: its contact is live in (nearly) every robot
+            lam = orc.field("LAMBDA").reshape(n, 4, 3)
+            assert (lam[:, :, 0].sum(axis=1) > 0).mean() > 0.9
+    env.close(); orc.close()
+
+
+def test_shipped_minicheetah_policy_probe():
+    """Behavioural anchor for config 3's robot, with its honest threshold: the reference's minicheetah_trot policy (trained in
+    PyBullet on the real URDF) does NOT finish the 600-step episode on this hand-authored mini-cheetah model -- it stays on
+    the clip for a while and then falls.  The test pins the measured level so that model changes show."""
+    import torch
+    W = np.load(os.path.join(ol.GOLDEN, "policy_minicheetah_trot.npz"))
+    n = 256
+    env, orc = make_pair("mini_cheetah", n=n, seed=1)
+    orc.close()
+    dev = env.device
+    w = {k: torch.tensor(W[k], device=dev) for k in W.files}
+    obs = env.reset()
+    alive = torch.ones(n, dtype=torch.bool, device=dev)
+    length = torch.zeros(n, device=dev)
+    ret = torch.zeros(n, device=dev)
+    for step in range(600):
+        h = torch.relu(obs @ w["model__pi_fc0__w_0"] + w["model__pi_fc0__b_0"])
+        h = torch.relu(h @ w["model__pi_fc1__w_0"] + w["model__pi_fc1__b_0"])
+        a = torch.clamp(h @ w["model__pi__w_0"] + w["model__pi__b_0"], -2 * np.pi, 2 * np.pi)
+        obs, rew, done, _ = env.step(a.contiguous())
+        ret += rew * alive
+        length += alive.float()
+        alive &= ~done.bool()
+    mean_len = length.mean().item()
+    rps = (ret / length).mean().item()
+    print("MINICHEETAH_PROBE mean_survival_steps=%.1f reward_per_step=%.3f finished=%.3f" % (mean_len, rps, alive.float().mean().item()))
+    assert 100.0 < mean_len < 450.0        # measured 158 (no robot finishes); far from the 600 the Laikago policy reaches
+    assert rps > 0.4                       # while it is up it tracks the clip
+    env.close()

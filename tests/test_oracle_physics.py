@@ -173,3 +173,30 @@ def test_friction_pyramid_bounds_tangential_impulse():
         assert np.all(np.abs(lam[:, 2]) <= 0.5 * lam[:, 0] + 1e-9)
     assert s[lay.sl("LINVEL")][1] < v0 - 0.05
     env.close()
+
+
+@pytest.mark.parametrize("robot", ["laikago", "mini_cheetah"])
+def test_shank_contact_carries_the_robot(robot):
+    """Lower legs are feet (minitaur.py:842-844): a robot resting on the knee ends of its shanks is held up by contact forces
+    there (normal impulses on the legs, no free fall through the plane) while its toes are in the air."""
+    from tests.parity_inputs import shank_contact_inputs
+    cfg, models, clips, st, tau = shank_contact_inputs(robot, n=8)
+    t = robots.ROBOT_TYPE_ID[robot]
+    env = ol.OracleEnv(cfg, models, clips, 8, robot_type=t)
+    env.state[:] = st
+    lay = env.lay
+    z0 = st[:, lay.sl("POS")][:, 2].copy()
+    zero = np.zeros(12)
+    imp = np.zeros(8)
+    for _ in range(60):
+        for i in range(8):
+            env.L.orc_physics_substep(env.h, P(env.state[i]), P(zero))
+        imp += env.state[:, lay.sl("LAMBDA")].reshape(8, 4, 3)[:, :, 0].sum(axis=1)
+    s = env.state
+    bodies, _ = pr.kinematics(models[t], s[0, lay.sl("POS")], s[0, lay.sl("QUAT")], s[0, lay.sl("Q")])
+    weight_impulse = sum(b["m"] for b in bodies) * 10.0 * 1e-3 * 60
+    assert (imp > 0.35 * weight_impulse).all(), imp / weight_impulse   # limp legs: the robot sags while the shank contacts take 0.5-0.9 of the weight
+    # 60 ms of free fall would be 18 mm and 0.6 m/s; the shank contact holds the robot (legs are limp, so it may sag a little)
+    assert (z0 - s[:, lay.sl("POS")][:, 2] < 0.012).all(), z0 - s[:, lay.sl("POS")][:, 2]
+    assert (np.abs(s[:, lay.sl("LINVEL")][:, 2]) < 0.35).all()
+    env.close()
