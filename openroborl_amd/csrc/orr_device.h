@@ -333,13 +333,49 @@ __device__ __forceinline__ float bcast_lane(float x, int sub) {
     return __int_as_float(sub ? b : a);
   }
 #ifndef ORR_READLANE_BCAST
-  return __int_as_float(__builtin_amdgcn_update_dpp(v, v, 0x150 + R, 0xF, 0xF, false));
+  // old = 0 with bound_ctrl (every source lane of a row_newbcast is valid, so neither matters): the form the compiler's DPP
+  // combiner folds into the consuming VOP2 (v_mul_f32_dpp / v_fmac_f32_dpp / v_max_f32_dpp ...) instead of a separate v_mov_b32_dpp
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, v, 0x150 + R, 0xF, 0xF, true));
 #else
   const int a0 = __builtin_amdgcn_readlane(v, R), a1 = __builtin_amdgcn_readlane(v, R + 16);
   const int a2 = __builtin_amdgcn_readlane(v, R + 32), a3 = __builtin_amdgcn_readlane(v, R + 48);
   const int lo = (sub & 1) ? a1 : a0, hi = (sub & 1) ? a3 : a2;
   return __int_as_float((sub & 2) ? hi : lo);
 #endif
+}
+// sum_k x_k(lane R of this robot) * w_k(own lane), k < 9: the broadcast rides as the DPP operand of the multiply-adds
+// (v_fmac_f32_dpp ... row_newbcast:R; the compiler's DPP combiner only folds v_mov_b32_dpp into v_mul, not into v_fmac).
+// Two accumulators halve the dependent chain.  The leading s_nop covers the "VALU write -> DPP read" hazard (2 wait states)
+// for whatever the compiler placed in front of the block: it does not look inside inline assembly.
+template <int R>
+__device__ __forceinline__ float dpp_dot9(float x0, float x1, float x2, float x3, float x4, float x5, float x6, float x7, float x8,
+                                          float w0, float w1, float w2, float w3, float w4, float w5, float w6, float w7, float w8) {
+  static_assert(kRPW == 4, "row_newbcast needs 16 lanes per robot");
+  float a, t;
+  asm("s_nop 1\n\t"
+      "v_mul_f32_dpp %0, %2, %11 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mul_f32_dpp %1, %3, %12 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %0, %4, %13 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %1, %5, %14 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %0, %6, %15 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %1, %7, %16 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %0, %8, %17 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %1, %9, %18 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %0, %10, %19 row_newbcast:%20 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32 %0, %0, %1"
+      : "=&v"(a), "=&v"(t)
+      : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(x4), "v"(x5), "v"(x6), "v"(x7), "v"(x8),
+        "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(w4), "v"(w5), "v"(w6), "v"(w7), "v"(w8), "n"(R));
+  return a;
+}
+// max(x in lane R of this robot, 0) in one instruction (v_max_f32_dpp): the clamp of a unilateral row (contact normal, joint
+// limit: bounds [0, inf)) fused with its broadcast.  x has usually just been written, hence the s_nop (DPP read hazard).
+template <int R>
+__device__ __forceinline__ float dpp_bcast_max0(float x, float zero) {
+  static_assert(kRPW == 4, "row_newbcast needs 16 lanes per robot");
+  float o;
+  asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(x), "v"(zero), "n"(R));
+  return o;
 }
 // same with r a loop counter of an unrolled loop (the switch folds to one case)
 __device__ __forceinline__ float bcast_row(float x, int r, int sub) {

@@ -375,6 +375,7 @@ struct Row {
   float Jb[6], jl[3];          // Jacobian: base part (world angular, linear) and the 3 joints of `leg`
   float rhs, jdi, lam, w, lam_n;
   float lo_c, hi_c, mu_e;      // bounds = constant part -/+ mu_e * lambda_normal
+  float wa[6], wq[12];         // own impulse response M^-1 J^T (base part, joint part): kept in registers for the Delassus columns
 };
 
 __device__ __forceinline__ float row_dot(const Row& R, const float* Wr) {
@@ -502,6 +503,10 @@ __device__ __forceinline__ void row_response(Shared& S, const orr_config& cfg, R
 #pragma unroll
     for (int i = 0; i < 12; i++) S.ph.sub.W[slot][6 + i] = mq[i];
   }
+#pragma unroll
+  for (int i = 0; i < 6; i++) R.wa[i] = a0[i];
+#pragma unroll
+  for (int i = 0; i < 12; i++) R.wq[i] = mq[i];
   R.jdi = R.active ? __builtin_amdgcn_rcpf(diag) : 0.0f;
   R.rhs *= R.jdi;
   R.lam = (R.active && R.warm >= 0) ? cfg.warmstart_factor * S.s[O(LAMBDA) + R.warm] : 0.0f;
@@ -520,7 +525,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 // and EVERY lane keeps the impulses of all rows (lam[r], equal in all lanes of the robot).  One row update is
 //   y' = y - Ac[r] lam[r];   lam[r] = broadcast_from_lane_of_r(clamp(y, lo, hi));   y = y' + Ac[r] lam[r]
 // with Ac[r] = -A[row][r] / diag(row) off the diagonal and 0 on it (y of the updated row does not move): four vector
-// instructions (fma, v_med3, v_mov_dpp row_newbcast, fma), three of them on the dependent chain.
+// instructions (fma, v_med3, v_mov_dpp row_newbcast, fma), three of them on the dependent chain; for the unilateral rows
+// (contact normals, joint limits: bounds [0, inf)) clamp and broadcast are ONE instruction (v_max_f32_dpp), two on the chain.
 // HAS_B: some robot of the wave has an active joint-limit row (bank B is swept too).
 // Knee and contact rows are swept unconditionally (a row visited for a robot where it is inactive is a no-op: its
 // bounds, 1/diag, lambda and Delassus column are zero); measured 9 % faster than one scalar branch per leg, which also
@@ -529,7 +535,8 @@ template <bool HAS_B>
 __device__ __forceinline__ void pgs_sweeps(int iters, unsigned int mask, int lane, int sub, Row& A, Row& B,
                                            const float (&AcA)[kMaxRows], const float (&AcB)[kMaxRows], float (&lam)[kMaxRows]) {
   float yA = A.lam + fmaf(-A.w, A.jdi, A.rhs), yB = B.lam + fmaf(-B.w, B.jdi, B.rhs);
-  const float hiB = B.hi_c, loB = B.lo_c;
+  float zero;
+  asm("v_mov_b32 %0, 0" : "=v"(zero));   // a VGPR operand for the DPP max (opaque, so that it stays in a register)
   float mun[4];  // friction rows: d(bound) / d(normal impulse of their toe)
 #pragma unroll
   for (int g = 0; g < 4; g++) mun[g] = A.nrm_slot == 16 + g ? A.mu_e : 0.0f;
@@ -539,7 +546,9 @@ __device__ __forceinline__ void pgs_sweeps(int iters, unsigned int mask, int lan
       constexpr int r = decltype(rc)::value, src = r < 4 ? r : r - 12;
       const float old = lam[r];
       const float yp = fmaf(-AcA[r], old, yA);
-      const float sb = bcast_lane<src>(__builtin_amdgcn_fmed3f(yA, loE, hiE), sub);
+      float sb;
+      if constexpr (r >= 16 && r < 20) sb = dpp_bcast_max0<src>(yA, zero);   // normal row: [0, inf); an inactive one has y == 0
+      else sb = bcast_lane<src>(__builtin_amdgcn_fmed3f(yA, loE, hiE), sub);
       yA = fmaf(AcA[r], sb, yp);
       lam[r] = sb;
       if (HAS_B) yB = fmaf(AcB[r], sb - old, yB);
@@ -556,7 +565,7 @@ __device__ __forceinline__ void pgs_sweeps(int iters, unsigned int mask, int lan
         if ((mask >> r) & 1u) {
           const float old = lam[r];
           const float yp = fmaf(-AcB[r], old, yB);
-          const float sb = bcast_lane<r>(__builtin_amdgcn_fmed3f(yB, loB, hiB), sub);
+          const float sb = dpp_bcast_max0<r>(yB, zero);                      // joint limit: [0, inf)
           yB = fmaf(AcB[r], sb, yp);
           lam[r] = sb;
           yA = fmaf(AcA[r], sb - old, yA);
@@ -567,9 +576,13 @@ __device__ __forceinline__ void pgs_sweeps(int iters, unsigned int mask, int lan
   }
 }
 
-// Delassus columns A[row][r] = J . W[r], kept in registers already scaled for the sweeps: Ac[r] = -A[row][r] / diag(row),
-// 0 on the diagonal; w = (A lambda) of the warm start; lam[r] = warm-start impulse of row r (in every lane).  Knee rows
-// always (an inactive one has a zero impulse response), joint-limit rows one by one, contact rows per leg.
+// Delassus columns A[row][r] = J_row . W[r] = J_r . W[row] (M^-1 is symmetric), kept in registers already scaled for the
+// sweeps: Ac[r] = -A[row][r] / diag(row), 0 on the diagonal; w = (A lambda) of the warm start; lam[r] = warm-start impulse of
+// row r (in every lane).  Every row lane holds its OWN impulse response in registers (Row::wa, wq) and receives the Jacobian
+// of row r from that row's lane as DPP operands of the multiply-adds (row_newbcast), so a column costs no LDS traffic:
+// knee rows have J = e_knee (the column is an element of wq), joint-limit rows J = +-e_joint (one multiply), contact rows
+// the full 9 terms (6 base + the 3 joints of their leg, whose index is static per slot).  Knee rows always, joint-limit
+// rows one by one, contact rows per leg.
 template <bool HAS_B>
 __device__ __forceinline__ void delassus_columns(const Shared& S, unsigned int mask, int lane, int sub, Row& A, Row& B,
                                                  float (&AcA)[kMaxRows], float (&AcB)[kMaxRows], float (&lam)[kMaxRows]) {
@@ -579,20 +592,34 @@ __device__ __forceinline__ void delassus_columns(const Shared& S, unsigned int m
     constexpr int r = decltype(rc)::value;
     constexpr bool inB = r >= 4 && r < 16;
     constexpr int src = inB ? r : (r < 4 ? r : r - 12);
-    const float* Wr = S.ph.sub.W[r];
-    const float l0 = bcast_lane<src>(inB ? B.lam : A.lam, sub);
+    constexpr int legr = r < 4 ? r : (r < 16 ? (r - 4) / 3 : (r < 20 ? r - 16 : (r - 20) >> 1));
+    const Row& X = inB ? B : A;   // bank that holds row r (in lane src)
+    const float l0 = bcast_lane<src>(X.lam, sub);
     lam[r] = l0;
-    const float a = row_dot(A, Wr);
+    float a, b = 0.0f;
+    if (r < 4) {                  // knee friction motor: J = unit vector of the knee joint of leg r
+      a = A.wq[3 * legr + 2];
+      if (HAS_B) b = B.wq[3 * legr + 2];
+    } else if (r < 16) {          // joint limit: J = +-unit vector of joint r - 4
+      const float sg = bcast_lane<src>(X.jl[(r - 4) % 3], sub);
+      a = sg * A.wq[r - 4];
+      if (HAS_B) b = sg * B.wq[r - 4];
+    } else {
+      // contact rows live in bank A: lane src holds J_r = (Jb, jl)
+      a = dpp_dot9<src>(A.Jb[0], A.Jb[1], A.Jb[2], A.Jb[3], A.Jb[4], A.Jb[5], A.jl[0], A.jl[1], A.jl[2],
+                        A.wa[0], A.wa[1], A.wa[2], A.wa[3], A.wa[4], A.wa[5], A.wq[3 * legr], A.wq[3 * legr + 1], A.wq[3 * legr + 2]);
+      if (HAS_B)
+        b = dpp_dot9<src>(A.Jb[0], A.Jb[1], A.Jb[2], A.Jb[3], A.Jb[4], A.Jb[5], A.jl[0], A.jl[1], A.jl[2],
+                          B.wa[0], B.wa[1], B.wa[2], B.wa[3], B.wa[4], B.wa[5], B.wq[3 * legr], B.wq[3 * legr + 1], B.wq[3 * legr + 2]);
+    }
     A.w += a * l0;
     AcA[r] = (!inB && lane == src) ? 0.0f : -a * A.jdi;
     if (r >= 16 && r < 20 && A.nrm_slot == r) A.lam_n = l0;
     if (HAS_B) {
-      const float b = row_dot(B, Wr);
       B.w += b * l0;
       AcB[r] = (inB && lane == src) ? 0.0f : -b * B.jdi;
     }
-    asm("" : "+v"(AcA[r]), "+v"(AcB[r]));  // keep the scaled value (do not re-derive it inside the sweeps); not volatile:
-                                           // a volatile asm would end the scheduling region and expose every LDS read
+    asm("" : "+v"(AcA[r]), "+v"(AcB[r]));  // keep the scaled value (do not re-derive it inside the sweeps)
   };
   static_for<0, 4>(column);
   if (HAS_B) {
