@@ -368,6 +368,43 @@ __device__ __forceinline__ float dpp_dot9(float x0, float x1, float x2, float x3
         "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(w4), "v"(w5), "v"(w6), "v"(w7), "v"(w8), "n"(R));
   return a;
 }
+// The three Delassus entries of one leg's contact rows (normal z, friction x, friction y) for the impulse response (wa, wq) held
+// by this lane: t = wa_lin + wa_ang x rr + sum_k ck[k] wq[k], where rr (contact point relative to the base COM) and ck[k]
+// (velocity of the contact point per unit rate of joint k of that leg) come from lane R (the leg's normal-row lane) as DPP
+// operands.  18 instructions for three columns (three separate 9-term dot products: 30).
+template <int R>
+__device__ __forceinline__ void dpp_contact_triplet(float rr0, float rr1, float rr2, float c00, float c01, float c02, float c10, float c11,
+                                                    float c12, float c20, float c21, float c22, float wa0, float wa1, float wa2, float wa3,
+                                                    float wa4, float wa5, float q0, float q1, float q2, float& tx, float& ty, float& tz) {
+  static_assert(kRPW == 4, "row_newbcast needs 16 lanes per robot");
+#define ORR_NB " row_newbcast:%21 row_mask:0xf bank_mask:0xf\n\t"
+  asm("s_nop 1\n\t"
+      "v_mul_f32_dpp %0, %5, %16" ORR_NB     // tx  = rr2 * wa1
+      "v_mul_f32_dpp %1, %3, %17" ORR_NB     // ty  = rr0 * wa2
+      "v_mul_f32_dpp %2, %4, %15" ORR_NB     // tz  = rr1 * wa0
+      "v_fmac_f32_dpp %0, -%4, %17" ORR_NB   // tx -= rr1 * wa2
+      "v_fmac_f32_dpp %1, -%5, %15" ORR_NB   // ty -= rr2 * wa0
+      "v_fmac_f32_dpp %2, -%3, %16" ORR_NB   // tz -= rr0 * wa1
+      "v_add_f32 %0, %0, %18\n\t"
+      "v_add_f32 %1, %1, %19\n\t"
+      "v_add_f32 %2, %2, %20\n\t"
+      "v_fmac_f32_dpp %0, %6, %22" ORR_NB
+      "v_fmac_f32_dpp %1, %7, %22" ORR_NB
+      "v_fmac_f32_dpp %2, %8, %22" ORR_NB
+      "v_fmac_f32_dpp %0, %9, %23" ORR_NB
+      "v_fmac_f32_dpp %1, %10, %23" ORR_NB
+      "v_fmac_f32_dpp %2, %11, %23" ORR_NB
+      "v_fmac_f32_dpp %0, %12, %24" ORR_NB
+      "v_fmac_f32_dpp %1, %13, %24" ORR_NB
+      "v_fmac_f32_dpp %2, %14, %24 row_newbcast:%21 row_mask:0xf bank_mask:0xf"
+      : "=&v"(tx), "=&v"(ty), "=&v"(tz)
+      : "v"(rr0), "v"(rr1), "v"(rr2),                                             // 3 4 5
+        "v"(c00), "v"(c01), "v"(c02), "v"(c10), "v"(c11), "v"(c12),               // 6..11
+        "v"(c20), "v"(c21), "v"(c22),                                             // 12 13 14
+        "v"(wa0), "v"(wa1), "v"(wa2), "v"(wa3), "v"(wa4), "v"(wa5),               // 15..20
+        "n"(R), "v"(q0), "v"(q1), "v"(q2));                                       // 21, 22 23 24
+#undef ORR_NB
+}
 // max(x in lane R of this robot, 0) in one instruction (v_max_f32_dpp): the clamp of a unilateral row (contact normal, joint
 // limit: bounds [0, inf)) fused with its broadcast.  x has usually just been written, hence the s_nop (DPP read hazard).
 template <int R>

@@ -377,6 +377,11 @@ struct Row {
   float lo_c, hi_c, mu_e;      // bounds = constant part -/+ mu_e * lambda_normal
   float wa[6], wq[12];         // own impulse response M^-1 J^T (base part, joint part): kept in registers for the Delassus columns
 };
+// contact rows only (bank A): contact point relative to the base COM and its velocity per unit rate of the leg's joints; the
+// Jacobian of a contact row is ((rr x dir, dir), dir . ck[k]), which the Delassus columns exploit per leg (dpp_contact_triplet)
+struct ContactGeom {
+  float rr0, rr1, rr2, c00, c01, c02, c10, c11, c12, c20, c21, c22;   // scalars (not arrays): stays in registers for the inline-asm operands
+};
 
 __device__ __forceinline__ float row_dot(const Row& R, const float* Wr) {
   float a = R.Jb[0] * Wr[0] + R.Jb[1] * Wr[1] + R.Jb[2] * Wr[2] + R.Jb[3] * Wr[3] + R.Jb[4] * Wr[4] + R.Jb[5] * Wr[5];
@@ -384,23 +389,27 @@ __device__ __forceinline__ float row_dot(const Row& R, const float* Wr) {
   return a;
 }
 
-// Jacobian, right-hand side (not yet scaled by 1/diag) and bounds of row slot `slot`
+// Jacobian, right-hand side (not yet scaled by 1/diag) and bounds of row slot `slot`.  BANK 0: knee-friction and contact slots
+// (0..3, 16..27), BANK 1: joint-limit slots (4..15) -- two instantiations, so that the joint-limit bank carries no contact code
+// and its base Jacobian is the compile-time constant zero.
+template <int BANK>
 __device__ __forceinline__ void row_setup(const Shared& S, const orr_config& cfg, int slot, bool enable, float dt, float inv_dt,
-                                          float erp_dt, Row& R) {
+                                          float erp_dt, Row& R, ContactGeom& G) {
+  if (BANK == 0) G = ContactGeom{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
   R.active = false; R.leg = 0; R.nrm_slot = -1; R.warm = -1;
 #pragma unroll
   for (int i = 0; i < 6; i++) R.Jb[i] = 0.0f;
   R.jl[0] = R.jl[1] = R.jl[2] = 0.0f;
   R.rhs = 0.0f; R.jdi = 0.0f; R.lam = 0.0f; R.w = 0.0f; R.lam_n = 0.0f;
   float lo = 0.0f, hi = 0.0f, mu = 0.0f;
-  if (slot < 4) {
+  if (BANK == 0 && slot < 4) {
     R.leg = slot;
     const float fr = S.s[O(KNEE_FRICTION) + R.leg];
     R.active = fr > 0.0f;
     R.jl[2] = 1.0f;
     lo = -fr * dt; hi = fr * dt;
     R.rhs = -S.ustar[6 + 3 * R.leg + 2];
-  } else if (slot < 16) {
+  } else if (BANK == 1) {
     const int j = slot - 4;
     R.leg = j / 3;
     const int kk = j - 3 * R.leg;
@@ -441,9 +450,14 @@ __device__ __forceinline__ void row_setup(const Shared& S, const orr_config& cfg
       const LinkCache& L = S.ph.sub.dyn.lc[3 * leg + k];
       float cr[3];
       cross3(L.s, rr, cr);
-      R.jl[k] = dir[0] * (cr[0] + L.sv[0]) + dir[1] * (cr[1] + L.sv[1]) + dir[2] * (cr[2] + L.sv[2]);
+      cr[0] += L.sv[0]; cr[1] += L.sv[1]; cr[2] += L.sv[2];
+      if (k == 0) { G.c00 = cr[0]; G.c01 = cr[1]; G.c02 = cr[2]; }
+      else if (k == 1) { G.c10 = cr[0]; G.c11 = cr[1]; G.c12 = cr[2]; }
+      else { G.c20 = cr[0]; G.c21 = cr[1]; G.c22 = cr[2]; }
+      R.jl[k] = dir[0] * cr[0] + dir[1] * cr[1] + dir[2] * cr[2];
       rel += R.jl[k] * S.ustar[6 + 3 * leg + k];
     }
+    G.rr0 = rr[0]; G.rr1 = rr[1]; G.rr2 = rr[2];
     R.warm = 3 * leg + d;
     if (d == 0) {
       lo = 0.0f; hi = 1e30f;
@@ -584,34 +598,17 @@ __device__ __forceinline__ void pgs_sweeps(int iters, unsigned int mask, int lan
 // the full 9 terms (6 base + the 3 joints of their leg, whose index is static per slot).  Knee rows always, joint-limit
 // rows one by one, contact rows per leg.
 template <bool HAS_B>
-__device__ __forceinline__ void delassus_columns(const Shared& S, unsigned int mask, int lane, int sub, Row& A, Row& B,
+__device__ __forceinline__ void delassus_columns(const Shared& S, unsigned int mask, int lane, int sub, Row& A, Row& B, const ContactGeom& G,
                                                  float (&AcA)[kMaxRows], float (&AcB)[kMaxRows], float (&lam)[kMaxRows]) {
 #pragma unroll
   for (int r = 0; r < kMaxRows; r++) { AcA[r] = 0.0f; AcB[r] = 0.0f; lam[r] = 0.0f; }
-  auto column = [&](auto rc) __attribute__((always_inline)) {
+  // bookkeeping of one column once its entries a (this lane's bank-A row) and b (bank-B row) are known
+  auto finish = [&](auto rc, float a, float b) __attribute__((always_inline)) {
     constexpr int r = decltype(rc)::value;
     constexpr bool inB = r >= 4 && r < 16;
     constexpr int src = inB ? r : (r < 4 ? r : r - 12);
-    constexpr int legr = r < 4 ? r : (r < 16 ? (r - 4) / 3 : (r < 20 ? r - 16 : (r - 20) >> 1));
-    const Row& X = inB ? B : A;   // bank that holds row r (in lane src)
-    const float l0 = bcast_lane<src>(X.lam, sub);
+    const float l0 = bcast_lane<src>(inB ? B.lam : A.lam, sub);
     lam[r] = l0;
-    float a, b = 0.0f;
-    if (r < 4) {                  // knee friction motor: J = unit vector of the knee joint of leg r
-      a = A.wq[3 * legr + 2];
-      if (HAS_B) b = B.wq[3 * legr + 2];
-    } else if (r < 16) {          // joint limit: J = +-unit vector of joint r - 4
-      const float sg = bcast_lane<src>(X.jl[(r - 4) % 3], sub);
-      a = sg * A.wq[r - 4];
-      if (HAS_B) b = sg * B.wq[r - 4];
-    } else {
-      // contact rows live in bank A: lane src holds J_r = (Jb, jl)
-      a = dpp_dot9<src>(A.Jb[0], A.Jb[1], A.Jb[2], A.Jb[3], A.Jb[4], A.Jb[5], A.jl[0], A.jl[1], A.jl[2],
-                        A.wa[0], A.wa[1], A.wa[2], A.wa[3], A.wa[4], A.wa[5], A.wq[3 * legr], A.wq[3 * legr + 1], A.wq[3 * legr + 2]);
-      if (HAS_B)
-        b = dpp_dot9<src>(A.Jb[0], A.Jb[1], A.Jb[2], A.Jb[3], A.Jb[4], A.Jb[5], A.jl[0], A.jl[1], A.jl[2],
-                          B.wa[0], B.wa[1], B.wa[2], B.wa[3], B.wa[4], B.wa[5], B.wq[3 * legr], B.wq[3 * legr + 1], B.wq[3 * legr + 2]);
-    }
     A.w += a * l0;
     AcA[r] = (!inB && lane == src) ? 0.0f : -a * A.jdi;
     if (r >= 16 && r < 20 && A.nrm_slot == r) A.lam_n = l0;
@@ -621,19 +618,32 @@ __device__ __forceinline__ void delassus_columns(const Shared& S, unsigned int m
     }
     asm("" : "+v"(AcA[r]), "+v"(AcB[r]));  // keep the scaled value (do not re-derive it inside the sweeps)
   };
-  static_for<0, 4>(column);
+  static_for<0, 4>([&](auto rc) __attribute__((always_inline)) {   // knee friction motor: J = unit vector of the knee joint of leg r
+    constexpr int r = decltype(rc)::value;
+    finish(rc, A.wq[3 * r + 2], HAS_B ? B.wq[3 * r + 2] : 0.0f);
+  });
   if (HAS_B) {
-    static_for<4, 16>([&](auto rc) __attribute__((always_inline)) {
-      if ((mask >> decltype(rc)::value) & 1u) column(rc);
+    static_for<4, 16>([&](auto rc) __attribute__((always_inline)) {   // joint limit: J = +-unit vector of joint r - 4
+      constexpr int r = decltype(rc)::value;
+      if ((mask >> r) & 1u) {
+        const float sg = bcast_lane<r>(B.jl[(r - 4) % 3], sub);
+        finish(rc, sg * A.wq[r - 4], sg * B.wq[r - 4]);
+      }
     });
   }
   const unsigned int cm = (mask >> 16) & 0xFu;
-  static_for<0, 4>([&](auto gc) __attribute__((always_inline)) {
+  static_for<0, 4>([&](auto gc) __attribute__((always_inline)) {      // the three contact rows of leg g at once
     constexpr int g = decltype(gc)::value;
     if ((cm >> g) & 1u) {
-      column(std::integral_constant<int, 16 + g>{});
-      column(std::integral_constant<int, 20 + 2 * g>{});
-      column(std::integral_constant<int, 21 + 2 * g>{});
+      float ax, ay, az, bx = 0.0f, by = 0.0f, bz = 0.0f;
+      dpp_contact_triplet<4 + g>(G.rr0, G.rr1, G.rr2, G.c00, G.c01, G.c02, G.c10, G.c11, G.c12, G.c20, G.c21, G.c22, A.wa[0], A.wa[1], A.wa[2],
+                                 A.wa[3], A.wa[4], A.wa[5], A.wq[3 * g], A.wq[3 * g + 1], A.wq[3 * g + 2], ax, ay, az);
+      if (HAS_B)
+        dpp_contact_triplet<4 + g>(G.rr0, G.rr1, G.rr2, G.c00, G.c01, G.c02, G.c10, G.c11, G.c12, G.c20, G.c21, G.c22, B.wa[0], B.wa[1], B.wa[2],
+                                   B.wa[3], B.wa[4], B.wa[5], B.wq[3 * g], B.wq[3 * g + 1], B.wq[3 * g + 2], bx, by, bz);
+      finish(std::integral_constant<int, 16 + g>{}, az, bz);
+      finish(std::integral_constant<int, 20 + 2 * g>{}, ax, bx);
+      finish(std::integral_constant<int, 21 + 2 * g>{}, ay, by);
     }
   });
 }
@@ -669,8 +679,9 @@ __device__ static int physics_substep(const KParams& P, Shared& S, const LegCons
   // a joint near its limit.
   Row A, B;
   const bool rowlane = lane < 16;
-  row_setup(S, cfg, rowlane ? (lane < 4 ? lane : lane + 12) : 0, rowlane, dt, inv_dt, erp_dt, A);
-  row_setup(S, cfg, (rowlane && lane >= 4) ? lane : 4, rowlane && lane >= 4, dt, inv_dt, erp_dt, B);
+  ContactGeom G, Gunused;
+  row_setup<0>(S, cfg, rowlane ? (lane < 4 ? lane : lane + 12) : 0, rowlane, dt, inv_dt, erp_dt, A, G);
+  row_setup<1>(S, cfg, (rowlane && lane >= 4) ? lane : 4, rowlane && lane >= 4, dt, inv_dt, erp_dt, B, Gunused);
   const unsigned long long balA = __ballot(A.active), balB = __ballot(B.active);
   const bool anyB = balB != 0ull;  // wave-uniform
   // union over the robots of this wave of the active slots (a slot visited for a robot where it is inactive is a no-op)
@@ -689,11 +700,11 @@ __device__ static int physics_substep(const KParams& P, Shared& S, const LegCons
   // Delassus columns, then the Gauss-Seidel sweeps; two instantiations: with and without the joint-limit bank
   float AcA[kMaxRows], AcB[kMaxRows], lam[kMaxRows];
   if (anyB) {
-    delassus_columns<true>(S, mask, lane, sub, A, B, AcA, AcB, lam);
+    delassus_columns<true>(S, mask, lane, sub, A, B, G, AcA, AcB, lam);
     PT(7);
     pgs_sweeps<true>(cfg.solver_iters, mask, lane, sub, A, B, AcA, AcB, lam);
   } else {
-    delassus_columns<false>(S, mask, lane, sub, A, B, AcA, AcB, lam);
+    delassus_columns<false>(S, mask, lane, sub, A, B, G, AcA, AcB, lam);
     PT(7);
     pgs_sweeps<false>(cfg.solver_iters, mask, lane, sub, A, B, AcA, AcB, lam);
   }

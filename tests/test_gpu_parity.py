@@ -346,6 +346,9 @@ def test_latency_ring_wraps_with_random_latency():
     orc.state[:] = gpu_state64(env)
     rng = np.random.RandomState(3)
     for k in range(3):
+        # both sides start every env step from the device's state (ring included): what is compared is the ring / latency logic
+        # over the wrap-arounds, not how far three steps of contact dynamics amplify float32 rounding
+        orc.state[:] = gpu_state64(env)
         a = rng.uniform(-0.15, 0.15, (n, 12)).astype(np.float32)
         og, rg, dg, _ = env.step(torch.from_numpy(a).to(env.device))
         oo, ro, do = orc.step(a.astype(np.float64))
@@ -357,10 +360,13 @@ def test_latency_ring_wraps_with_random_latency():
     alive = ~(dg.cpu().numpy().astype(bool) | do)
     assert alive.mean() > 0.9
     rg_, ro_ = g[alive][:, sl].reshape(-1, _abi.RING_DEPTH, _abi.RING_ENTRY), orc.state[alive][:, sl].reshape(-1, _abi.RING_DEPTH, _abi.RING_ENTRY)
-    np.testing.assert_allclose(rg_[:, :, :16], ro_[:, :, :16], atol=1e-2)          # motor angles + relative quaternion of every entry
-    assert np.median(np.abs(rg_[:, :, 16:19] - ro_[:, :, 16:19])) < 2e-3           # base rates: contact dynamics amplify rounding
-    assert np.abs(rg_[:, :, 16:19] - ro_[:, :, 16:19]).max() < 0.3
-    np.testing.assert_allclose(og.cpu().numpy()[alive][:, 12:84], oo[alive][:, 12:84], atol=1e-2)   # last actions + delayed motor angles
+    # motor angles + relative quaternion of every ring entry: three env steps of contact dynamics amplify float32 rounding in a few
+    # robots, so 99.5 % of the entries within 1e-2 and none beyond 0.1
+    # motor angles + relative quaternion of every ring entry (one env step apart at most)
+    np.testing.assert_allclose(rg_[:, :, :16], ro_[:, :, :16], atol=2e-3)
+    dr = np.abs(rg_[:, :, 16:19] - ro_[:, :, 16:19])                                  # base rates: noisier (contacts)
+    assert np.median(dr) < 1e-3 and dr.max() < 0.3, (np.median(dr), dr.max())
+    np.testing.assert_allclose(og.cpu().numpy()[alive][:, 12:84], oo[alive][:, 12:84], atol=2e-3)   # last actions + delayed motor angles
 
 
 def test_auto_reset_inside_step_matches_oracle():
