@@ -129,9 +129,8 @@ struct alignas(16) LegExchange {  // per leg, hand-over between the lanes (parts
   float F[3][6];      // F_k = Ic_k S_k of joint k, written by part k
   float Hc[3][4];     // Hc[k][i] = S_i . F_k (valid for i <= k)
   float b[4];         // tau_k - C_k
-  float I[6], h[3], m, f[6];  // composite of the whole leg about O (part 0) and its bias force
 };
-struct alignas(16) LegSolve {   // per leg, written by its part-0 lane, read by the row lanes (see leg_dynamics in orr_physics.h)
+struct alignas(16) LegSolve {   // per leg: column k of T written by the leg's part-k lane, Hi by part 0; read by the row lanes
   float T[3][6];    // F H^-1: column k = base wrench (angular; linear, world axes, about the base COM) per unit of joint k
   float Hi[6];      // H^-1 of the leg's 3x3 joint-space inertia (00 11 22 01 02 12)
 };
@@ -319,6 +318,15 @@ __device__ __forceinline__ void symv(const float S[6], const float v[3], float o
 __device__ __forceinline__ float quad_sum(float x) {
   x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));  // quad_perm:[1,0,3,2]
   x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, true));  // quad_perm:[2,3,0,1]
+  return x;
+}
+
+// sum of x over the 16 lanes of this robot (one DPP row), in every lane: quad butterflies, then the two mirror permutes
+__device__ __forceinline__ float row_sum16(float x) {
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));   // quad_perm:[1,0,3,2]
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, true));   // quad_perm:[2,3,0,1]
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x140, 0xF, 0xF, true));  // row_mirror
   return x;
 }
 

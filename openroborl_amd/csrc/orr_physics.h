@@ -50,24 +50,30 @@ __device__ __forceinline__ void chol6_solve(const float L[21], const float invdi
 struct LegConst {
   float r[3][3], jdir[3], joff[3];  // chain: joint origin in the parent frame, internal angle = jdir * (q - joff)
   float com[3], m, Ic[6];           // own link: COM in the link frame, mass, inertia about the COM (xx yy zz xy xz yz)
+  float damp_l, damp_a;             // Bullet base damping coefficients in the lane that owns the base body, 0 elsewhere
 };
 __device__ static void load_leg_const(const Shared& S, int lane, LegConst& K) {
   const int leg = lane & 3, part = (lane >> 2) & 3, own = 3 * leg + (part < 3 ? part : 2);
 #pragma unroll
   for (int k = 0; k < 3; k++) {
     const int j = 3 * leg + k;
-    const bool on = k <= part;
+    const bool on = k <= part && part < 3;   // part-3 lanes walk no joint at all: their link frame is the base frame
 #pragma unroll
     for (int i = 0; i < 3; i++) K.r[k][i] = on ? S.m.joint_pos[j][i] : 0.0f;
     K.jdir[k] = on ? S.m.jdir[j] : 0.0f;
     K.joff[k] = S.m.joff[j];
   }
-  const bool real = part < 3;
+  // the part-3 lane of leg 0 (lane 12) owns the BASE body (its joint walk is the identity, so its link frame is the base frame and
+  // its bias force the base's gyroscopic terms); the part-3 lanes of the other legs stay idle copies with zero inertia
+  const bool real = part < 3, base = lane == 12;
+  const int body = real ? own + 1 : 0;
 #pragma unroll
   for (int i = 0; i < 3; i++) K.com[i] = real ? S.m.link_com[own][i] : 0.0f;
 #pragma unroll
-  for (int i = 0; i < 6; i++) K.Ic[i] = real ? S.Ic[own + 1][i] : 0.0f;
-  K.m = real ? S.mass[own + 1] : 0.0f;
+  for (int i = 0; i < 6; i++) K.Ic[i] = (real || base) ? S.Ic[body][i] : 0.0f;
+  K.m = (real || base) ? S.mass[body] : 0.0f;
+  K.damp_l = base ? S.s[O(BASE_DAMPING)] : 0.0f;
+  K.damp_a = base ? S.s[O(BASE_DAMPING) + 1] : 0.0f;
 }
 
 // ================================================================================================
@@ -85,9 +91,11 @@ __device__ static void load_leg_const(const Shared& S, int lane, LegConst& K) {
 // LDS: T_L (6x3), H_L^-1 per leg and A0^-1 (LegSolve / Shared::IA0inv) - the impulse response of a row is then
 //   da0 = A0^-1 (Jb - T_L jl);  dqdd_L = H_L^-1 jl - T_L^T da0;  dqdd_K = -T_K^T da0  (K != L).
 // Lane (leg = lane & 3, part = (lane >> 2) & 3): all lanes of a leg walk down its joints, but each computes the costly
-// per-link terms (inertia about O, bias force) only for link `part`; subtree sums run over the parts with DPP row
-// shifts, F / H / bias torques of the three joints are exchanged through LDS (LegExchange), and from there on every
-// lane of the leg holds the whole leg again (the base system is solved redundantly in all lanes).
+// per-link terms (inertia about O, bias force) only for link `part` (lane 12 = (leg 0, part 3) for the base body itself);
+// subtree sums run over the parts with DPP row shifts, F / H / bias torques of the three joints are exchanged through LDS
+// (LegExchange).  The base system is then ASSEMBLED across the 16 lanes: lane (leg, k) contributes its own link's inertia /
+// bias force and the k-th term of the leg's elimination, -T_k F_k^T and T_k b_k (T_k = column k of F H^-1), and one 16-lane
+// DPP butterfly per entry sums bodies, legs and joints at once; the 6x6 solve itself is redundant in all lanes.
 // ================================================================================================
 
 // R S R^T for a symmetric S (xx yy zz xy xz yz) and a general rotation R (row-major)
@@ -154,11 +162,13 @@ __device__ __forceinline__ void joint_down(const Shared& S, const LegConst& K, i
   for (int i = 0; i < 3; i++) { Aa[i] += t0[i]; Al[i] += t1[i] + t2[i]; }
 }
 
-// x_q + x_{q+1} + x_{q+2} over the lanes of one leg (lane = leg + 4 q): two DPP row shifts, zero beyond the row
+// sum of x over the own and the later LINK parts (q..2) of one leg (lane = leg + 4 q): two DPP row shifts, zero beyond the
+// row.  The part-3 lanes are not links of the chain (lane 12 carries the base body), so they are never a source: the bank masks
+// switch off the destination quads that would read them (lanes 8..11 for row_shl:4, lanes 4..7 for row_shl:8).
 __device__ __forceinline__ float part_suffix_sum(float x) {
   const int v = __float_as_int(x);
-  const float a = __int_as_float(__builtin_amdgcn_update_dpp(0, v, 0x104, 0xF, 0xF, true));  // row_shl:4
-  const float b = __int_as_float(__builtin_amdgcn_update_dpp(0, v, 0x108, 0xF, 0xF, true));  // row_shl:8
+  const float a = __int_as_float(__builtin_amdgcn_update_dpp(0, v, 0x104, 0xF, 0xB, true));  // row_shl:4, not into bank 2
+  const float b = __int_as_float(__builtin_amdgcn_update_dpp(0, v, 0x108, 0xF, 0xD, true));  // row_shl:8, not into bank 1
   return x + a + b;
 }
 
@@ -183,8 +193,8 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
   float so[3], svo[3];
 #pragma unroll
   for (int i = 0; i < 3; i++) {
-    so[i] = part == 0 ? s0[i] : (part == 1 ? s1[i] : s2[i]);
-    svo[i] = part == 0 ? sv0[i] : (part == 1 ? sv1[i] : sv2[i]);
+    so[i] = part == 0 ? s0[i] : (part == 1 ? s1[i] : (part == 2 ? s2[i] : 0.0f));       // part 3 owns no joint: F, T columns = 0
+    svo[i] = part == 0 ? sv0[i] : (part == 1 ? sv1[i] : (part == 2 ? sv2[i] : 0.0f));
   }
   const float ado = part == 0 ? ad0 : (part == 1 ? ad1 : ad2);
   if (lane < 12) {  // pose and joint axis of the own link for the constraint rows
@@ -195,7 +205,7 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
     for (int i = 0; i < 3; i++) { L.ow[i] = S.s[O(POS) + i] + d[i]; L.s[i] = so[i]; L.sv[i] = svo[i]; }
   }
   // ---- own link: spatial inertia about O and bias force f = I A + V x* (I V) ----
-  float I[6], h[3], m = K.m, f[6];
+  float I[6], h[3], m = K.m, f[6], pacc[6];
   {
     float c[3];
     mv3(Rw, K.com, c);
@@ -213,6 +223,21 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
     cross3(Vw, Pl, t2);
 #pragma unroll
     for (int i = 0; i < 3; i++) { f[i] = Fa[i] + t0[i] + t1[i]; f[3 + i] = Fl[i] + t2[i]; }
+    // force side of the base system: the link's bias force (+ Bullet's base damping on the base body, whose momentum is
+    // (Pa, Pl) = (I w, m v): torque k_a I w, force k_l m v; btMultiBody)
+#pragma unroll
+    for (int i = 0; i < 3; i++) { pacc[i] = f[i] + K.damp_a * Pa[i]; pacc[3 + i] = f[3 + i] + K.damp_l * Pl[i]; }
+  }
+  // own link's share of the matrix of the base system, before the subtree sums overwrite I / h / m: inertia about O, first
+  // moment, mass
+  float Iacc[6], Hacc[9], Macc[6];
+  {
+#pragma unroll
+    for (int i = 0; i < 6; i++) Iacc[i] = I[i];
+    Hacc[0] = 0.0f;   Hacc[1] = -h[2]; Hacc[2] = h[1];      // skew(h): top-right block of the composite spatial inertia
+    Hacc[3] = h[2];   Hacc[4] = 0.0f;  Hacc[5] = -h[0];
+    Hacc[6] = -h[1];  Hacc[7] = h[0];  Hacc[8] = 0.0f;
+    Macc[0] = Macc[1] = Macc[2] = m; Macc[3] = Macc[4] = Macc[5] = 0.0f;
   }
   // ---- way up: composite inertia and force sum of the subtree behind the own joint (sum over the leg's later parts) ----
 #pragma unroll
@@ -221,10 +246,10 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
   for (int i = 0; i < 3; i++) h[i] = part_suffix_sum(h[i]);
   m = part_suffix_sum(m);
   // own column of F and of the leg's joint-space inertia H (entries H[i][part], i <= part), own bias torque
+  float Fo[6], bo;
   {
-    float Fo[6];
     spatial_inertia_mul(I, h, m, so, svo, &Fo[0], &Fo[3]);
-    const float bo = S.tau[3 * leg + (part < 3 ? part : 2)] - (dot3(so, &f[0]) + dot3(svo, &f[3]));
+    bo = S.tau[3 * leg + (part < 3 ? part : 2)] - (dot3(so, &f[0]) + dot3(svo, &f[3]));
     const float hc0 = dot3(s0, &Fo[0]) + dot3(sv0, &Fo[3]), hc1 = dot3(s1, &Fo[0]) + dot3(sv1, &Fo[3]);
     const float hc2 = dot3(s2, &Fo[0]) + dot3(sv2, &Fo[3]);
     if (lane < 12) {
@@ -233,18 +258,11 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
       for (int i = 0; i < 6; i++) X.F[part][i] = Fo[i];
       X.b[part] = bo;
       X.Hc[part][0] = hc0; X.Hc[part][1] = hc1; X.Hc[part][2] = hc2;
-      if (part == 0) {  // composite of the whole leg
-#pragma unroll
-        for (int i = 0; i < 6; i++) { X.I[i] = I[i]; X.f[i] = f[i]; }
-#pragma unroll
-        for (int i = 0; i < 3; i++) X.h[i] = h[i];
-        X.m = m;
-      }
     }
   }
   WSYNC();
-  // ---- every lane of the leg: all three F columns, H, the leg composite ----
-  float F[3][6], b[3], GI[6], Gh[3], Gm, Gf[6];
+  // ---- every lane of the leg: all three F columns and H ----
+  float F[3][6], b[3];
   float H00, H01, H02, H11, H12, H22;
   {
     const LegExchange& X = S.ph.sub.dyn.legx[leg];
@@ -255,11 +273,6 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
       b[k] = X.b[k];
     }
     H00 = X.Hc[0][0]; H01 = X.Hc[1][0]; H11 = X.Hc[1][1]; H02 = X.Hc[2][0]; H12 = X.Hc[2][1]; H22 = X.Hc[2][2];
-#pragma unroll
-    for (int i = 0; i < 6; i++) { GI[i] = X.I[i]; Gf[i] = X.f[i]; }
-#pragma unroll
-    for (int i = 0; i < 3; i++) Gh[i] = X.h[i];
-    Gm = X.m;
   }
   float Hi[6];  // H^-1, symmetric (00 11 22 01 02 12), by cofactors
   {
@@ -268,71 +281,58 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
     const float idet = __builtin_amdgcn_rcpf(H00 * c00 + H01 * c01 + H02 * c02);
     Hi[0] = c00 * idet; Hi[1] = c11 * idet; Hi[2] = c22 * idet; Hi[3] = c01 * idet; Hi[4] = c02 * idet; Hi[5] = c12 * idet;
   }
-  float T[3][6];  // T = F H^-1 (column k of T = sum_m F_m Hi[m][k])
+  // row / column `part` of H^-1 (zero in the part-3 lanes: they own no joint)
+  const float hq0 = part == 0 ? Hi[0] : (part == 1 ? Hi[3] : (part == 2 ? Hi[4] : 0.0f));
+  const float hq1 = part == 0 ? Hi[3] : (part == 1 ? Hi[1] : (part == 2 ? Hi[5] : 0.0f));
+  const float hq2 = part == 0 ? Hi[4] : (part == 1 ? Hi[5] : (part == 2 ? Hi[2] : 0.0f));
+  float Tq[6];  // column `part` of T = F H^-1
 #pragma unroll
-  for (int i = 0; i < 6; i++) {
-    T[0][i] = F[0][i] * Hi[0] + F[1][i] * Hi[3] + F[2][i] * Hi[4];
-    T[1][i] = F[0][i] * Hi[3] + F[1][i] * Hi[1] + F[2][i] * Hi[5];
-    T[2][i] = F[0][i] * Hi[4] + F[1][i] * Hi[5] + F[2][i] * Hi[2];
-  }
-  if (first) {
+  for (int i = 0; i < 6; i++) Tq[i] = F[0][i] * hq0 + F[1][i] * hq1 + F[2][i] * hq2;
+  if (lane < 12) {
     LegSolve& Q = S.leg[leg];
 #pragma unroll
-    for (int k = 0; k < 3; k++)
+    for (int i = 0; i < 6; i++) Q.T[part][i] = Tq[i];
+    if (first) {
 #pragma unroll
-      for (int i = 0; i < 6; i++) Q.T[k][i] = T[k][i];
-#pragma unroll
-    for (int i = 0; i < 6; i++) Q.Hi[i] = Hi[i];
+      for (int i = 0; i < 6; i++) Q.Hi[i] = Hi[i];
+    }
   }
-  // this leg's part of the base equation: composite inertia minus T F^T, force p + T b
-  float Iacc[6], Hacc[9], Macc[6], pacc[6];
-#define TFT(i, j) (T[0][i] * F[0][j] + T[1][i] * F[1][j] + T[2][i] * F[2][j])
-  Iacc[0] = GI[0] - TFT(0, 0); Iacc[1] = GI[1] - TFT(1, 1); Iacc[2] = GI[2] - TFT(2, 2);
-  Iacc[3] = GI[3] - TFT(0, 1); Iacc[4] = GI[4] - TFT(0, 2); Iacc[5] = GI[5] - TFT(1, 2);
-  Macc[0] = Gm - TFT(3, 3); Macc[1] = Gm - TFT(4, 4); Macc[2] = Gm - TFT(5, 5);
-  Macc[3] = -TFT(3, 4); Macc[4] = -TFT(3, 5); Macc[5] = -TFT(4, 5);
-  // top-right block: skew(h) - (T F^T)[a][3 + b]
-  Hacc[0] = -TFT(0, 3);          Hacc[1] = -Gh[2] - TFT(0, 4); Hacc[2] = Gh[1] - TFT(0, 5);
-  Hacc[3] = Gh[2] - TFT(1, 3);   Hacc[4] = -TFT(1, 4);         Hacc[5] = -Gh[0] - TFT(1, 5);
-  Hacc[6] = -Gh[1] - TFT(2, 3);  Hacc[7] = Gh[0] - TFT(2, 4);  Hacc[8] = -TFT(2, 5);
+  // this lane's term of the elimination: -T_k F_k^T on the matrix, +T_k b_k on the force (Fo is zero in the part-3 lanes)
+#define TFT(i, j) (Tq[i] * Fo[j])
+  Iacc[0] -= TFT(0, 0); Iacc[1] -= TFT(1, 1); Iacc[2] -= TFT(2, 2);
+  Iacc[3] -= TFT(0, 1); Iacc[4] -= TFT(0, 2); Iacc[5] -= TFT(1, 2);
+  Macc[0] -= TFT(3, 3); Macc[1] -= TFT(4, 4); Macc[2] -= TFT(5, 5);
+  Macc[3] -= TFT(3, 4); Macc[4] -= TFT(3, 5); Macc[5] -= TFT(4, 5);
+  Hacc[0] -= TFT(0, 3); Hacc[1] -= TFT(0, 4); Hacc[2] -= TFT(0, 5);
+  Hacc[3] -= TFT(1, 3); Hacc[4] -= TFT(1, 4); Hacc[5] -= TFT(1, 5);
+  Hacc[6] -= TFT(2, 3); Hacc[7] -= TFT(2, 4); Hacc[8] -= TFT(2, 5);
 #undef TFT
 #pragma unroll
-  for (int i = 0; i < 6; i++) pacc[i] = Gf[i] + T[0][i] * b[0] + T[1][i] * b[1] + T[2][i] * b[2];
-  // base: sum the four leg contributions (butterfly over lane bits 0, 1 = DPP quad permutes, fused into the adds)
+  for (int i = 0; i < 6; i++) pacc[i] += Tq[i] * bo;
+  // base system: sum over all bodies / legs / joints = over the robot's 16 lanes (DPP butterfly fused into the adds)
 #pragma unroll
-  for (int i = 0; i < 6; i++) { Iacc[i] = quad_sum(Iacc[i]); Macc[i] = quad_sum(Macc[i]); pacc[i] = quad_sum(pacc[i]); }
+  for (int i = 0; i < 6; i++) { Iacc[i] = row_sum16(Iacc[i]); Macc[i] = row_sum16(Macc[i]); pacc[i] = row_sum16(pacc[i]); }
 #pragma unroll
-  for (int i = 0; i < 9; i++) Hacc[i] = quad_sum(Hacc[i]);
+  for (int i = 0; i < 9; i++) Hacc[i] = row_sum16(Hacc[i]);
   float a0[6];
   {
-    float A6[36], pA0[6], Ibw[6];
-    const float m0 = S.mass[0];
-    rot_sym_full(Rb, S.Ic[0], Ibw);
-    float n[3], fb[3] = {m0 * vb[0], m0 * vb[1], m0 * vb[2]}, t1[3], t2[3];
-    symv(Ibw, wb, n);
-    cross3(wb, n, t1);
-    cross3(wb, fb, t2);
-    // Bullet base damping (btMultiBody): torque k_a I w, force k_l m v on the bias side
-    const float kl = S.s[O(BASE_DAMPING)], ka = S.s[O(BASE_DAMPING) + 1];
-#pragma unroll
-    for (int i = 0; i < 3; i++) { pA0[i] = t1[i] + ka * n[i] + pacc[i]; pA0[3 + i] = t2[i] + kl * fb[i] + pacc[3 + i]; }
-    float Ib[9], Im[9], Mm[9];
-    sym_to_m3(Ibw, Ib);
+    float A6[36];
+    float Im[9], Mm[9];
     sym_to_m3(Iacc, Im);
     sym_to_m3(Macc, Mm);
 #pragma unroll
     for (int a_ = 0; a_ < 3; a_++)
 #pragma unroll
       for (int b_ = 0; b_ < 3; b_++) {
-        A6[a_ * 6 + b_] = Ib[a_ * 3 + b_] + Im[a_ * 3 + b_];
+        A6[a_ * 6 + b_] = Im[a_ * 3 + b_];
         A6[a_ * 6 + 3 + b_] = Hacc[a_ * 3 + b_];
         A6[(3 + a_) * 6 + b_] = Hacc[b_ * 3 + a_];
-        A6[(3 + a_) * 6 + 3 + b_] = Mm[a_ * 3 + b_] + (a_ == b_ ? m0 : 0.0f);
+        A6[(3 + a_) * 6 + 3 + b_] = Mm[a_ * 3 + b_];
       }
     float Lc[21], idg[6], nb[6];
     chol6(A6, Lc, idg);
 #pragma unroll
-    for (int i = 0; i < 6; i++) nb[i] = -pA0[i];
+    for (int i = 0; i < 6; i++) nb[i] = -pacc[i];
     chol6_solve(Lc, idg, nb, a0);
     // explicit inverse for the impulse responses: lane c (< 6) solves for unit column c
     float e[6], x[6];
@@ -345,17 +345,15 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
       for (int i = 0; i < 6; i++) S.IA0inv[i * 6 + col] = x[i];
     }
   }
-  // joint accelerations qdd = H^-1 (b - F^T a0); written as the unconstrained velocities u* = u + dt udot by the lane
-  // that owns the joint (it has the joint rate)
+  // joint accelerations qdd = H^-1 (b - F^T a0): row `part` of H^-1 for the lane's own joint; written as the unconstrained
+  // velocity u* = u + dt udot by the lane that owns the joint (it has the joint rate)
   const float dt = P.cfg.sim_dt;
   {
     float g[3];
 #pragma unroll
     for (int k = 0; k < 3; k++)
       g[k] = b[k] - (F[k][0] * a0[0] + F[k][1] * a0[1] + F[k][2] * a0[2] + F[k][3] * a0[3] + F[k][4] * a0[4] + F[k][5] * a0[5]);
-    const float q0 = Hi[0] * g[0] + Hi[3] * g[1] + Hi[4] * g[2], q1 = Hi[3] * g[0] + Hi[1] * g[1] + Hi[5] * g[2];
-    const float q2 = Hi[4] * g[0] + Hi[5] * g[1] + Hi[2] * g[2];
-    if (lane < 12) S.ustar[6 + 3 * leg + part] = ado + dt * (part == 0 ? q0 : (part == 1 ? q1 : q2));
+    if (lane < 12) S.ustar[6 + 3 * leg + part] = ado + dt * (hq0 * g[0] + hq1 * g[1] + hq2 * g[2]);
   }
   if (lane == 0) {
     // classical base acceleration (Bullet: vdot = a_lin + w x v); gravity = uniform-field offset
