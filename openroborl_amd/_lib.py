@@ -23,8 +23,11 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # schedule for instruction-level parallelism rather than occupancy, and keep the SLP vectoriser off (its packed-fp32
 # operations cost more register moves than they save).  Measured on MI355X, 4096 robots: -O3 default 7.1 M env steps/s,
 # + iterative-ilp 7.5 M, + no SLP 7.9 M, -O2 8.1 M.
+# -amdgpu-atomic-optimizer-strategy=None: the optimizer merges the atomics of a wave into one and hands every lane its share with
+# v_readfirstlane right after it, i.e. it waits for the L2 round trip on the spot; the episode-log slot atomic is issued before
+# the reset and consumed after it instead, and the per-launch counters are combined per wave by hand (orr_step_kernel).
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O2", "-fPIC", "-shared", "-std=c++17", "-Wno-unused-value", "-fno-slp-vectorize",
-               "-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
+               "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
 
 EXPORTS = [
     "orr_last_error", "orr_abi_version", "orr_source_hash", "orr_state_stride", "orr_layout_count", "orr_layout_name",

@@ -151,7 +151,7 @@ struct alignas(16) StepEndBuf {           // live only at reset / end of step
   float vel[18];
   float ee[2][8][3];          // end-effector world positions, [0] sim [1] ref
   float obs[ORR_OBS_DIM];
-  float red[64];              // small cross-lane reductions of the step-end code
+  float red[80];              // small cross-lane reductions of the step-end code; reset_robot: ring entries #1 / #2 and the 28 draws
 };
 union PhaseBuf {
   SubstepBuf sub;
@@ -171,7 +171,7 @@ struct alignas(16) Shared {
   alignas(16) float co[20];    // control (latency-delayed) observation
   alignas(16) PhaseBuf ph;
 #ifdef ORR_PHASE_TIMERS
-  long long pt_acc[16], pt_last;  // development aid, see PT() in orr_kernels.hip
+  long long pt_acc[24], pt_last;  // development aid, see PT() in orr_kernels.hip
 #endif
 };
 
@@ -570,6 +570,21 @@ __device__ __forceinline__ float philox_uniform(unsigned long long seed, uint32_
   uint32_t sel = idx & 3u;
   uint32_t x = sel == 0 ? c0 : (sel == 1 ? c1 : (sel == 2 ? c2 : c3));
   return (float)(x >> 8) * (1.0f / 16777216.0f);
+}
+// one whole block: draws 4 * block .. 4 * block + 3 of stream (robot, episode)
+__device__ __forceinline__ void philox_block(unsigned long long seed, uint32_t robot, uint32_t episode, uint32_t block, float u[4]) {
+  uint32_t c0 = robot, c1 = episode, c2 = block, c3 = 0x4F52524Cu;
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  u[0] = (float)(c0 >> 8) * (1.0f / 16777216.0f); u[1] = (float)(c1 >> 8) * (1.0f / 16777216.0f);
+  u[2] = (float)(c2 >> 8) * (1.0f / 16777216.0f); u[3] = (float)(c3 >> 8) * (1.0f / 16777216.0f);
 }
 
 // ------------------------------------------------------------------------------------------------

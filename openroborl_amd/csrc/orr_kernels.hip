@@ -19,10 +19,10 @@
 // Development aid (tools/phase_cycles.py): -DORR_PHASE_TIMERS makes lane 0 of one wave accumulate shader-clock cycles
 // per phase (Shared::pt_acc) and add them to g_phase_cycles at the end of the launch.
 #ifdef ORR_PHASE_TIMERS
-__device__ long long g_phase_cycles[16];
-#define PT_INIT() do { if (threadIdx.x == 0) { for (int i_ = 0; i_ < 16; i_++) S.pt_acc[i_] = 0; S.pt_last = clock64(); } } while (0)
+__device__ long long g_phase_cycles[24];   // 0..15: phases of the step, 16..23: stages of reset_robot
+#define PT_INIT() do { if (threadIdx.x == 0) { for (int i_ = 0; i_ < 24; i_++) S.pt_acc[i_] = 0; S.pt_last = clock64(); } } while (0)
 #define PT(k) do { if (threadIdx.x == 0) { const long long t_ = clock64(); S.pt_acc[k] += t_ - S.pt_last; S.pt_last = clock64(); } } while (0)
-#define PT_FLUSH() do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) for (int i_ = 0; i_ < 16; i_++) atomicAdd((unsigned long long*)&g_phase_cycles[i_], (unsigned long long)S.pt_acc[i_]); } while (0)
+#define PT_FLUSH() do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) for (int i_ = 0; i_ < 24; i_++) atomicAdd((unsigned long long*)&g_phase_cycles[i_], (unsigned long long)S.pt_acc[i_]); } while (0)
 #else
 #define PT_INIT()
 #define PT(k)
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(64) void orr_reset_kernel(KParams P, const uint8_t*
   ORR_PROLOGUE();
   const bool valid = in_range && !(mask && !mask[robot]);
   load_robot(P, rec, S, lane);
-  const long long total = P.counters ? P.counters[ORR_CNT_TOTAL_STEP_COUNT] : 0;
+  const long long total = P.counters[ORR_CNT_TOTAL_STEP_COUNT];
   reset_robot(P, rec, S, lane, valid, total, obs);
   WSYNC();
   store_robot(rec, S, lane, valid);
@@ -77,6 +77,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
   const bool valid = in_range;
   const orr_config& c = P.cfg;
   PT_INIT();
+  // curriculum counter as of the start of the launch (the last wave of the previous launch folded that launch's episodes in):
+  // read here, far ahead of its only use (the time limit of an episode that starts in this launch)
+  const long long total_snapshot = P.counters[ORR_CNT_TOTAL_STEP_COUNT];
   load_robot(P, rec, S, lane);
   // impulse-response table: stale rows are multiplied by zero impulses, so they only have to be finite
   for (int i = lane; i < kMaxRows * kWStride; i += kLanes) (&S.ph.sub.W[0][0])[i] = 0.0f;
@@ -239,25 +242,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
     done_out[robot] = reason != 0;
   }
   PT(13);
-  long long total_snapshot = P.counters ? P.counters[ORR_CNT_TOTAL_STEP_COUNT] : 0;
   if (reason != 0) {
+    // episode log (imitation_runners.py:185-197): the slot comes from a returning atomic; it is issued first and consumed after
+    // the reset, so its round trip to L2 overlaps the reset instead of stalling in front of it
+    unsigned long long slot;   // deliberately not initialised: a merged value would make the compiler wait for the atomic right away
+    float log_ret = 0.0f, log_len = 0.0f;
+    const bool logs = lane == 0 && valid;
+    if (logs) slot = atomicAdd((unsigned long long*)&P.counters[ORR_CNT_EPISODES], 1ull);
     if (lane == 0) {
-      S.s[O(LAST_EP_RETURN)] = S.s[O(EP_RETURN)];
+      log_ret = S.s[O(EP_RETURN)]; log_len = (float)geti(S, O(EP_STEP));
+      S.s[O(LAST_EP_RETURN)] = log_ret;
       seti(S, O(LAST_EP_LEN), geti(S, O(EP_STEP)));
-      if (P.counters && valid) {
-        atomicAdd((unsigned long long*)&P.counters[ORR_CNT_DONE_ACCUM], 1ull);
-        const unsigned long long slot = atomicAdd((unsigned long long*)&P.counters[ORR_CNT_EPISODES], 1ull);
-        if (P.ep_log && slot < (unsigned long long)P.ep_log_cap) {
-          P.ep_log[2 * slot] = S.s[O(EP_RETURN)];
-          P.ep_log[2 * slot + 1] = (float)geti(S, O(EP_STEP));
-        } else if (P.ep_log) {
-          atomicAdd((unsigned long long*)&P.counters[ORR_CNT_EPLOG_DROPPED], 1ull);
-        }
-      }
     }
     WSYNC();
     if (c.flags & ORR_FLAG_AUTO_RESET) {
       reset_robot(P, rec, S, lane, valid, total_snapshot, obs);
+    }
+    if (logs && P.ep_log) {
+      if (slot < (unsigned long long)P.ep_log_cap) {
+        P.ep_log[2 * slot] = log_ret;
+        P.ep_log[2 * slot + 1] = log_len;
+      } else {
+        atomicAdd((unsigned long long*)&P.counters[ORR_CNT_EPLOG_DROPPED], 1ull);
+      }
     }
   }
   WSYNC();
@@ -267,11 +274,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
     for (int i = lane; i < ORR_OBS_DIM; i += kLanes) obs_out[(size_t)robot * ORR_OBS_DIM + i] = obs[i];
   PT(15);
   PT_FLUSH();
-  // the last wave to finish folds this launch's done count into the curriculum counter (wrapper_env.py:82-83)
-  if (P.counters && valid && lane == 0) {
+  // One counter update per WAVE (the compiler's own atomic combining is switched off, see _lib.HIPCC_FLAGS: it makes the issuing
+  // lane wait for the returned value on the spot): thread 0 adds the wave's finished episodes to the launch accumulator and takes
+  // a ticket for the wave's robots; the last wave to finish folds the launch's done count into the curriculum counter
+  // (wrapper_env.py:82-83).
+  const unsigned long long fin_mask = __ballot(valid && lane == 0 && reason != 0), val_mask = __ballot(valid && lane == 0);
+  if (threadIdx.x == 0) {
+    const unsigned long long nfin = (unsigned long long)__popcll(fin_mask), nval = (unsigned long long)__popcll(val_mask);
+    if (nfin) atomicAdd((unsigned long long*)&P.counters[ORR_CNT_DONE_ACCUM], nfin);
     __threadfence();  // this wave's DONE_ACCUM / episode-log writes are visible before its ticket is
-    const unsigned long long ticket = atomicAdd((unsigned long long*)&P.counters[ORR_CNT_TICKET], 1ull);
-    if (ticket == (unsigned long long)P.cfg.num_robots - 1ull) {
+    const unsigned long long ticket = atomicAdd((unsigned long long*)&P.counters[ORR_CNT_TICKET], nval);
+    if (ticket + nval == (unsigned long long)P.cfg.num_robots) {
       const unsigned long long nd = atomicExch((unsigned long long*)&P.counters[ORR_CNT_DONE_ACCUM], 0ull);
       atomicAdd((unsigned long long*)&P.counters[ORR_CNT_TOTAL_STEP_COUNT], nd);
       atomicAdd((unsigned long long*)&P.counters[ORR_CNT_TOTAL_TIMESTEPS], (unsigned long long)P.cfg.num_robots);
@@ -463,7 +476,7 @@ int32_t orr_set_motion(orr_handle* h, int32_t clip_id, const float* frames_dev, 
 }
 
 int32_t orr_bind(orr_handle* h, void* state_dev, int64_t* counters_dev, float* ep_log_dev, int32_t ep_log_capacity) {
-  if (!h || !state_dev) return fail(-1, "orr_bind: null argument");
+  if (!h || !state_dev || !counters_dev) return fail(-1, "orr_bind: null argument (state and counters are required)");
   h->state = (float*)state_dev;
   h->counters = (long long*)counters_dev;
   h->ep_log = ep_log_dev;
@@ -525,11 +538,11 @@ int32_t orr_time_steps(orr_handle* h, const float* actions_dev, float* obs_dev, 
 
 #ifdef ORR_PHASE_TIMERS
 // development aid: read (and optionally clear) the per-phase cycle totals of the instrumented wave
-int orr_debug_phase_cycles(long long* out16, int reset) {
+int orr_debug_phase_cycles(long long* out24, int reset) {
   HIPCHK(hipDeviceSynchronize(), "orr_debug_phase_cycles: sync");
-  HIPCHK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_cycles), 16 * sizeof(long long)), "orr_debug_phase_cycles: read");
+  HIPCHK(hipMemcpyFromSymbol(out24, HIP_SYMBOL(g_phase_cycles), 24 * sizeof(long long)), "orr_debug_phase_cycles: read");
   if (reset) {
-    long long z[16] = {0};
+    long long z[24] = {0};
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z)), "orr_debug_phase_cycles: clear");
   }
   return 0;

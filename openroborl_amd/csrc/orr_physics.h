@@ -129,13 +129,10 @@ __device__ __forceinline__ void spatial_inertia_mul(const float I[6], const floa
 // velocity and velocity-product acceleration.  For a joint beyond the lane's own link the constants are zero and the
 // step is the identity (angle 0, rate 0, offset 0).
 template <int AX>
-__device__ __forceinline__ void joint_down(const Shared& S, const LegConst& K, int k, int j, float Rw[9], float d[3], float Vw[3],
-                                           float Vv[3], float Aa[3], float Al[3], float s[3], float sv[3], float& ad_out) {
-  const float a = K.jdir[k] * (S.s[O(Q) + j] - K.joff[k]);
+__device__ __forceinline__ void joint_down(const Shared& S, const LegConst& K, int k, int j, float sn, float cs, float Rw[9], float d[3],
+                                           float Vw[3], float Vv[3], float Aa[3], float Al[3], float s[3], float sv[3], float& ad_out) {
   const float ad = K.jdir[k] * S.s[O(QD) + j];
   ad_out = ad;
-  float sn, cs;
-  joint_sincos(a, &sn, &cs);
   // pose: d += Rw_parent r;  Rw = Rw_parent R(a)
   {
     float t[3];
@@ -186,9 +183,30 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
   float s0[3], sv0[3], s1[3], sv1[3], s2[3], sv2[3], ad0, ad1, ad2;
 #pragma unroll
   for (int i = 0; i < 9; i++) Rw[i] = Rb[i];
-  joint_down<0>(S, K, 0, 3 * leg, Rw, d, Vw, Vv, Aa, Al, s0, sv0, ad0);
-  joint_down<1>(S, K, 1, 3 * leg + 1, Rw, d, Vw, Vv, Aa, Al, s1, sv1, ad1);
-  joint_down<1>(S, K, 2, 3 * leg + 2, Rw, d, Vw, Vv, Aa, Al, s2, sv2, ad2);
+  // sine / cosine of the joint angles: every lane evaluates ONE polynomial pair, for its own joint (part 3: angle 0), and gets
+  // the joints in front of it from the lanes of the earlier parts of its leg (DPP row_shr:4 / :8); joints behind its own link
+  // are identity steps (sin 0, cos 1)
+  float sn0, cs0, sn1, cs1, sn2, cs2;
+  {
+    const int jo = 3 * leg + (part < 3 ? part : 2);
+    const float jd = part == 0 ? K.jdir[0] : (part == 1 ? K.jdir[1] : (part == 2 ? K.jdir[2] : 0.0f));
+    const float jf = part == 0 ? K.joff[0] : (part == 1 ? K.joff[1] : K.joff[2]);
+    float sno, cso;
+    joint_sincos(jd * (S.s[O(Q) + jo] - jf), &sno, &cso);
+    const float sA = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sno), 0x114, 0xF, 0xF, true));  // row_shr:4
+    const float cA = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(cso), 0x114, 0xF, 0xF, true));
+    const float sB = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sno), 0x118, 0xF, 0xF, true));  // row_shr:8
+    const float cB = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(cso), 0x118, 0xF, 0xF, true));
+    sn0 = part == 0 ? sno : (part == 1 ? sA : (part == 2 ? sB : 0.0f));
+    cs0 = part == 0 ? cso : (part == 1 ? cA : (part == 2 ? cB : 1.0f));
+    sn1 = part == 1 ? sno : (part == 2 ? sA : 0.0f);
+    cs1 = part == 1 ? cso : (part == 2 ? cA : 1.0f);
+    sn2 = part == 2 ? sno : 0.0f;
+    cs2 = part == 2 ? cso : 1.0f;
+  }
+  joint_down<0>(S, K, 0, 3 * leg, sn0, cs0, Rw, d, Vw, Vv, Aa, Al, s0, sv0, ad0);
+  joint_down<1>(S, K, 1, 3 * leg + 1, sn1, cs1, Rw, d, Vw, Vv, Aa, Al, s1, sv1, ad1);
+  joint_down<1>(S, K, 2, 3 * leg + 2, sn2, cs2, Rw, d, Vw, Vv, Aa, Al, s2, sv2, ad2);
   // own joint: axis and rate
   float so[3], svo[3];
 #pragma unroll

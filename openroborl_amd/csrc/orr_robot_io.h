@@ -66,8 +66,9 @@ __device__ __forceinline__ void base_rotation(Shared& S, int lane, float rel[4],
   }
 }
 
-// Minitaur.receive_obs + get_true_obs (minitaur.py:304-334): push the true observation
-__device__ static void receive_obs(float* rec, Shared& S, int lane, bool valid) {
+// Minitaur.receive_obs + get_true_obs (minitaur.py:304-334): push the true observation.  entry: optional copy of the pushed
+// entry (20 words, LDS) for callers that build the control observation without reading the ring back (reset_robot).
+__device__ static void receive_obs(float* rec, Shared& S, int lane, bool valid, float* entry = nullptr) {
   const int head = (geti(S, O(RING_HEAD)) + 1) % ORR_RING_DEPTH, len = geti(S, O(RING_LEN));
   float rel[4], Rb[9], rate[3];
   base_rotation(S, lane, rel, Rb);
@@ -83,6 +84,7 @@ __device__ static void receive_obs(float* rec, Shared& S, int lane, bool valid) 
       val = i == 16 ? rate[0] : (i == 17 ? rate[1] : rate[2]);
     }
     if (valid) rec[O(RING) + head * ORR_RING_ENTRY + i] = val;
+    if (entry) entry[i] = val;
   }
   WSYNC();
   if (lane == 0) {

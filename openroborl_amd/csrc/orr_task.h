@@ -60,15 +60,38 @@ __device__ static void sample_poses(const KParams& P, Shared& S, int lane, int n
   Sample sm = clip_index(c, lane < nt ? t_lane : 0.0f);
   if (lane < nt) { S.ph.end.red[2 * lane] = __int_as_float(sm.f0); S.ph.end.red[2 * lane + 1] = __int_as_float(sm.f1); }
   WSYNC();
-  for (int e = 0; e < 2 * nt; e++) {
-    const int f = __float_as_int(S.ph.end.red[e]);
-    for (int i = lane; i < 19; i += kLanes) S.ph.end.frames[e][i] = c.frames[f * 19 + i];
+  {
+    // The clip pointers come out of a device table, i.e. as generic pointers: loads through them would be FLAT instructions,
+    // which also count on the LDS counter, so every LDS access in between would wait for the previous frame to arrive (13
+    // serialised round trips).  They point to global memory (orr_set_motion takes device pointers): say so, fetch all rows
+    // first (frame row = 19 words: lane i and, for lanes 0..2, word 16 + i), then stage them.
+    typedef const float __attribute__((address_space(1))) * gptr;
+    const gptr frames = (gptr)c.frames, vels = (gptr)c.vels;
+    constexpr int kMaxE = 10;
+    float lo[kMaxE + 1], hi[kMaxE + 1], v0[2], v1[2];
+    const int w1 = lane < 3 ? 16 + lane : lane;
+#pragma unroll
+    for (int e = 0; e < kMaxE; e++) {
+      const int f = e < 2 * nt ? __float_as_int(S.ph.end.red[e]) : 0;
+      lo[e] = frames[f * 19 + lane]; hi[e] = frames[f * 19 + w1];
+    }
+    lo[kMaxE] = frames[lane]; hi[kMaxE] = frames[w1];                       // frame 0 (warm-up heading)
+    {
+      const int f0 = __float_as_int(S.ph.end.red[0]), f1 = __float_as_int(S.ph.end.red[1]);
+      const int w2 = lane < 2 ? 16 + lane : lane;
+      v0[0] = vels[f0 * 18 + lane]; v0[1] = vels[f0 * 18 + w2];
+      v1[0] = vels[f1 * 18 + lane]; v1[1] = vels[f1 * 18 + w2];
+    }
+#pragma unroll
+    for (int e = 0; e <= kMaxE; e++) {
+      S.ph.end.frames[e][lane] = lo[e];
+      if (lane < 3) S.ph.end.frames[e][16 + lane] = hi[e];
+    }
+    if (with_vel) {
+      S.ph.end.fvel[0][lane] = v0[0]; S.ph.end.fvel[1][lane] = v1[0];
+      if (lane < 2) { S.ph.end.fvel[0][16 + lane] = v0[1]; S.ph.end.fvel[1][16 + lane] = v1[1]; }
+    }
   }
-  if (with_vel) {
-    const int f0 = __float_as_int(S.ph.end.red[0]), f1 = __float_as_int(S.ph.end.red[1]);
-    for (int i = lane; i < 18; i += kLanes) { S.ph.end.fvel[0][i] = c.vels[f0 * 18 + i]; S.ph.end.fvel[1][i] = c.vels[f1 * 18 + i]; }
-  }
-  for (int i = lane; i < 19; i += kLanes) S.ph.end.frames[10][i] = c.frames[i];  // frame 0 (warm-up heading)
   WSYNC();
   if (lane < nt) {
     const bool warm_pose = warm_ep && t_lane >= -P.cfg.warmup_time && t_lane < 0.0f;
@@ -143,9 +166,10 @@ __device__ __forceinline__ float motion_time(const KParams& P, const Shared& S) 
   return t;
 }
 
-// build the 76-d target observation into obs76 (LDS) from S.ph.end.pose[1..4] (already origin-offset) -- imitation_task.py:254-301
+// build the 76-d target observation into obs76 (LDS) from S.ph.end.pose[1..4] (already origin-offset) -- imitation_task.py:254-301.
+// The control observation S.co must be current (it is after the last sub-step's ring push and after reset_robot's local blend).
 __device__ static void target_obs(const KParams& P, const float* rec, Shared& S, int lane, float* obs76) {
-  ctrl_obs(P, rec, S, lane);
+  if (kLanes != 16) ctrl_obs(P, rec, S, lane);
   if (lane >= 1 && lane <= 4) {
     float rpy[3];
     euler_from_quat(&S.co[12], rpy);
@@ -340,15 +364,34 @@ __device__ static void reset_robot(const KParams& P, float* rec, Shared& S, int 
     S.s[O(EP_RETURN)] = 0.0f;
   }
   WSYNC();
-  receive_obs(rec, S, lane, valid);  // ring entry #1
+  PT(16);
+  // ring entries #1 and #2 of the new episode are kept (LDS) so that the control observations of the reset are blended from them
+  // directly: reading the ring back would be a store -> load round trip through memory each time
+  float* e1 = S.ph.end.red;            // 20 words each; red[] is free here (sample_poses uses red[0..9] later: e1 is consumed before)
+  receive_obs(rec, S, lane, valid, e1);  // ring entry #1
   // 3. sensor histories <- 3 copies of the current readings (minitaur.py:270-271; sensor_wrappers.py:122-129)
-  ctrl_obs(P, rec, S, lane);
+  PT(17);
+  WSYNC();
+  for (int i = lane; i < 19; i += kLanes) S.co[i] = e1[i];   // one entry in the ring: _get_delay_obs returns it (minitaur.py:345-346)
+  WSYNC();
   sensors_push(S, lane, true);
+  const float e1_keep[2] = {e1[lane], e1[lane < 3 ? 16 + lane : lane]};   // ring entry #1: words lane and (lanes 0..2) 16 + lane
+  PT(18);
   // 4. randomiser (controllable_env_randomizer_from_config.py:92-122), sorted-name draw order:
   //    inertia 2 | joint friction 8 | latency 1 | lateral friction 1 | mass 2 | motor strength 12
+  // all 28 draws of the episode (0..25 randomiser, 26 ref-state-init, 27 time offset) = 7 Philox blocks: lane b < 7 evaluates
+  // block b once and parks its four numbers in LDS
+  float* draws = S.ph.end.red + 24;    // 28 words
+  static_assert(kLanes == 16, "reset_robot / sample_poses assume 16 lanes per robot");
+  if (lane < 7) {
+    float u4[4];
+    philox_block(c.seed, robot, ep, (uint32_t)lane, u4);
+    draws[4 * lane] = u4[0]; draws[4 * lane + 1] = u4[1]; draws[4 * lane + 2] = u4[2]; draws[4 * lane + 3] = u4[3];
+  }
+  WSYNC();
   if (c.flags & ORR_FLAG_RANDOMIZER) {
     for (int i = lane; i < 26; i += kLanes) {
-      const float u = philox_uniform(c.seed, robot, ep, (uint32_t)i);
+      const float u = draws[i];
       if (i < 2) S.s[O(INERTIA_RATIO) + i] = 0.5f + u * 1.0f;
       else if (i < 10) { if (((i - 2) & 1) == 0) S.s[O(KNEE_FRICTION) + ((i - 2) >> 1)] = u * 0.05f; }
       else if (i == 10) S.s[O(LATENCY)] = u * 0.04f;
@@ -360,10 +403,11 @@ __device__ static void reset_robot(const KParams& P, float* rec, Shared& S, int 
     refresh_mass(P.tab->model[geti(S, O(ROBOT_TYPE))], S, lane);
     WSYNC();
   }
+  PT(19);
   // 5. task reset (imitation_task.py:183-199, 694-732, 1103-1110)
   const DevClip& clip = P.tab->clip[geti(S, O(CLIP_ID))];
   {
-    const float u1 = philox_uniform(c.seed, robot, ep, 26u), u2 = philox_uniform(c.seed, robot, ep, 27u);
+    const float u1 = draws[26], u2 = draws[27];
     const bool ref_init = u1 < c.ref_state_init_prob;
     const bool warm = (!ref_init) && c.warmup_time > 0.0f;
     if (lane == 0) {
@@ -378,7 +422,9 @@ __device__ static void reset_robot(const KParams& P, float* rec, Shared& S, int 
   const float step_dt = c.sim_dt * c.action_repeat;
   float tl = t;
   if (lane >= 1 && lane <= 4) tl = t + c.tar_frame_steps[lane - 1] * step_dt;
+  PT(20);
   sample_poses(P, S, lane, 5, tl, true);
+  PT(21);
   if (lane == 0) {
     // origin offset: position first (with identity rotation), then rotation; position is NOT recomputed
     // afterwards (imitation_task.py:712-723)
@@ -404,10 +450,26 @@ __device__ static void reset_robot(const KParams& P, float* rec, Shared& S, int 
   if (lane < 4) S.s[O(QUAT) + lane] = S.ph.end.pose[0][3 + lane];
   if (lane < 12) { S.s[O(Q) + lane] = S.ph.end.pose[0][7 + lane]; S.s[O(QD) + lane] = S.ph.end.vel[6 + lane]; }
   WSYNC();
-  receive_obs(rec, S, lane, valid);  // ring entry #2 (imitation_task.py:792)
+  PT(22);
+  float* e2 = S.ph.end.red + 56;         // ring entry #2; entry #1 was saved in registers below before red[] was reused
+  receive_obs(rec, S, lane, valid, e2);  // ring entry #2 (imitation_task.py:792)
+  {
+    // control observation with two entries in the ring (Minitaur._get_delay_obs, minitaur.py:336-357): latency <= 0 -> newest;
+    // int(latency / dt) + 1 >= 2 -> the OLDEST entry (#1, the default pose: SURVEY 8a quirk 3); else blend newest / #1
+    const float lat = S.s[O(LATENCY)], dt = c.sim_dt;
+    const int n = (int)(lat / dt);
+    const float al = (lat - n * dt) / dt;
+    WSYNC();
+    for (int i = lane; i < 19; i += kLanes) {
+      const float newest = e2[i], oldest = i < 16 ? e1_keep[0] : e1_keep[1];
+      S.co[i] = lat <= 0.0f ? newest : (n + 1 >= 2 ? oldest : (1.0f - al) * newest + al * oldest);
+    }
+    WSYNC();
+  }
   // 7. observation = histories from step 3 + target observation (quadruped_gym_env.py:100-102; wrapper_env.py:101-105)
   if (lane == 0) seti(S, O(MAX_EP_STEPS), time_limit(c, total_step_count));
   if (lane < 12) obs[lane] = S.s[O(IMU_HIST) + lane];
   for (int i = lane; i < 36; i += kLanes) { obs[12 + i] = S.s[O(LASTACT_HIST) + i]; obs[48 + i] = S.s[O(MOTORANG_HIST) + i]; }
+  PT(23);
   target_obs(P, rec, S, lane, obs + ORR_PROPRIO_DIM);
 }

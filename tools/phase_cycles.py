@@ -29,14 +29,25 @@ g = torch.Generator().manual_seed(0)
 act = (torch.randn(4096, 12, generator=g) * 0.1).to(env.device)
 L = _lib.load()
 L.orr_debug_phase_cycles.argtypes = [C.POINTER(C.c_longlong), C.c_int]
-buf = (C.c_longlong * 16)()
+buf = (C.c_longlong * 24)()
 for _ in range(50):
     env.step(act)
 L.orr_debug_phase_cycles(buf, 1)
+events = 0       # env steps in which the instrumented wave (block gridDim / 2 = robots 2048..2051) reset at least one robot
+dones = torch.zeros(4, dtype=torch.int64, device=env.device)
 for _ in range(steps):
-    env.step(act)
+    _, _, d, _ = env.step(act)
+    dones += d[2048:2052].long()
+    events += int(d[2048:2052].any())
 L.orr_debug_phase_cycles(buf, 1)
-tot = float(sum(buf))
+tot = float(sum(buf[:16]))
 print("cycles per env step (one wave, %d steps): %.0f" % (steps, tot / steps))
-for n, v in zip(NAMES, buf):
+for n, v in zip(NAMES, buf[:16]):
     print("  %-22s %9.0f  %5.1f%%" % (n, v / steps, 100.0 * v / tot))
+print("steps with a reset in the instrumented wave: %d of %d (robot resets: %s); cycles per such step in 'episode end/reset': %.0f"
+      % (events, steps, dones.tolist(), buf[14] / max(events, 1)))
+RESET = ["state defaults", "ring entry #1", "ctrl obs + sensor fill", "randomiser draws", "task draws", "clip sampling", "origin + teleport",
+         "ring entry #2 + time limit"]
+print("stages of reset_robot, cycles per reset of robot 0 of the wave (the last stage, target observation, is timed inside 'episode end/reset'):")
+for n, v in zip(RESET, buf[16:24]):
+    print("  %-28s %9.0f" % (n, v / max(int(dones[0]), 1)))

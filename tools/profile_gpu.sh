@@ -11,6 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $ROOT/bench.py --config $CFG --steps 40 --warmup 10 --no-cpu-baseline"
 BENCH_TRACE="python3 $ROOT/bench.py --config $CFG --no-cpu-baseline"   # = the default bench.py run
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH_TRACE > $OUT/trace.log 2>&1
+export ORR_BENCH_WARMUP_FLOOR=50     # PMC passes: a short warm-up (every dispatch is serialised and recorded)
 for P in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
          "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM" \
          "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32"; do
