@@ -237,6 +237,16 @@ int32_t orr_step(orr_handle* h, const float* actions_dev, float* obs_dev, float*
  * [N,12] applied as tau_urdf = tau * JOINT_DIRECTIONS; fall_dev [N] receives the fall-proxy flag (may be NULL). */
 int32_t orr_debug_physics(orr_handle* h, const float* torques_dev, uint8_t* fall_dev, int32_t nsub, void* stream);
 
+/* parity / debug entries (not part of the drop-in surface): WrapperEnv.step / reset with the physics engine REPLAYED.
+ * traj [N][action_repeat][37] = rigid state (POS QUAT LINVEL ANGVEL Q QD) after each sub-step, eff [N][2][8][3] = link positions
+ * for the end-effector reward ([0] robot, [1] reference model; lower leg, toe per leg), fall [N] = non-foot ground contact,
+ * tau_out [N][action_repeat][12] receives the motor torques; uniforms [N][28] = the draws of the reset in [0, 1).  They exist so
+ * that the HIP path can be compared with fixtures recorded from the reference's own Python (tests/golden/make_golden_task.py). */
+int32_t orr_debug_replay_step(orr_handle* h, const float* actions_dev, const float* traj_dev, const float* eff_dev,
+                              const uint8_t* fall_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev,
+                              float* tau_out_dev, void* stream);
+int32_t orr_debug_replay_reset(orr_handle* h, const float* uniforms_dev, float* obs_dev, void* stream);
+
 /* last launch durations in ms measured with hipEvents on the launch stream (bench only; syncs) */
 int32_t orr_time_steps(orr_handle* h, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev,
                        void* stream, int32_t num_steps, float* total_ms_out);

@@ -105,6 +105,17 @@ struct DevTables {
   DevClip clip[ORR_MAX_CLIPS];
 };
 
+// Replay inputs of the parity entry points orr_debug_replay_reset / orr_debug_replay_step (kernel MODE 2): the scripted states,
+// link positions, contact flags and random draws recorded while the reference's own Python was driven with a scripted pybullet
+// client (tests/golden/make_golden_task.py).  All NULL in the product launches.
+struct ReplayArgs {
+  const float* traj;       // [N][action_repeat][37] rigid state after each sub-step: replaces physics_substep
+  const float* eff;        // [N][2][8][3] link positions for the end-effector reward: [0] sim robot, [1] reference model
+  const uint8_t* fall;     // [N] a ground contact on a non-foot link was reported
+  float* tau_out;          // [N][action_repeat][12] motor torques of the actuator chain (motor order), recorded
+  const float* uniforms;   // [N][28] random draws in [0, 1): replace the Philox stream at reset
+};
+
 struct KParams {
   orr_config cfg;
   float fb[3], fa[3];  // Butterworth coefficients (action_filter.py:196-217), computed on the host in double

@@ -51,12 +51,12 @@ using namespace orr;
   const int robot = in_range ? robot_raw : 0; /* a padding lane group shadows robot 0 and never stores */ \
   float* rec = P.state + (size_t)robot * ORR_STATE_STRIDE
 
-__global__ __launch_bounds__(64) void orr_reset_kernel(KParams P, const uint8_t* mask, float* obs_out) {
+__global__ __launch_bounds__(64) void orr_reset_kernel(KParams P, const uint8_t* mask, float* obs_out, const float* uniforms) {
   ORR_PROLOGUE();
   const bool valid = in_range && !(mask && !mask[robot]);
   load_robot(P, rec, S, lane);
   const long long total = P.counters[ORR_CNT_TOTAL_STEP_COUNT];
-  reset_robot(P, rec, S, lane, valid, total, obs);
+  reset_robot(P, rec, S, lane, valid, total, obs, uniforms ? uniforms + (size_t)robot * 28 : nullptr);
   WSYNC();
   store_robot(rec, S, lane, valid);
   if (obs_out && valid)
@@ -64,7 +64,10 @@ __global__ __launch_bounds__(64) void orr_reset_kernel(KParams P, const uint8_t*
 }
 
 // mode 0: full env step.  mode 1 (debug / parity of row C): nsub physics sub-steps with the given
-// motor torques (actions = torques), no robot or task logic.
+// motor torques (actions = torques), no robot or task logic.  mode 2 (parity of everything BUT row C): a full env step in
+// which the physics sub-step is replaced by the recorded states of ReplayArgs, the end-effector reward reads recorded link
+// positions and the fall flag is given -- the device-side counterpart of the oracle's replay mode, fed with the fixtures that the
+// reference's own Python produced (tests/test_gpu_golden_task.py).
 #ifndef ORR_WAVES_PER_EU
 #define ORR_WAVES_PER_EU 1  // 4096 robots, four per wave = one wave on each of the 1024 SIMDs: the whole batch is resident at once
 #endif
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(64) void orr_reset_kernel(KParams P, const uint8_t*
 // occupancy-improving reschedules once the kernel fits 256 VGPRs and then crashes in the register allocator.
 template <int MODE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PER_EU, ORR_WAVES_PER_EU))) void orr_step_kernel(KParams P, const float* actions, float* obs_out, float* reward_out,
-                                                      uint8_t* done_out, int nsub) {
+                                                      uint8_t* done_out, int nsub, ReplayArgs RP) {
   ORR_PROLOGUE();
   const bool valid = in_range;
   const orr_config& c = P.cfg;
@@ -155,6 +158,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
     if (kLanes == 16) {  // receive_obs, then the control observation of the next sub-step / of get_obs
       RingFetch F;
       ring_prefetch(rlat, rec, ring, lane, F);
+      if constexpr (MODE == 2) {
+        const size_t slot = (size_t)robot * c.action_repeat + sstep;
+        if (lane < 12 && valid) RP.tau_out[slot * 12 + lane] = S.tau[mj] * S.m.tau_sign[mj] ;  // motor torque, motor order
+        WSYNC();
+        for (int i = lane; i < 37; i += kLanes) S.s[O(POS) + i] = RP.traj[slot * 37 + i];        // POS QUAT LINVEL ANGVEL Q QD
+        WSYNC();
+        fall = RP.fall[robot];
+      } else
       fall = physics_substep(P, S, K, lane, sub, sstep == c.action_repeat - 1);
       ring_push_and_ctrl_obs(rec, S, lane, valid, F, ring, (S.s[O(Q) + mj] - m_off) * m_dir);
     } else {
@@ -176,7 +187,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
   sensors_push(S, lane, false);
   PT(11);
   // ---- reward -> update -> done (quadruped_gym_env.py:230-233) ----
-  float rew = calc_reward(P, S, lane);
+  float rew = calc_reward(P, S, lane, MODE == 2 ? RP.eff + (size_t)robot * 48 : nullptr);
   const DevClip& clip = P.tab->clip[geti(S, O(CLIP_ID))];
   const float t = motion_time(P, S);
   const float step_dt = c.sim_dt * c.action_repeat;
@@ -498,7 +509,8 @@ static KParams make_params(const orr_handle* h) {
 
 int32_t orr_reset(orr_handle* h, const uint8_t* mask_dev, float* obs_dev, void* stream) {
   if (!h || !h->state) return fail(-1, "orr_reset: handle not bound");
-  hipLaunchKernelGGL(orr_reset_kernel, dim3((h->cfg.num_robots + kRPW - 1) / kRPW), dim3(64), 0, (hipStream_t)stream, make_params(h), mask_dev, obs_dev);
+  hipLaunchKernelGGL(orr_reset_kernel, dim3((h->cfg.num_robots + kRPW - 1) / kRPW), dim3(64), 0, (hipStream_t)stream, make_params(h), mask_dev, obs_dev,
+                     (const float*)nullptr);
   HIPCHK(hipGetLastError(), "orr_reset: launch");
   return 0;
 }
@@ -507,7 +519,7 @@ int32_t orr_step(orr_handle* h, const float* actions_dev, float* obs_dev, float*
   if (!h || !h->state) return fail(-1, "orr_step: handle not bound");
   if (!actions_dev || !obs_dev || !reward_dev || !done_dev) return fail(-1, "orr_step: null buffer");
   hipLaunchKernelGGL(orr_step_kernel<0>, dim3((h->cfg.num_robots + kRPW - 1) / kRPW), dim3(64), 0, (hipStream_t)stream, make_params(h), actions_dev,
-                     obs_dev, reward_dev, done_dev, 0);
+                     obs_dev, reward_dev, done_dev, 0, ReplayArgs{});
   HIPCHK(hipGetLastError(), "orr_step: launch");
   return 0;
 }
@@ -516,8 +528,30 @@ int32_t orr_step(orr_handle* h, const float* actions_dev, float* obs_dev, float*
 int32_t orr_debug_physics(orr_handle* h, const float* torques_dev, uint8_t* fall_dev, int32_t nsub, void* stream) {
   if (!h || !h->state || !torques_dev) return fail(-1, "orr_debug_physics: bad argument");
   hipLaunchKernelGGL(orr_step_kernel<1>, dim3((h->cfg.num_robots + kRPW - 1) / kRPW), dim3(64), 0, (hipStream_t)stream, make_params(h), torques_dev,
-                     nullptr, nullptr, fall_dev, nsub);
+                     nullptr, nullptr, fall_dev, nsub, ReplayArgs{});
   HIPCHK(hipGetLastError(), "orr_debug_physics: launch");
+  return 0;
+}
+
+// parity / debug entry points (not part of the drop-in surface): the env step / reset with the physics engine, the link
+// positions, the contact flag and the random draws REPLAYED from buffers (see ReplayArgs in orr_device.h)
+int32_t orr_debug_replay_step(orr_handle* h, const float* actions_dev, const float* traj_dev, const float* eff_dev, const uint8_t* fall_dev,
+                              float* obs_dev, float* reward_dev, uint8_t* done_dev, float* tau_out_dev, void* stream) {
+  if (!h || !h->state) return fail(-1, "orr_debug_replay_step: handle not bound");
+  if (!actions_dev || !traj_dev || !eff_dev || !fall_dev || !obs_dev || !reward_dev || !done_dev || !tau_out_dev)
+    return fail(-1, "orr_debug_replay_step: null buffer");
+  if (h->cfg.flags & ORR_FLAG_AUTO_RESET) return fail(-1, "orr_debug_replay_step: needs a handle without ORR_FLAG_AUTO_RESET");
+  ReplayArgs rp{traj_dev, eff_dev, fall_dev, tau_out_dev, nullptr};
+  hipLaunchKernelGGL(orr_step_kernel<2>, dim3((h->cfg.num_robots + kRPW - 1) / kRPW), dim3(64), 0, (hipStream_t)stream, make_params(h), actions_dev,
+                     obs_dev, reward_dev, done_dev, 0, rp);
+  HIPCHK(hipGetLastError(), "orr_debug_replay_step: launch");
+  return 0;
+}
+int32_t orr_debug_replay_reset(orr_handle* h, const float* uniforms_dev, float* obs_dev, void* stream) {
+  if (!h || !h->state || !uniforms_dev) return fail(-1, "orr_debug_replay_reset: bad argument");
+  hipLaunchKernelGGL(orr_reset_kernel, dim3((h->cfg.num_robots + kRPW - 1) / kRPW), dim3(64), 0, (hipStream_t)stream, make_params(h),
+                     (const uint8_t*)nullptr, obs_dev, uniforms_dev);
+  HIPCHK(hipGetLastError(), "orr_debug_replay_reset: launch");
   return 0;
 }
 

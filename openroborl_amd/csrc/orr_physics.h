@@ -495,18 +495,28 @@ __device__ __forceinline__ void row_setup(const Shared& S, const orr_config& cfg
 
 // impulse response M^-1 J^T of the row (what btMultiBody::calcAccelerationDeltasMultiDof returns) -> W[slot]; 1/diag;
 // warm start.  Block form, see leg_dynamics: da0 = A0^-1 (Jb - T_L jl); dqdd_L = H_L^-1 jl - T_L^T da0; dqdd_K = -T_K^T da0.
+// The 6-vector algebra runs on PACKED float pairs (v_pk_fma_f32 / v_pk_mul_f32: two multiply-adds per issued instruction): rows
+// of T and of A0^-1 come out of LDS as aligned pairs, scalar factors ride as op_sel broadcasts.  A0^-1 is symmetric, so its
+// row k doubles as column k and a pair of outputs needs no horizontal add.
+typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void row_response(Shared& S, const orr_config& cfg, Row& R, int slot) {
   const int leg = R.leg;
   const LegSolve& QL = S.leg[leg];
-  float fb[6], a0[6], mq[12];
+  float a0[6], mq[12];
+  v2f fb2[3], a02[3];
+  {
+    const v2f* TL = reinterpret_cast<const v2f*>(&QL.T[0][0]);   // TL[3 k + p] = (T[k][2p], T[k][2p+1])
 #pragma unroll
-  for (int i = 0; i < 6; i++) fb[i] = R.Jb[i] - (QL.T[0][i] * R.jl[0] + QL.T[1][i] * R.jl[1] + QL.T[2][i] * R.jl[2]);
+    for (int p = 0; p < 3; p++) {
+      const v2f jb = {R.Jb[2 * p], R.Jb[2 * p + 1]};
+      fb2[p] = jb - (TL[p] * R.jl[0] + TL[3 + p] * R.jl[1] + TL[6 + p] * R.jl[2]);
+    }
+    const v2f* IA = reinterpret_cast<const v2f*>(S.IA0inv);       // IA[3 k + p] = (A0^-1[k][2p], A0^-1[k][2p+1])
 #pragma unroll
-  for (int i = 0; i < 6; i++) {
-    float sacc = 0.0f;
+    for (int p = 0; p < 3; p++)
+      a02[p] = IA[p] * fb2[0].x + IA[3 + p] * fb2[0].y + IA[6 + p] * fb2[1].x + IA[9 + p] * fb2[1].y + IA[12 + p] * fb2[2].x + IA[15 + p] * fb2[2].y;
 #pragma unroll
-    for (int k = 0; k < 6; k++) sacc += S.IA0inv[i * 6 + k] * fb[k];
-    a0[i] = sacc;
+    for (int p = 0; p < 3; p++) { a0[2 * p] = a02[p].x; a0[2 * p + 1] = a02[p].y; }
   }
   const float h0 = QL.Hi[0] * R.jl[0] + QL.Hi[3] * R.jl[1] + QL.Hi[4] * R.jl[2];
   const float h1 = QL.Hi[3] * R.jl[0] + QL.Hi[1] * R.jl[1] + QL.Hi[5] * R.jl[2];
@@ -514,14 +524,12 @@ __device__ __forceinline__ void row_response(Shared& S, const orr_config& cfg, R
   float diag = 0.0f;
 #pragma unroll
   for (int L4 = 0; L4 < 4; L4++) {
-    const LegSolve& Q = S.leg[L4];
+    const v2f* TK = reinterpret_cast<const v2f*>(&S.leg[L4].T[0][0]);
     const bool mine = (L4 == leg);
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-      float t = 0.0f;
-#pragma unroll
-      for (int i = 0; i < 6; i++) t += Q.T[k][i] * a0[i];
-      mq[3 * L4 + k] = (mine ? (k == 0 ? h0 : (k == 1 ? h1 : h2)) : 0.0f) - t;
+      const v2f t2 = TK[3 * k] * a02[0] + TK[3 * k + 1] * a02[1] + TK[3 * k + 2] * a02[2];
+      mq[3 * L4 + k] = (mine ? (k == 0 ? h0 : (k == 1 ? h1 : h2)) : 0.0f) - (t2.x + t2.y);
     }
     diag += mine ? (R.jl[0] * mq[3 * L4] + R.jl[1] * mq[3 * L4 + 1] + R.jl[2] * mq[3 * L4 + 2]) : 0.0f;
   }

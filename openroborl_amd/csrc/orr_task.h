@@ -230,7 +230,8 @@ __device__ __forceinline__ void task_heading_rot(const Shared& S, const float q[
 }
 
 // ImitationTask.reward (imitation_task.py:341-516); every lane returns the same value
-__device__ static float calc_reward(const KParams& P, Shared& S, int lane) {
+// eff_replay (parity replay only, else NULL): [2][8][3] link positions that replace the forward kinematics
+__device__ static float calc_reward(const KParams& P, Shared& S, int lane, const float* eff_replay = nullptr) {
   const float* rp = &S.s[O(REF_POSE)];
   const float* rv = &S.s[O(REF_VEL)];
   if (lane < 8) {
@@ -240,6 +241,10 @@ __device__ static float calc_reward(const KParams& P, Shared& S, int lane) {
     else leg_end_effectors(S, rp, rp + 3, rp + 7, leg, lower, toe);
 #pragma unroll
     for (int i = 0; i < 3; i++) { S.ph.end.ee[which][2 * leg][i] = lower[i]; S.ph.end.ee[which][2 * leg + 1][i] = toe[i]; }
+  }
+  if (eff_replay) {
+    WSYNC();
+    for (int i = lane; i < 48; i += kLanes) (&S.ph.end.ee[0][0][0])[i] = eff_replay[i];
   }
   WSYNC();
   const orr_config& c = P.cfg;
@@ -338,7 +343,9 @@ __device__ static void sensors_push(Shared& S, int lane, bool fill_all) {
 // reset of one robot (wrapper_env.py:87-107 -> quadruped_gym_env.py:63-104 -> minitaur.py:232-278 ->
 // imitation_task.py:166-199); SURVEY.md Appendix A.2.  Writes the 160-d observation into obs (LDS).
 // ================================================================================================
-__device__ static void reset_robot(const KParams& P, float* rec, Shared& S, int lane, bool valid, long long total_step_count, float* obs) {
+// uni_replay (parity replay only, else NULL): 28 draws in [0, 1) that replace the Philox stream
+__device__ static void reset_robot(const KParams& P, float* rec, Shared& S, int lane, bool valid, long long total_step_count, float* obs,
+                                   const float* uni_replay = nullptr) {
   const orr_config& c = P.cfg;
   // every reset starts a new episode = a new RNG stream (robot, episode)
   const uint32_t robot = (uint32_t)geti(S, O(ROBOT_INDEX)), ep = (uint32_t)geti(S, O(EPISODE_IDX)) + 1u;
@@ -385,7 +392,8 @@ __device__ static void reset_robot(const KParams& P, float* rec, Shared& S, int 
   static_assert(kLanes == 16, "reset_robot / sample_poses assume 16 lanes per robot");
   if (lane < 7) {
     float u4[4];
-    philox_block(c.seed, robot, ep, (uint32_t)lane, u4);
+    if (uni_replay) { u4[0] = uni_replay[4 * lane]; u4[1] = uni_replay[4 * lane + 1]; u4[2] = uni_replay[4 * lane + 2]; u4[3] = uni_replay[4 * lane + 3]; }
+    else philox_block(c.seed, robot, ep, (uint32_t)lane, u4);
     draws[4 * lane] = u4[0]; draws[4 * lane + 1] = u4[1]; draws[4 * lane + 2] = u4[2]; draws[4 * lane + 3] = u4[3];
   }
   WSYNC();

@@ -78,7 +78,7 @@ class VecQuadrupedEnv(object):
 
     def __init__(self, task_name=None, training_yaml=None, sim_yaml=None, device="cuda", num_robot=None, seed=None,
                  robot=None, motion_file=None, mode=None, enable_randomizer=None, auto_reset=True, num_procs=1,
-                 robot_index_offset=0, legacy_grid=False, mixed_robots=None, ep_log_capacity=65536):
+                 robot_index_offset=0, legacy_grid=False, mixed_robots=None, ep_log_capacity=65536, config_overrides=None):
         import torch
         self.torch = torch
         if not torch.cuda.is_available():
@@ -109,6 +109,10 @@ class VecQuadrupedEnv(object):
         self.mode = mode
         self.cfg = cfgmod.make_config(num_robot, sim_params=sim, mode=mode, enable_randomizer=enable_randomizer, seed=seed,
                                       num_procs=num_procs, auto_reset=auto_reset, legacy_grid=legacy_grid)
+        for k, v in (config_overrides or {}).items():     # e.g. a shorter episode-length curriculum (WrapperEnv arguments, run.py:54-75)
+            if not hasattr(self.cfg, k):
+                raise ValueError("unknown orr_config field %r" % (k,))
+            setattr(self.cfg, k, v)
         # robots: homogeneous batch, or interleaved heterogeneous batch (BASELINE config 5)
         if mixed_robots:
             self.robot_names = list(mixed_robots)
@@ -231,6 +235,19 @@ class VecQuadrupedEnv(object):
                                          self.done.data_ptr(), self._stream(), int(num_steps), C.byref(ms)), self.L)
         self._env_step_counter += int(num_steps)
         return float(ms.value)
+
+    def replay_reset(self, uniforms):
+        """Parity entry: reset of all robots with the given draws ([N,28] in [0,1)) instead of the Philox stream."""
+        _lib.check(self.L.orr_debug_replay_reset(self.h, uniforms.data_ptr(), self.obs.data_ptr(), self._stream()), self.L)
+        self._env_step_counter = 0
+        return self.obs
+
+    def replay_step(self, actions, traj, eff, fall, tau_out):
+        """Parity entry: one env step with the physics sub-steps replaced by recorded states (include/openroborl_hip.h)."""
+        _lib.check(self.L.orr_debug_replay_step(self.h, actions.data_ptr(), traj.data_ptr(), eff.data_ptr(), fall.data_ptr(), self.obs.data_ptr(),
+                                                self.reward.data_ptr(), self.done.data_ptr(), tau_out.data_ptr(), self._stream()), self.L)
+        self._env_step_counter += 1
+        return self.obs, self.reward, self.done
 
     def debug_physics(self, torques, nsub):
         fall = self.torch.zeros(self.num_robot, dtype=self.torch.uint8, device=self.device)
