@@ -28,7 +28,8 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # ORR_FORCE_DIST=1: build the process group even for one rank (a one-GPU smoke test of the RCCL code path)
+    if (world > 1 or os.environ.get("ORR_FORCE_DIST")) and not dist.is_initialized():
         if backend is None:
             backend = os.environ.get("ORR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -127,7 +128,7 @@ def allgather_episode_stats(returns, lengths, total_timesteps, dropped=0, capaci
     import torch
     import torch.distributed as dist
     buf = pack_episode_stats(returns, lengths, total_timesteps, dropped, capacity, count)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not os.environ.get("ORR_FORCE_DIST")):
         return unpack_episode_stats([buf], capacity)
     if dist.get_backend(group) == "gloo" and buf.is_cuda:   # rehearsal on a one-GPU box: stage through the host
         buf = buf.cpu()

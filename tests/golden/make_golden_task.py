@@ -28,7 +28,7 @@ task's _rand_uniform / cal_reward are wrapped to log the draws and the five rewa
 Note: run.py:57 builds Minitaur(name_robot="minicheetah"), which minitaur.py:93-97 rejects ("wrong robot select"); the
 mini-cheetah robot is constructed here with the name minitaur.py accepts ("mini_cheetah").
 
-Outputs (committed): task_laikago.npz, task_mini_cheetah.npz, task_laikago_testmode.npz
+Outputs (committed): task_laikago.npz, task_mini_cheetah.npz, task_laikago_testmode.npz, task_laikago_spin.npz
 """
 import collections
 import collections.abc
@@ -58,12 +58,12 @@ CLIP = {"laikago": "laikago_pace.txt", "mini_cheetah": "minicheetah_trot.txt"}
 TOES = [3, 7, 11, 15]
 
 
-def build(robot_name, n, randomizer, ep_start, ep_end, curriculum_steps, seed):
+def build(robot_name, n, randomizer, ep_start, ep_end, curriculum_steps, seed, clip=None):
     np.random.seed(seed)
     robots = [minitaur.Minitaur(name_robot=robot_name, robot_index=i, enable_randomizer=randomizer) for i in range(n)]
     for i, r in enumerate(robots):
         r._randomizers[0]._np_random = np.random.RandomState(1000 * seed + i)
-    tasks = [imitation_task.ImitationTask(ref_motion_filenames=[os.path.join(MOTIONS, CLIP[robot_name])],
+    tasks = [imitation_task.ImitationTask(ref_motion_filenames=[os.path.join(MOTIONS, clip or CLIP[robot_name])],
                                           enable_cycle_sync=True, tar_frame_steps=[1, 2, 10, 30],
                                           ref_state_init_prob=0.9, warmup_time=0.25) for _ in range(n)]     # run.py:58-64
     for t in tasks:
@@ -185,8 +185,8 @@ def flip(body, angle):
     return ev
 
 
-def run(robot_name, n, randomizer, ep_start, ep_end, curriculum_steps, seed, total_steps, events):
-    env, robots, tasks = build(robot_name, n, randomizer, ep_start, ep_end, curriculum_steps, seed)
+def run(robot_name, n, randomizer, ep_start, ep_end, curriculum_steps, seed, total_steps, events, clip=None):
+    env, robots, tasks = build(robot_name, n, randomizer, ep_start, ep_end, curriculum_steps, seed, clip)
     fake = env.pybullet_client
     rng = np.random.RandomState(seed + 77)
     init = robots[0]._init_motor_angle
@@ -227,7 +227,7 @@ def run(robot_name, n, randomizer, ep_start, ep_end, curriculum_steps, seed, tot
         k += 1
         if any(done):
             need_reset = True
-    out = {"robot": np.array(robot_name), "num_robot": np.float64(n), "randomizer": np.float64(randomizer),
+    out = {"robot": np.array(robot_name), "clip": np.array((clip or CLIP[robot_name])[:-4]), "num_robot": np.float64(n), "randomizer": np.float64(randomizer),
            "ep_start": np.float64(ep_start), "ep_end": np.float64(ep_end), "curriculum_steps": np.float64(curriculum_steps),
            "marks": np.array([(0.0 if m[0] == "reset" else 1.0, float(m[1])) for m in marks]),
            "joint_of_motor": np.array([(lambda j: j - j // 4)(robots[0]._joint_name_to_id[nm]) for nm in robots[0].name_motor], dtype=np.float64),
@@ -271,7 +271,11 @@ def main():
     # test mode (run.py:66-67,205-206): no randomiser, fixed 2 ms latency, full-length episodes, no curriculum effect
     out = run("laikago", 1, False, 600, 600, 30000000, seed=3, total_steps=45, events={})
     np.savez_compressed(os.path.join(HERE, "task_laikago_testmode.npz"), **out)
-    for f in ("task_laikago.npz", "task_mini_cheetah.npz", "task_laikago_testmode.npz"):
+    # a clip with EnableCycleOffsetRotation (motion_data.py:591-633: the cycle offset rotates from cycle to cycle): 55 steps = 2.4
+    # cycles of the 0.75 s spin clip, so target frames and the reference pose cross several cycle boundaries
+    out = run("laikago", 1, True, 600, 600, 30000000, seed=4, total_steps=55, events={}, clip="laikago_spin.txt")
+    np.savez_compressed(os.path.join(HERE, "task_laikago_spin.npz"), **out)
+    for f in ("task_laikago.npz", "task_mini_cheetah.npz", "task_laikago_testmode.npz", "task_laikago_spin.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
 
 

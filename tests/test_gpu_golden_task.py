@@ -27,7 +27,7 @@ def _replay(name):
     g = np.load(os.path.join(ol.GOLDEN, name))
     robot, n = str(g["robot"]), int(g["num_robot"])
     rnd = bool(g["randomizer"])
-    env = VecQuadrupedEnv(num_robot=n, robot=robot, motion_file=CLIP[robot], mode="train", enable_randomizer=rnd, auto_reset=False,
+    env = VecQuadrupedEnv(num_robot=n, robot=robot, motion_file=str(g["clip"]), mode="train", enable_randomizer=rnd, auto_reset=False,
                           legacy_grid=True, seed=0,
                           config_overrides=dict(ep_len_start=int(g["ep_start"]), ep_len_end=int(g["ep_end"]), curriculum_steps=int(g["curriculum_steps"])))
     dev = env.device
@@ -94,6 +94,6 @@ def _replay(name):
     env.close()
 
 
-@pytest.mark.parametrize("name", ["task_laikago.npz", "task_mini_cheetah.npz", "task_laikago_testmode.npz"])
+@pytest.mark.parametrize("name", ["task_laikago.npz", "task_mini_cheetah.npz", "task_laikago_testmode.npz", "task_laikago_spin.npz"])
 def test_hip_path_reproduces_the_reference_python(name):
     _replay(name)

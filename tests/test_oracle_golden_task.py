@@ -44,7 +44,7 @@ def _setup(name):
     models = [None] * _abi.MAX_ROBOT_TYPES
     t = robots.ROBOT_TYPE_ID[robot]
     models[t] = robots.ROBOTS[robot]()
-    orc = ol.OracleEnv(cfg, models, [motion.MotionClip(CLIP[robot])], n, robot_type=t, clip_id=0)
+    orc = ol.OracleEnv(cfg, models, [motion.MotionClip(str(g["clip"]))], n, robot_type=t, clip_id=0)
     if not bool(g["randomizer"]):
         orc.state[:, orc.lay.sl("LATENCY")] = config.CTRL_LATENCY     # the decimal 0.002 (laikago.py:27), not its float32 rounding
     L = orc.L
@@ -187,3 +187,10 @@ def test_mini_cheetah_train_mode_replay():
 def test_laikago_test_mode_replay():
     seen = _replay("task_laikago_testmode.npz")
     assert seen["wrap"] >= 1 and seen["done_time"] == 0 and seen["oldest"] >= 1, seen
+
+
+def test_laikago_spin_clip_with_rotation_cycling_replay():
+    """laikago_spin has EnableCycleOffsetRotation: the cycle offset itself rotates from cycle to cycle (motion_data.py:591-633);
+    55 steps = 2.4 cycles, so reference pose, cycle sync and the four target frames cross several cycle boundaries."""
+    seen = _replay("task_laikago_spin.npz")
+    assert seen["wrap"] >= 2, seen
