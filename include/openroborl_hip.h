@@ -233,6 +233,12 @@ int32_t orr_reset(orr_handle* h, const uint8_t* mask_dev, float* obs_dev, void* 
 int32_t orr_step(orr_handle* h, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev,
                  void* stream);
 
+/* replaces the rank-local side of MPI allgather((ep_lens, ep_rets)) + allreduce(total_timestep) at a rollout boundary
+ * (agents/ppo_imitation.py:405-423): packs the episode log into the fixed-size float64 payload of ONE all-gather,
+ *   out_dev[6 + 2 * capacity] = [n_listed, total_timesteps, n_dropped, n_episodes, sum_ret, sum_len, ret[capacity], len[capacity]],
+ * and clears the log (one launch, no host sync; n_episodes / sums cover every logged episode, the lists the first `capacity`). */
+int32_t orr_episode_stats(orr_handle* h, double total_timesteps, int32_t capacity, double* out_dev, void* stream);
+
 /* parity / debug entry (not part of the drop-in surface): nsub physics sub-steps with fixed motor torques
  * [N,12] applied as tau_urdf = tau * JOINT_DIRECTIONS; fall_dev [N] receives the fall-proxy flag (may be NULL). */
 int32_t orr_debug_physics(orr_handle* h, const float* torques_dev, uint8_t* fall_dev, int32_t nsub, void* stream);

@@ -33,7 +33,7 @@ EXPORTS = [
     "orr_last_error", "orr_abi_version", "orr_source_hash", "orr_state_stride", "orr_layout_count", "orr_layout_name",
     "orr_layout_offset", "orr_layout_size", "orr_layout_is_int", "orr_sizeof_config", "orr_sizeof_model",
     "orr_create", "orr_destroy", "orr_set_seed", "orr_set_model", "orr_set_motion", "orr_bind", "orr_reset", "orr_step",
-    "orr_time_steps", "orr_debug_physics", "orr_debug_replay_step", "orr_debug_replay_reset",
+    "orr_episode_stats", "orr_time_steps", "orr_debug_physics", "orr_debug_replay_step", "orr_debug_replay_reset",
     "orr_policy_packed_size", "orr_policy_pack", "orr_policy_forward", "orr_gae",
 ]
 
@@ -158,6 +158,8 @@ def load():
     L.orr_debug_replay_step.argtypes = [vp] * 10
     L.orr_debug_replay_reset.restype = C.c_int32
     L.orr_debug_replay_reset.argtypes = [vp, vp, vp, vp]
+    L.orr_episode_stats.restype = C.c_int32
+    L.orr_episode_stats.argtypes = [vp, C.c_double, C.c_int32, vp, vp]
     L.orr_time_steps.restype = C.c_int32
     L.orr_time_steps.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int32, C.POINTER(C.c_float)]
     L.orr_sizeof_config.restype = C.c_int32

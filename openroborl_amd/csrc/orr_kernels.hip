@@ -304,6 +304,43 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
   }
 }
 
+// Rollout boundary (agents/ppo_imitation.py:405-423): pack this rank's episode log into the fixed-size float64 payload of the
+// all-gather -- [n_listed, total_timesteps, n_dropped, n_episodes, sum_ret, sum_len, ret[K], len[K]] -- and clear the log, in
+// ONE launch of one workgroup (the log holds at most a few ten thousand (return, length) pairs).
+__global__ __launch_bounds__(1024) void orr_eplog_pack_kernel(long long* counters, const float* ep_log, int cap_log, double total_timesteps,
+                                                              int K, double* out) {
+  __shared__ double red_r[1024], red_l[1024];
+  const int tid = threadIdx.x;
+  const long long cnt_all = counters[ORR_CNT_EPISODES], dropped = counters[ORR_CNT_EPLOG_DROPPED];
+  const long long cnt = cnt_all < (long long)cap_log ? cnt_all : (long long)cap_log;   // logged (the rest was counted as dropped)
+  const float2* log2 = reinterpret_cast<const float2*>(ep_log);
+  double sr = 0.0, sl = 0.0;
+  for (long long i0 = tid; i0 < cnt; i0 += 4096) {   // four independent loads in flight per thread
+    float2 e[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const long long i = i0 + 1024 * u; e[u] = i < cnt ? log2[i] : make_float2(0.0f, 0.0f); }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const long long i = i0 + 1024 * u;
+      sr += (double)e[u].x; sl += (double)e[u].y;
+      if (i < cnt && i < K) { out[6 + i] = (double)e[u].x; out[6 + K + i] = (double)e[u].y; }
+    }
+  }
+  for (long long i = cnt + tid; i < K; i += 1024) { out[6 + i] = 0.0; out[6 + K + i] = 0.0; }
+  red_r[tid] = sr; red_l[tid] = sl;
+  __syncthreads();
+  for (int w = 512; w > 0; w >>= 1) {
+    if (tid < w) { red_r[tid] += red_r[tid + w]; red_l[tid] += red_l[tid + w]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const long long listed = cnt < (long long)K ? cnt : (long long)K;
+    out[0] = (double)listed; out[1] = total_timesteps; out[2] = (double)(dropped + (cnt - listed)); out[3] = (double)cnt;
+    out[4] = red_r[0]; out[5] = red_l[0];
+    counters[ORR_CNT_EPISODES] = 0; counters[ORR_CNT_EPLOG_DROPPED] = 0;   // every thread read them before the first barrier
+  }
+}
+
 // ================================================================================================
 // C-ABI (include/openroborl_hip.h)
 // ================================================================================================
@@ -530,6 +567,15 @@ int32_t orr_debug_physics(orr_handle* h, const float* torques_dev, uint8_t* fall
   hipLaunchKernelGGL(orr_step_kernel<1>, dim3((h->cfg.num_robots + kRPW - 1) / kRPW), dim3(64), 0, (hipStream_t)stream, make_params(h), torques_dev,
                      nullptr, nullptr, fall_dev, nsub, ReplayArgs{});
   HIPCHK(hipGetLastError(), "orr_debug_physics: launch");
+  return 0;
+}
+
+int32_t orr_episode_stats(orr_handle* h, double total_timesteps, int32_t capacity, double* out_dev, void* stream) {
+  if (!h || !h->counters || !h->ep_log || !out_dev) return fail(-1, "orr_episode_stats: needs a bound episode log and an output buffer");
+  if (capacity < 1) return fail(-1, "orr_episode_stats: capacity must be >= 1");
+  hipLaunchKernelGGL(orr_eplog_pack_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, h->counters, h->ep_log, h->ep_log_cap, total_timesteps,
+                     (int)capacity, out_dev);
+  HIPCHK(hipGetLastError(), "orr_episode_stats: launch");
   return 0;
 }
 

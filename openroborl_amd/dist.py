@@ -125,9 +125,13 @@ class EpisodeStats(tuple):
 
 def allgather_episode_stats(returns, lengths, total_timesteps, dropped=0, capacity=4096, group=None, count=None):
     """The rollout-boundary collective.  Works without a process group (world size 1)."""
+    return allgather_packed(pack_episode_stats(returns, lengths, total_timesteps, dropped, capacity, count), capacity, group)
+
+
+def allgather_packed(buf, capacity, group=None):
+    """all_gather of one packed payload per rank (pack_episode_stats layout) + unpack."""
     import torch
     import torch.distributed as dist
-    buf = pack_episode_stats(returns, lengths, total_timesteps, dropped, capacity, count)
     if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not os.environ.get("ORR_FORCE_DIST")):
         return unpack_episode_stats([buf], capacity)
     if dist.get_backend(group) == "gloo" and buf.is_cuda:   # rehearsal on a one-GPU box: stage through the host
@@ -139,5 +143,7 @@ def allgather_episode_stats(returns, lengths, total_timesteps, dropped=0, capaci
 
 def gather_env_episodes(env, steps_since_last, capacity=4096, group=None):
     """Drain the env's device-side episode log and all-gather it across ranks (no host sync before the collective)."""
+    if hasattr(env, "episode_stats_packed"):      # one HIP launch packs the payload and clears the log (orr_episode_stats)
+        return allgather_packed(env.episode_stats_packed(steps_since_last * env.num_robot, capacity), capacity, group)
     log, count, dropped = env.episode_log_device()
     return allgather_episode_stats(log[:, 0], log[:, 1], steps_since_last * env.num_robot, dropped, capacity, group, count)

@@ -291,6 +291,12 @@ class VecQuadrupedEnv(object):
         self.counters[_abi.CNT_EPISODES:_abi.CNT_EPLOG_DROPPED + 1] = 0
         return log, t.clamp(cnt, max=log.shape[0]), dropped
 
+    def episode_stats_packed(self, total_timesteps, capacity):
+        """The rank's payload of the rollout-boundary all-gather (dist.py layout, float64 [6 + 2 capacity]) in one launch; clears the log."""
+        out = self.torch.empty(6 + 2 * int(capacity), dtype=self.torch.float64, device=self.device)
+        _lib.check(self.L.orr_episode_stats(self.h, float(total_timesteps), int(capacity), out.data_ptr(), self._stream()), self.L)
+        return out
+
     def episode_log(self, with_dropped=False):
         """(returns[K], lengths[K]) of the episodes finished since the last call (+ the number of episodes that did not fit
         the device log when with_dropped); clears the log.  Syncs."""

@@ -103,6 +103,15 @@ def test_episode_log_row_j():
     torch.cuda.synchronize()
     n_eps = int(env.counters[_abi.CNT_EPISODES].item())
     assert n_eps == len(exp_g) and n_eps >= n          # 20-step limit: every robot finishes at least once in 25 steps
+    # the one-launch pack (orr_episode_stats) against the torch restatement of the payload on the same log
+    cnt_dev = torch.clamp(env.counters[_abi.CNT_EPISODES].clone(), max=env.ep_log.shape[0])
+    ref_buf = odist.pack_episode_stats(env.ep_log[:, 0].clone(), env.ep_log[:, 1].clone(), steps * n, env.counters[_abi.CNT_EPLOG_DROPPED].clone(),
+                                       64, count=cnt_dev)
+    state = (env.counters.clone(), env.ep_log.clone())
+    buf = env.episode_stats_packed(steps * n, 64)          # capacity 64 < number of episodes: the list is truncated, the sums are not
+    np.testing.assert_allclose(buf.cpu().numpy(), ref_buf.cpu().numpy(), rtol=1e-12, atol=1e-9)
+    assert int(buf[0]) == 64 and int(buf[3]) == n_eps and int(buf[2]) == n_eps - 64
+    env.counters.copy_(state[0]); env.ep_log.copy_(state[1])       # put the log back for the checks below
     stats = odist.gather_env_episodes(env, steps)       # drains the device log through the rollout-boundary collective path
     rets, lens, ts, dropped = stats
     assert dropped == 0 and ts == steps * n and stats.sums[0] == n_eps and rets.numel() == n_eps
