@@ -193,7 +193,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
   const float step_dt = c.sim_dt * c.action_repeat;
   float tl = t;
   if (lane >= 1 && lane <= 4) tl = t + c.tar_frame_steps[lane - 1] * step_dt;
-  sample_poses(P, S, lane, 5, tl, true);
+  sample_poses(P, S, lane, tl, true);
   {
     // _update_ref_motion (imitation_task.py:734-761) with _sync_ref_origin (:1020-1055)
     const float ph = clip_phase(clip, t);

@@ -51,6 +51,9 @@ struct LegConst {
   float r[3][3], jdir[3], joff[3];  // chain: joint origin in the parent frame, internal angle = jdir * (q - joff)
   float com[3], m, Ic[6];           // own link: COM in the link frame, mass, inertia about the COM (xx yy zz xy xz yz)
   float damp_l, damp_a;             // Bullet base damping coefficients in the lane that owns the base body, 0 elsewhere
+  float jdir_own, joff_own;         // the lane's own joint (part < 3; jdir 0 for part 3): scalars, NOT selects over jdir[] / joff[] --
+                                    // the compiler turns such a select into a dynamically indexed load, which pushes the whole
+                                    // struct out of registers (into LDS via promote-alloca)
 };
 __device__ static void load_leg_const(const Shared& S, int lane, LegConst& K) {
   const int leg = lane & 3, part = (lane >> 2) & 3, own = 3 * leg + (part < 3 ? part : 2);
@@ -72,6 +75,8 @@ __device__ static void load_leg_const(const Shared& S, int lane, LegConst& K) {
 #pragma unroll
   for (int i = 0; i < 6; i++) K.Ic[i] = (real || base) ? S.Ic[body][i] : 0.0f;
   K.m = (real || base) ? S.mass[body] : 0.0f;
+  K.jdir_own = real ? S.m.jdir[own] : 0.0f;
+  K.joff_own = S.m.joff[own];
   K.damp_l = base ? S.s[O(BASE_DAMPING)] : 0.0f;
   K.damp_a = base ? S.s[O(BASE_DAMPING) + 1] : 0.0f;
 }
@@ -189,10 +194,8 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
   float sn0, cs0, sn1, cs1, sn2, cs2;
   {
     const int jo = 3 * leg + (part < 3 ? part : 2);
-    const float jd = part == 0 ? K.jdir[0] : (part == 1 ? K.jdir[1] : (part == 2 ? K.jdir[2] : 0.0f));
-    const float jf = part == 0 ? K.joff[0] : (part == 1 ? K.joff[1] : K.joff[2]);
     float sno, cso;
-    joint_sincos(jd * (S.s[O(Q) + jo] - jf), &sno, &cso);
+    joint_sincos(K.jdir_own * (S.s[O(Q) + jo] - K.joff_own), &sno, &cso);
     const float sA = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sno), 0x114, 0xF, 0xF, true));  // row_shr:4
     const float cA = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(cso), 0x114, 0xF, 0xF, true));
     const float sB = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sno), 0x118, 0xF, 0xF, true));  // row_shr:8
@@ -399,12 +402,6 @@ struct ContactGeom {
   float rr0, rr1, rr2, c00, c01, c02, c10, c11, c12, c20, c21, c22;   // scalars (not arrays): stays in registers for the inline-asm operands
 };
 
-__device__ __forceinline__ float row_dot(const Row& R, const float* Wr) {
-  float a = R.Jb[0] * Wr[0] + R.Jb[1] * Wr[1] + R.Jb[2] * Wr[2] + R.Jb[3] * Wr[3] + R.Jb[4] * Wr[4] + R.Jb[5] * Wr[5];
-  a += R.jl[0] * Wr[6 + 3 * R.leg] + R.jl[1] * Wr[6 + 3 * R.leg + 1] + R.jl[2] * Wr[6 + 3 * R.leg + 2];
-  return a;
-}
-
 // Jacobian, right-hand side (not yet scaled by 1/diag) and bounds of row slot `slot`.  BANK 0: knee-friction and contact slots
 // (0..3, 16..27), BANK 1: joint-limit slots (4..15) -- two instantiations, so that the joint-limit bank carries no contact code
 // and its base Jacobian is the compile-time constant zero.
@@ -504,12 +501,18 @@ __device__ __forceinline__ void row_response(Shared& S, const orr_config& cfg, R
   const LegSolve& QL = S.leg[leg];
   float a0[6], mq[12];
   v2f fb2[3], a02[3];
+  // the row's Jacobian through opaque copies: otherwise the compiler fuses neighbouring fields of the Row struct into vector loads
+  // for the packed operations, which stops it from keeping the struct in registers (the fields went to LDS via promote-alloca)
+  float jl0 = R.jl[0], jl1 = R.jl[1], jl2 = R.jl[2];
+  asm("" : "+v"(jl0), "+v"(jl1), "+v"(jl2));
   {
     const v2f* TL = reinterpret_cast<const v2f*>(&QL.T[0][0]);   // TL[3 k + p] = (T[k][2p], T[k][2p+1])
 #pragma unroll
     for (int p = 0; p < 3; p++) {
-      const v2f jb = {R.Jb[2 * p], R.Jb[2 * p + 1]};
-      fb2[p] = jb - (TL[p] * R.jl[0] + TL[3 + p] * R.jl[1] + TL[6 + p] * R.jl[2]);
+      float jb0 = R.Jb[2 * p], jb1 = R.Jb[2 * p + 1];
+      asm("" : "+v"(jb0), "+v"(jb1));
+      const v2f jb = {jb0, jb1};
+      fb2[p] = jb - (TL[p] * jl0 + TL[3 + p] * jl1 + TL[6 + p] * jl2);
     }
     const v2f* IA = reinterpret_cast<const v2f*>(S.IA0inv);       // IA[3 k + p] = (A0^-1[k][2p], A0^-1[k][2p+1])
 #pragma unroll
@@ -518,9 +521,9 @@ __device__ __forceinline__ void row_response(Shared& S, const orr_config& cfg, R
 #pragma unroll
     for (int p = 0; p < 3; p++) { a0[2 * p] = a02[p].x; a0[2 * p + 1] = a02[p].y; }
   }
-  const float h0 = QL.Hi[0] * R.jl[0] + QL.Hi[3] * R.jl[1] + QL.Hi[4] * R.jl[2];
-  const float h1 = QL.Hi[3] * R.jl[0] + QL.Hi[1] * R.jl[1] + QL.Hi[5] * R.jl[2];
-  const float h2 = QL.Hi[4] * R.jl[0] + QL.Hi[5] * R.jl[1] + QL.Hi[2] * R.jl[2];
+  const float h0 = QL.Hi[0] * jl0 + QL.Hi[3] * jl1 + QL.Hi[4] * jl2;
+  const float h1 = QL.Hi[3] * jl0 + QL.Hi[1] * jl1 + QL.Hi[5] * jl2;
+  const float h2 = QL.Hi[4] * jl0 + QL.Hi[5] * jl1 + QL.Hi[2] * jl2;
   float diag = 0.0f;
 #pragma unroll
   for (int L4 = 0; L4 < 4; L4++) {
@@ -531,7 +534,7 @@ __device__ __forceinline__ void row_response(Shared& S, const orr_config& cfg, R
       const v2f t2 = TK[3 * k] * a02[0] + TK[3 * k + 1] * a02[1] + TK[3 * k + 2] * a02[2];
       mq[3 * L4 + k] = (mine ? (k == 0 ? h0 : (k == 1 ? h1 : h2)) : 0.0f) - (t2.x + t2.y);
     }
-    diag += mine ? (R.jl[0] * mq[3 * L4] + R.jl[1] * mq[3 * L4 + 1] + R.jl[2] * mq[3 * L4 + 2]) : 0.0f;
+    diag += mine ? (jl0 * mq[3 * L4] + jl1 * mq[3 * L4 + 1] + jl2 * mq[3 * L4 + 2]) : 0.0f;
   }
 #pragma unroll
   for (int i = 0; i < 6; i++) diag += R.Jb[i] * a0[i];

@@ -54,7 +54,8 @@ __device__ static void cycle_offset(const DevClip& c, int count, float pos[3], f
 // coalesced row loads (lanes 0..18 read one 19-float frame row), then lanes 0..nt-1 blend serially.
 // Result: S.ph.end.pose[l] = raw (no origin offset) pose; if with_vel, S.vel = raw frame velocity at time of lane 0.
 // Warm-up poses (imitation_task.py:985-1009) are substituted where `warm` and -warmup <= t < 0.
-__device__ static void sample_poses(const KParams& P, Shared& S, int lane, int nt, float t_lane, bool with_vel) {
+__device__ static void sample_poses(const KParams& P, Shared& S, int lane, float t_lane, bool with_vel) {
+  constexpr int nt = 5;   // update time + the four target times (compile-time: the staging arrays below must stay in registers)
   const DevClip& c = P.tab->clip[geti(S, O(CLIP_ID))];
   const bool warm_ep = geti(S, O(WARMUP)) != 0;
   Sample sm = clip_index(c, lane < nt ? t_lane : 0.0f);
@@ -67,12 +68,12 @@ __device__ static void sample_poses(const KParams& P, Shared& S, int lane, int n
     // first (frame row = 19 words: lane i and, for lanes 0..2, word 16 + i), then stage them.
     typedef const float __attribute__((address_space(1))) * gptr;
     const gptr frames = (gptr)c.frames, vels = (gptr)c.vels;
-    constexpr int kMaxE = 10;
+    constexpr int kMaxE = 2 * nt;
     float lo[kMaxE + 1], hi[kMaxE + 1], v0[2], v1[2];
     const int w1 = lane < 3 ? 16 + lane : lane;
 #pragma unroll
     for (int e = 0; e < kMaxE; e++) {
-      const int f = e < 2 * nt ? __float_as_int(S.ph.end.red[e]) : 0;
+      const int f = __float_as_int(S.ph.end.red[e]);
       lo[e] = frames[f * 19 + lane]; hi[e] = frames[f * 19 + w1];
     }
     lo[kMaxE] = frames[lane]; hi[kMaxE] = frames[w1];                       // frame 0 (warm-up heading)
@@ -431,7 +432,7 @@ __device__ static void reset_robot(const KParams& P, float* rec, Shared& S, int 
   float tl = t;
   if (lane >= 1 && lane <= 4) tl = t + c.tar_frame_steps[lane - 1] * step_dt;
   PT(20);
-  sample_poses(P, S, lane, 5, tl, true);
+  sample_poses(P, S, lane, tl, true);
   PT(21);
   if (lane == 0) {
     // origin offset: position first (with identity rotation), then rotation; position is NOT recomputed

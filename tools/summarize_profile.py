@@ -12,7 +12,17 @@ src = os.path.join(root, "gpurun_out", tag)
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 KERNEL = "orr_step_kernel"
-for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True):
+def newest(pattern):
+    """gpurun merges every call's files into the same directory: keep the newest file of each directory"""
+    best = {}
+    for f in glob.glob(pattern, recursive=True):
+        d = os.path.dirname(f)
+        if d not in best or os.path.getmtime(f) > os.path.getmtime(best[d]):
+            best[d] = f
+    return sorted(best.values())
+
+
+for f in newest(os.path.join(src, "trace", "**", "*kernel_stats.csv")):
     rows = list(csv.reader(open(f)))
     with open(os.path.join(dst, name + "_kernel_stats.csv"), "w") as o:
         w = csv.writer(o)
@@ -21,7 +31,7 @@ for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recurs
             r[0] = r[0][:120]
             w.writerow(r)
 summary = {}
-for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+for f in newest(os.path.join(src, "pmc_*", "**", "*counter_collection.csv")):
     rd = csv.DictReader(open(f))
     acc = {}
     for r in rd:
@@ -29,9 +39,10 @@ for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), 
             continue
         c = r["Counter_Name"]
         acc.setdefault(c, []).append(float(r["Counter_Value"]))
-        for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Grid_Size", "Workgroup_Size"):
-            if k in r:
-                summary.setdefault("dispatch", {})[k] = r[k]
+        if "ILi0E" in r.get("Kernel_Name", "") or "<0>" in r.get("Kernel_Name", ""):
+            for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Grid_Size", "Workgroup_Size"):
+                if k in r:
+                    summary.setdefault("dispatch", {})[k] = r[k]
     for c, v in acc.items():
         summary[c] = {"mean_per_launch": sum(v) / len(v), "launches": len(v)}
 if "FETCH_SIZE" in summary and "WRITE_SIZE" in summary:
