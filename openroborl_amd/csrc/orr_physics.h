@@ -572,9 +572,85 @@ __device__ __forceinline__ void static_for(F&& f) {
 // Knee and contact rows are swept unconditionally (a row visited for a robot where it is inactive is a no-op: its
 // bounds, 1/diag, lambda and Delassus column are zero); measured 9 % faster than one scalar branch per leg, which also
 // stopped the scheduler from overlapping consecutive row updates.
+//
+// Without the joint-limit bank (HAS_B false: the common case) the whole sweep loop is ONE hand-scheduled block, because a lone wave
+// per SIMD pays an issue slot for every instruction, wait states included, and "VALU write -> DPP read of that register" needs two
+// of them.  Per bounded row (knee, friction; their bounds are symmetric, -hi .. hi):
+//     m = med3(y, -hi, hi);  y -= Ac[r] lam[r];  <filler>;  y += Ac[r] * m(lane of r)      (v_fmac_f32_dpp: broadcast fused)
+// and lam[r] = m(lane of r) (v_mov_b32_dpp) is deferred by one row, where it is the filler; the loop counter's s_sub / s_cmp fill
+// the two rows that have no deferred broadcast in front of them.  Per contact normal:
+//     t = y - Ac[r] lam[r];  lam[r] = max(y(lane of r), 0)  (v_max_f32_dpp);  t += Ac[r] lam[r];  hi (+)= mun[g] lam[r]
+// (the friction bound hi = hi_c + sum_g mun[g] lam[16+g] is rebuilt from the fresh normal impulses: mun[g] = mu in the friction
+// lanes of toe g, else 0).  67 issue slots per sweep, no idle ones (the compiler's schedule of the generic form below: 110).
+__device__ __forceinline__ void pgs_sweeps_bank_a(int iters, const Row& A, const float (&Ac)[kMaxRows], float (&lam)[kMaxRows]) {
+  static_assert(kRPW == 4, "row_newbcast needs 16 lanes per robot");
+  float y = A.lam + fmaf(-A.w, A.jdi, A.rhs);
+  float hi = fmaf(A.mu_e, A.lam_n, A.hi_c);
+  const float hic = A.hi_c;
+  float mun0 = A.nrm_slot == 16 ? A.mu_e : 0.0f, mun1 = A.nrm_slot == 17 ? A.mu_e : 0.0f;
+  float mun2 = A.nrm_slot == 18 ? A.mu_e : 0.0f, mun3 = A.nrm_slot == 19 ? A.mu_e : 0.0f;
+  float zero = 0.0f, t0, m0, m1;
+  int it = __builtin_amdgcn_readfirstlane(iters);
+  if (it <= 0) return;
+#define ORR_RB(S) " row_newbcast:" #S " row_mask:0xf bank_mask:0xf\n\t"
+#define ORR_ROW(M, R, FILL, S)                                      \
+  "v_med3_f32 %[" #M "], %[y], -%[hi], %[hi]\n\t"                   \
+  "v_fma_f32 %[y], -%[a" #R "], %[l" #R "], %[y]\n\t"               \
+  FILL                                                              \
+  "v_fmac_f32_dpp %[y], %[" #M "], %[a" #R "]" ORR_RB(S)
+#define ORR_LAM(R, M, S) "v_mov_b32_dpp %[l" #R "], %[" #M "]" ORR_RB(S)
+#define ORR_NRM(TO, FROM, R, S, HI)                                 \
+  "v_fma_f32 %[" #TO "], -%[a" #R "], %[l" #R "], %[" #FROM "]\n\t" \
+  HI                                                                \
+  "v_max_f32_dpp %[l" #R "], %[" #FROM "], %[zero]" ORR_RB(S)       \
+  "v_fmac_f32 %[" #TO "], %[a" #R "], %[l" #R "]\n\t"
+  asm("v_mov_b32 %[zero], 0\n"
+      "1:\n\t"
+      ORR_ROW(m0, 0, "s_sub_u32 %[it], %[it], 1\n\t", 0)
+      ORR_ROW(m1, 1, ORR_LAM(0, m0, 0), 1)
+      ORR_ROW(m0, 2, ORR_LAM(1, m1, 1), 2)
+      ORR_ROW(m1, 3, ORR_LAM(2, m0, 2), 3)
+      ORR_NRM(t0, y, 16, 4, ORR_LAM(3, m1, 3))
+      ORR_NRM(y, t0, 17, 5, "v_fma_f32 %[hi], %[mun0], %[l16], %[hic]\n\t")
+      ORR_NRM(t0, y, 18, 6, "v_fmac_f32 %[hi], %[mun1], %[l17]\n\t")
+      ORR_NRM(y, t0, 19, 7, "v_fmac_f32 %[hi], %[mun2], %[l18]\n\t")
+      "v_fmac_f32 %[hi], %[mun3], %[l19]\n\t"
+      ORR_ROW(m0, 20, "s_cmp_eq_u32 %[it], 0\n\t", 8)
+      ORR_ROW(m1, 21, ORR_LAM(20, m0, 8), 9)
+      ORR_ROW(m0, 22, ORR_LAM(21, m1, 9), 10)
+      ORR_ROW(m1, 23, ORR_LAM(22, m0, 10), 11)
+      ORR_ROW(m0, 24, ORR_LAM(23, m1, 11), 12)
+      ORR_ROW(m1, 25, ORR_LAM(24, m0, 12), 13)
+      ORR_ROW(m0, 26, ORR_LAM(25, m1, 13), 14)
+      ORR_ROW(m1, 27, ORR_LAM(26, m0, 14), 15)
+      ORR_LAM(27, m1, 15)
+      "s_cbranch_scc0 1b"
+      : [y] "+v"(y), [hi] "+v"(hi), [it] "+s"(it), [zero] "=&v"(zero), [t0] "=&v"(t0), [m0] "=&v"(m0), [m1] "=&v"(m1),
+        [l0] "+v"(lam[0]), [l1] "+v"(lam[1]), [l2] "+v"(lam[2]), [l3] "+v"(lam[3]),
+        [l16] "+v"(lam[16]), [l17] "+v"(lam[17]), [l18] "+v"(lam[18]), [l19] "+v"(lam[19]),
+        [l20] "+v"(lam[20]), [l21] "+v"(lam[21]), [l22] "+v"(lam[22]), [l23] "+v"(lam[23]),
+        [l24] "+v"(lam[24]), [l25] "+v"(lam[25]), [l26] "+v"(lam[26]), [l27] "+v"(lam[27])
+      : [hic] "v"(hic), [mun0] "v"(mun0), [mun1] "v"(mun1), [mun2] "v"(mun2), [mun3] "v"(mun3),
+        [a0] "v"(Ac[0]), [a1] "v"(Ac[1]), [a2] "v"(Ac[2]), [a3] "v"(Ac[3]),
+        [a16] "v"(Ac[16]), [a17] "v"(Ac[17]), [a18] "v"(Ac[18]), [a19] "v"(Ac[19]),
+        [a20] "v"(Ac[20]), [a21] "v"(Ac[21]), [a22] "v"(Ac[22]), [a23] "v"(Ac[23]),
+        [a24] "v"(Ac[24]), [a25] "v"(Ac[25]), [a26] "v"(Ac[26]), [a27] "v"(Ac[27])
+      : "scc");
+#undef ORR_RB
+#undef ORR_ROW
+#undef ORR_LAM
+#undef ORR_NRM
+}
+
 template <bool HAS_B>
 __device__ __forceinline__ void pgs_sweeps(int iters, unsigned int mask, int lane, int sub, Row& A, Row& B,
                                            const float (&AcA)[kMaxRows], const float (&AcB)[kMaxRows], float (&lam)[kMaxRows]) {
+#ifndef ORR_GENERIC_PGS
+  if constexpr (!HAS_B) {
+    pgs_sweeps_bank_a(iters, A, AcA, lam);
+    return;
+  }
+#endif
   float yA = A.lam + fmaf(-A.w, A.jdi, A.rhs), yB = B.lam + fmaf(-B.w, B.jdi, B.rhs);
   float zero;
   asm("v_mov_b32 %0, 0" : "=v"(zero));   // a VGPR operand for the DPP max (opaque, so that it stays in a register)
