@@ -148,14 +148,16 @@ __device__ __forceinline__ void ring_push_and_ctrl_obs(float* rec, Shared& S, in
   // word 16 + lane (lanes 0..3): rate 16..18, pad 19
   const float va = lane < 12 ? mang : (lane == 12 ? rel[0] : (lane == 13 ? rel[1] : (lane == 14 ? rel[2] : rel[3])));
   const float vb = lane == 0 ? rate[0] : (lane == 1 ? rate[1] : (lane == 2 ? rate[2] : 0.0f));
-  float* dst = rec + O(RING) + C.head * ORR_RING_ENTRY;
-  if (valid) {
-    dst[lane] = va;
-    if (lane < 4) dst[16 + lane] = vb;
-  }
   const float a0 = F.new0 ? va : F.e0[0], a1 = F.new1 ? va : F.e1[0];
   const float b0 = F.new0 ? vb : F.e0[1], b1 = F.new1 ? vb : F.e1[1];
   S.co[lane] = F.same ? a0 : (1.0f - F.al) * a0 + F.al * a1;
   if (lane < 3) S.co[16 + lane] = F.same ? b0 : (1.0f - F.al) * b0 + F.al * b1;
   WSYNC();
+  // the push is stored AFTER the prefetched entries were consumed: loads and stores share one in-order counter (vmcnt) on this
+  // target, so a wait for the (long finished) prefetch behind a fresh store would sit out the store's whole round trip
+  float* dst = rec + O(RING) + C.head * ORR_RING_ENTRY;
+  if (valid) {
+    dst[lane] = va;
+    if (lane < 4) dst[16 + lane] = vb;
+  }
 }
