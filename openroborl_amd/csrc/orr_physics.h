@@ -642,14 +642,91 @@ __device__ __forceinline__ void pgs_sweeps_bank_a(int iters, const Row& A, const
 #undef ORR_NRM
 }
 
+// The same with the joint-limit bank: every row update also moves yB (bank B's unclamped values), and the joint-limit rows
+// (unilateral, bank B) are skipped by a scalar bit test unless some robot of the wave has that limit active.
+// 6 issue slots per knee / contact row, 2 + 5 per joint-limit row (2 if skipped).
+__device__ __forceinline__ void pgs_sweeps_bank_ab(int iters, unsigned int mask, const Row& A, const Row& B, const float (&Aa)[kMaxRows],
+                                                   const float (&Ab)[kMaxRows], float (&lam)[kMaxRows]) {
+  static_assert(kRPW == 4, "row_newbcast needs 16 lanes per robot");
+  float ya = A.lam + fmaf(-A.w, A.jdi, A.rhs), yb = B.lam + fmaf(-B.w, B.jdi, B.rhs);
+  float hi = fmaf(A.mu_e, A.lam_n, A.hi_c);
+  const float hic = A.hi_c;
+  float mun0 = A.nrm_slot == 16 ? A.mu_e : 0.0f, mun1 = A.nrm_slot == 17 ? A.mu_e : 0.0f;
+  float mun2 = A.nrm_slot == 18 ? A.mu_e : 0.0f, mun3 = A.nrm_slot == 19 ? A.mu_e : 0.0f;
+  float zero = 0.0f, t0, m;
+  int it = __builtin_amdgcn_readfirstlane(iters);
+  const unsigned int msk = __builtin_amdgcn_readfirstlane(mask);
+  if (it <= 0) return;
+#define ORR_RB(S) " row_newbcast:" #S " row_mask:0xf bank_mask:0xf\n\t"
+#define ORR_ROW(R, S)                                               \
+  "v_med3_f32 %[m], %[ya], -%[hi], %[hi]\n\t"                       \
+  "v_fma_f32 %[ya], -%[a" #R "], %[l" #R "], %[ya]\n\t"             \
+  "v_fma_f32 %[yb], -%[b" #R "], %[l" #R "], %[yb]\n\t"             \
+  "v_fmac_f32_dpp %[ya], %[m], %[a" #R "]" ORR_RB(S)                \
+  "v_fmac_f32_dpp %[yb], %[m], %[b" #R "]" ORR_RB(S)                \
+  "v_mov_b32_dpp %[l" #R "], %[m]" ORR_RB(S)
+#define ORR_NRM(R, S, HI)                                           \
+  "v_fma_f32 %[t0], -%[a" #R "], %[l" #R "], %[ya]\n\t"             \
+  "v_fma_f32 %[yb], -%[b" #R "], %[l" #R "], %[yb]\n\t"             \
+  "v_max_f32_dpp %[l" #R "], %[ya], %[zero]" ORR_RB(S)              \
+  "v_fma_f32 %[ya], %[a" #R "], %[l" #R "], %[t0]\n\t"              \
+  "v_fmac_f32 %[yb], %[b" #R "], %[l" #R "]\n\t"                    \
+  HI
+#define ORR_LIM(R)                                                  \
+  "s_bitcmp1_b32 %[msk], " #R "\n\t"                                \
+  "s_cbranch_scc0 2f\n\t"                                           \
+  "v_fma_f32 %[ya], -%[a" #R "], %[l" #R "], %[ya]\n\t"             \
+  "v_fma_f32 %[t0], -%[b" #R "], %[l" #R "], %[yb]\n\t"             \
+  "v_max_f32_dpp %[l" #R "], %[yb], %[zero]" ORR_RB(R)              \
+  "v_fma_f32 %[yb], %[b" #R "], %[l" #R "], %[t0]\n\t"              \
+  "v_fmac_f32 %[ya], %[a" #R "], %[l" #R "]\n"                       \
+  "2:\n\t"
+  asm("v_mov_b32 %[zero], 0\n"
+      "1:\n\t"
+      ORR_ROW(0, 0) ORR_ROW(1, 1) ORR_ROW(2, 2) ORR_ROW(3, 3)
+      ORR_LIM(4) ORR_LIM(5) ORR_LIM(6) ORR_LIM(7) ORR_LIM(8) ORR_LIM(9)
+      ORR_LIM(10) ORR_LIM(11) ORR_LIM(12) ORR_LIM(13) ORR_LIM(14) ORR_LIM(15)
+      ORR_NRM(16, 4, "v_fma_f32 %[hi], %[mun0], %[l16], %[hic]\n\t")
+      ORR_NRM(17, 5, "v_fmac_f32 %[hi], %[mun1], %[l17]\n\t")
+      ORR_NRM(18, 6, "v_fmac_f32 %[hi], %[mun2], %[l18]\n\t")
+      ORR_NRM(19, 7, "v_fmac_f32 %[hi], %[mun3], %[l19]\n\t")
+      ORR_ROW(20, 8) ORR_ROW(21, 9) ORR_ROW(22, 10) ORR_ROW(23, 11)
+      ORR_ROW(24, 12) ORR_ROW(25, 13) ORR_ROW(26, 14) ORR_ROW(27, 15)
+      "s_sub_u32 %[it], %[it], 1\n\t"
+      "s_cmp_lg_u32 %[it], 0\n\t"
+      "s_cbranch_scc1 1b"
+      : [ya] "+v"(ya), [yb] "+v"(yb), [hi] "+v"(hi), [it] "+s"(it), [zero] "=&v"(zero), [t0] "=&v"(t0), [m] "=&v"(m),
+        [l0] "+v"(lam[0]), [l1] "+v"(lam[1]), [l2] "+v"(lam[2]), [l3] "+v"(lam[3]), [l4] "+v"(lam[4]), [l5] "+v"(lam[5]),
+        [l6] "+v"(lam[6]), [l7] "+v"(lam[7]), [l8] "+v"(lam[8]), [l9] "+v"(lam[9]), [l10] "+v"(lam[10]), [l11] "+v"(lam[11]),
+        [l12] "+v"(lam[12]), [l13] "+v"(lam[13]), [l14] "+v"(lam[14]), [l15] "+v"(lam[15]),
+        [l16] "+v"(lam[16]), [l17] "+v"(lam[17]), [l18] "+v"(lam[18]), [l19] "+v"(lam[19]),
+        [l20] "+v"(lam[20]), [l21] "+v"(lam[21]), [l22] "+v"(lam[22]), [l23] "+v"(lam[23]),
+        [l24] "+v"(lam[24]), [l25] "+v"(lam[25]), [l26] "+v"(lam[26]), [l27] "+v"(lam[27])
+      : [hic] "v"(hic), [mun0] "v"(mun0), [mun1] "v"(mun1), [mun2] "v"(mun2), [mun3] "v"(mun3), [msk] "s"(msk),
+        [a0] "v"(Aa[0]), [a1] "v"(Aa[1]), [a2] "v"(Aa[2]), [a3] "v"(Aa[3]), [a4] "v"(Aa[4]), [a5] "v"(Aa[5]), [a6] "v"(Aa[6]),
+        [a7] "v"(Aa[7]), [a8] "v"(Aa[8]), [a9] "v"(Aa[9]), [a10] "v"(Aa[10]), [a11] "v"(Aa[11]), [a12] "v"(Aa[12]), [a13] "v"(Aa[13]),
+        [a14] "v"(Aa[14]), [a15] "v"(Aa[15]), [a16] "v"(Aa[16]), [a17] "v"(Aa[17]), [a18] "v"(Aa[18]), [a19] "v"(Aa[19]),
+        [a20] "v"(Aa[20]), [a21] "v"(Aa[21]), [a22] "v"(Aa[22]), [a23] "v"(Aa[23]), [a24] "v"(Aa[24]), [a25] "v"(Aa[25]),
+        [a26] "v"(Aa[26]), [a27] "v"(Aa[27]),
+        [b0] "v"(Ab[0]), [b1] "v"(Ab[1]), [b2] "v"(Ab[2]), [b3] "v"(Ab[3]), [b4] "v"(Ab[4]), [b5] "v"(Ab[5]), [b6] "v"(Ab[6]),
+        [b7] "v"(Ab[7]), [b8] "v"(Ab[8]), [b9] "v"(Ab[9]), [b10] "v"(Ab[10]), [b11] "v"(Ab[11]), [b12] "v"(Ab[12]), [b13] "v"(Ab[13]),
+        [b14] "v"(Ab[14]), [b15] "v"(Ab[15]), [b16] "v"(Ab[16]), [b17] "v"(Ab[17]), [b18] "v"(Ab[18]), [b19] "v"(Ab[19]),
+        [b20] "v"(Ab[20]), [b21] "v"(Ab[21]), [b22] "v"(Ab[22]), [b23] "v"(Ab[23]), [b24] "v"(Ab[24]), [b25] "v"(Ab[25]),
+        [b26] "v"(Ab[26]), [b27] "v"(Ab[27])
+      : "scc");
+#undef ORR_RB
+#undef ORR_ROW
+#undef ORR_NRM
+#undef ORR_LIM
+}
+
 template <bool HAS_B>
 __device__ __forceinline__ void pgs_sweeps(int iters, unsigned int mask, int lane, int sub, Row& A, Row& B,
                                            const float (&AcA)[kMaxRows], const float (&AcB)[kMaxRows], float (&lam)[kMaxRows]) {
 #ifndef ORR_GENERIC_PGS
-  if constexpr (!HAS_B) {
-    pgs_sweeps_bank_a(iters, A, AcA, lam);
-    return;
-  }
+  if constexpr (!HAS_B) pgs_sweeps_bank_a(iters, A, AcA, lam);
+  else pgs_sweeps_bank_ab(iters, mask, A, B, AcA, AcB, lam);
+  return;
 #endif
   float yA = A.lam + fmaf(-A.w, A.jdi, A.rhs), yB = B.lam + fmaf(-B.w, B.jdi, B.rhs);
   float zero;
