@@ -146,6 +146,7 @@ struct alignas(16) LegSolve {   // per leg: column k of T written by the leg's p
   float Hi[6];      // H^-1 of the leg's 3x3 joint-space inertia (00 11 22 01 02 12)
 };
 
+constexpr int kPhaseSlots = 40;   // phase timers of the -DORR_PHASE_TIMERS build (tools/phase_cycles.py)
 constexpr int kWStride = 20;   // 18 DOFs, padded to a multiple of 16 bytes
 struct alignas(16) DynamicsBuf {           // leg dynamics -> row setup hand-over (dead once the impulse responses are written)
   LinkCache lc[12];
@@ -182,7 +183,7 @@ struct alignas(16) Shared {
   alignas(16) float co[20];    // control (latency-delayed) observation
   alignas(16) PhaseBuf ph;
 #ifdef ORR_PHASE_TIMERS
-  long long pt_acc[24], pt_last;  // development aid, see PT() in orr_kernels.hip
+  long long pt_acc[kPhaseSlots], pt_last, pt_t0, pt_r0;  // development aid, see PT() in orr_kernels.hip
 #endif
 };
 

@@ -19,14 +19,17 @@
 // Development aid (tools/phase_cycles.py): -DORR_PHASE_TIMERS makes lane 0 of one wave accumulate shader-clock cycles
 // per phase (Shared::pt_acc) and add them to g_phase_cycles at the end of the launch.
 #ifdef ORR_PHASE_TIMERS
-__device__ long long g_phase_cycles[24];   // 0..15: phases of the step, 16..23: stages of reset_robot
-#define PT_INIT() do { if (threadIdx.x == 0) { for (int i_ = 0; i_ < 24; i_++) S.pt_acc[i_] = 0; S.pt_last = clock64(); } } while (0)
+__device__ long long g_phase_cycles[orr::kPhaseSlots];   // 0..15: phases of the step, 16..23: stages of reset_robot, 24..: finer marks inside the reset
+__device__ long long g_wave_timeline[4 * 2048];   // per wave of the last launch: realtime start, realtime end, shader cycles, reset flag
+#define PT_INIT() do { if (threadIdx.x == 0) { S.pt_t0 = clock64(); S.pt_r0 = wall_clock64(); } if (threadIdx.x == 0) { for (int i_ = 0; i_ < orr::kPhaseSlots; i_++) S.pt_acc[i_] = 0; S.pt_last = clock64(); } } while (0)
 #define PT(k) do { if (threadIdx.x == 0) { const long long t_ = clock64(); S.pt_acc[k] += t_ - S.pt_last; S.pt_last = clock64(); } } while (0)
-#define PT_FLUSH() do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) for (int i_ = 0; i_ < 24; i_++) atomicAdd((unsigned long long*)&g_phase_cycles[i_], (unsigned long long)S.pt_acc[i_]); } while (0)
+#define PT_TIMELINE(flag) do { if (threadIdx.x == 0 && blockIdx.x < 2048) { g_wave_timeline[4 * blockIdx.x] = S.pt_r0; g_wave_timeline[4 * blockIdx.x + 1] = wall_clock64(); g_wave_timeline[4 * blockIdx.x + 2] = clock64() - S.pt_t0; g_wave_timeline[4 * blockIdx.x + 3] = (flag); } } while (0)
+#define PT_FLUSH() do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) for (int i_ = 0; i_ < orr::kPhaseSlots; i_++) atomicAdd((unsigned long long*)&g_phase_cycles[i_], (unsigned long long)S.pt_acc[i_]); } while (0)
 #else
 #define PT_INIT()
 #define PT(k)
 #define PT_FLUSH()
+#define PT_TIMELINE(flag)
 #endif
 
 using namespace orr;
@@ -267,6 +270,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
     }
     WSYNC();
     if (c.flags & ORR_FLAG_AUTO_RESET) {
+      PT(31);
       reset_robot(P, rec, S, lane, valid, total_snapshot, obs);
     }
     if (logs && P.ep_log) {
@@ -302,6 +306,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
       atomicExch((unsigned long long*)&P.counters[ORR_CNT_TICKET], 0ull);
     }
   }
+  PT_TIMELINE((long long)fin_mask);
 }
 
 // Rollout boundary (agents/ppo_imitation.py:405-423): pack this rank's episode log into the fixed-size float64 payload of the
@@ -618,13 +623,20 @@ int32_t orr_time_steps(orr_handle* h, const float* actions_dev, float* obs_dev, 
 
 #ifdef ORR_PHASE_TIMERS
 // development aid: read (and optionally clear) the per-phase cycle totals of the instrumented wave
-int orr_debug_phase_cycles(long long* out24, int reset) {
+int orr_debug_phase_cycles(long long* out40, int reset) {
   HIPCHK(hipDeviceSynchronize(), "orr_debug_phase_cycles: sync");
-  HIPCHK(hipMemcpyFromSymbol(out24, HIP_SYMBOL(g_phase_cycles), 24 * sizeof(long long)), "orr_debug_phase_cycles: read");
+  HIPCHK(hipMemcpyFromSymbol(out40, HIP_SYMBOL(g_phase_cycles), kPhaseSlots * sizeof(long long)), "orr_debug_phase_cycles: read");
   if (reset) {
-    long long z[24] = {0};
+    long long z[kPhaseSlots] = {0};
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z)), "orr_debug_phase_cycles: clear");
   }
+  return 0;
+}
+// development aid: per-wave timeline of the last step launch (4 words per wave: realtime start / end in 100 MHz ticks, shader cycles,
+// mask of the robots that finished an episode)
+int orr_debug_wave_timeline(long long* out, int waves) {
+  HIPCHK(hipDeviceSynchronize(), "orr_debug_wave_timeline: sync");
+  HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_timeline), (size_t)waves * 4 * sizeof(long long)), "orr_debug_wave_timeline: read");
   return 0;
 }
 #endif

@@ -54,13 +54,14 @@ __device__ static void cycle_offset(const DevClip& c, int count, float pos[3], f
 // coalesced row loads (lanes 0..18 read one 19-float frame row), then lanes 0..nt-1 blend serially.
 // Result: S.ph.end.pose[l] = raw (no origin offset) pose; if with_vel, S.vel = raw frame velocity at time of lane 0.
 // Warm-up poses (imitation_task.py:985-1009) are substituted where `warm` and -warmup <= t < 0.
-__device__ static void sample_poses(const KParams& P, Shared& S, int lane, float t_lane, bool with_vel) {
+__device__ static void sample_poses(const KParams& P, Shared& S, int lane, float t_lane, bool with_vel, int pt_slot = 32) {
   constexpr int nt = 5;   // update time + the four target times (compile-time: the staging arrays below must stay in registers)
   const DevClip& c = P.tab->clip[geti(S, O(CLIP_ID))];
   const bool warm_ep = geti(S, O(WARMUP)) != 0;
   Sample sm = clip_index(c, lane < nt ? t_lane : 0.0f);
   if (lane < nt) { S.ph.end.red[2 * lane] = __int_as_float(sm.f0); S.ph.end.red[2 * lane + 1] = __int_as_float(sm.f1); }
   WSYNC();
+  PT(pt_slot);
   {
     // The clip pointers come out of a device table, i.e. as generic pointers: loads through them would be FLAT instructions,
     // which also count on the LDS counter, so every LDS access in between would wait for the previous frame to arrive (13
@@ -94,6 +95,7 @@ __device__ static void sample_poses(const KParams& P, Shared& S, int lane, float
     }
   }
   WSYNC();
+  PT(pt_slot + 1);
   if (lane < nt) {
     const bool warm_pose = warm_ep && t_lane >= -P.cfg.warmup_time && t_lane < 0.0f;
     float out[19];
@@ -382,6 +384,7 @@ __device__ static void reset_robot(const KParams& P, float* rec, Shared& S, int 
   WSYNC();
   for (int i = lane; i < 19; i += kLanes) S.co[i] = e1[i];   // one entry in the ring: _get_delay_obs returns it (minitaur.py:345-346)
   WSYNC();
+  PT(29);
   sensors_push(S, lane, true);
   const float e1_keep[2] = {e1[lane], e1[lane < 3 ? 16 + lane : lane]};   // ring entry #1: words lane and (lanes 0..2) 16 + lane
   PT(18);
@@ -398,6 +401,7 @@ __device__ static void reset_robot(const KParams& P, float* rec, Shared& S, int 
     draws[4 * lane] = u4[0]; draws[4 * lane + 1] = u4[1]; draws[4 * lane + 2] = u4[2]; draws[4 * lane + 3] = u4[3];
   }
   WSYNC();
+  PT(24);
   if (c.flags & ORR_FLAG_RANDOMIZER) {
     for (int i = lane; i < 26; i += kLanes) {
       const float u = draws[i];
@@ -409,6 +413,7 @@ __device__ static void reset_robot(const KParams& P, float* rec, Shared& S, int 
       else S.s[O(STRENGTH) + i - 14] = 0.8f + u * 0.4f;
     }
     WSYNC();
+    PT(25);
     refresh_mass(P.tab->model[geti(S, O(ROBOT_TYPE))], S, lane);
     WSYNC();
   }
@@ -432,7 +437,7 @@ __device__ static void reset_robot(const KParams& P, float* rec, Shared& S, int 
   float tl = t;
   if (lane >= 1 && lane <= 4) tl = t + c.tar_frame_steps[lane - 1] * step_dt;
   PT(20);
-  sample_poses(P, S, lane, tl, true);
+  sample_poses(P, S, lane, tl, true, 26);
   PT(21);
   if (lane == 0) {
     // origin offset: position first (with identity rotation), then rotation; position is NOT recomputed
@@ -481,4 +486,5 @@ __device__ static void reset_robot(const KParams& P, float* rec, Shared& S, int 
   for (int i = lane; i < 36; i += kLanes) { obs[12 + i] = S.s[O(LASTACT_HIST) + i]; obs[48 + i] = S.s[O(MOTORANG_HIST) + i]; }
   PT(23);
   target_obs(P, rec, S, lane, obs + ORR_PROPRIO_DIM);
+  PT(30);
 }

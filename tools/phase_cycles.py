@@ -29,7 +29,7 @@ g = torch.Generator().manual_seed(0)
 act = (torch.randn(4096, 12, generator=g) * 0.1).to(env.device)
 L = _lib.load()
 L.orr_debug_phase_cycles.argtypes = [C.POINTER(C.c_longlong), C.c_int]
-buf = (C.c_longlong * 24)()
+buf = (C.c_longlong * 40)()
 for _ in range(50):
     env.step(act)
 L.orr_debug_phase_cycles(buf, 1)
@@ -51,3 +51,9 @@ RESET = ["state defaults", "ring entry #1", "ctrl obs + sensor fill", "randomise
 print("stages of reset_robot, cycles per reset of robot 0 of the wave (the last stage, target observation, is timed inside 'episode end/reset'):")
 for n, v in zip(RESET, buf[16:24]):
     print("  %-28s %9.0f" % (n, v / max(int(dones[0]), 1)))
+FINE = {24: "  philox blocks (inside randomiser draws, up to here)", 25: "  scatter of the draws", 26: "  clip_index (inside clip sampling)",
+        27: "  frame loads + staging", 29: "  ctrl obs copy (inside ctrl obs + sensor fill)", 30: "target observation",
+        31: "episode log + entry (before reset_robot)"}
+print("finer marks (cycles per reset of robot 0; a mark closes the interval since the previous mark of any kind):")
+for k in sorted(FINE):
+    print("  %-60s %9.0f" % (FINE[k], buf[k] / max(int(dones[0]), 1)))

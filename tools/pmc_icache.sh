@@ -1,0 +1,25 @@
+#!/bin/bash
+# Run on the GPU box (through gpurun): instruction-fetch counters of the step kernel (development aid).
+# usage: tools/pmc_icache.sh <tag>      outputs under gpurun_out/<tag>/
+set -u
+TAG=${1:-icache}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+export ORR_BENCH_WARMUP_FLOOR=50
+BENCH="python3 $ROOT/bench.py --config laikago4096 --steps 40 --warmup 10 --no-cpu-baseline"
+for P in "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE" "SQ_IFETCH SQ_IFETCH_LEVEL SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" \
+         "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY"; do
+  N=$(echo $P | tr ' ' '_' | cut -c1-40)
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/pmc_$N -- $BENCH > $OUT/pmc_$N.log 2>&1 || echo "pass $N failed"
+done
+python3 - <<PY
+import csv, glob, collections
+for f in sorted(glob.glob("$OUT/pmc_*/**/*counter_collection.csv", recursive=True)):
+    acc = collections.defaultdict(float); n = collections.Counter()
+    for r in csv.DictReader(open(f)):
+        if "orr_step_kernel" in r["Kernel_Name"]:
+            acc[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
+    for k in acc: print("%-32s %16.0f per launch" % (k, acc[k] / max(n[k], 1)))
+PY
