@@ -517,9 +517,12 @@ __device__ __forceinline__ float q_norm_angle(const float q[4]) {
   return ang;
 }
 __device__ __forceinline__ float map_pi(float a) {  // pose3d.MapToMinusPiToPi (pose3d.py:358-374)
-  float m = fmodf(a, 2.0f * ORR_PI_F);
-  if (m >= ORR_PI_F) m -= 2.0f * ORR_PI_F;
-  else if (m < -ORR_PI_F) m += 2.0f * ORR_PI_F;
+  // fmod(a, 2 pi) without libm's loop and branches (a taken or skipped branch costs a lone wave 3-6 multiply-adds): whole turns
+  // k = trunc(a / 2 pi), removed with a two-part 2 pi; exact (k = 0) for |a| < 2 pi, i.e. for every joint angle
+  const float k = truncf(a * 0.15915494309189535f);
+  float m = fmaf(-k, 6.2831854820251465f, a);       // 2 pi rounded to float ...
+  m = fmaf(-k, -1.7484555e-07f, m);                 // ... and the rest of it
+  m = m >= ORR_PI_F ? m - 2.0f * ORR_PI_F : (m < -ORR_PI_F ? m + 2.0f * ORR_PI_F : m);
   return m;
 }
 __device__ __forceinline__ void q_to_mat(const float qin[4], float R[9]) {

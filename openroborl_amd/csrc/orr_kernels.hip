@@ -404,6 +404,10 @@ int32_t orr_create(const orr_config* cfg, orr_handle** out) {
   if (cfg->abi_version != ORR_ABI_VERSION) return fail(-1, "orr_create: ABI version mismatch");
   if (cfg->num_robots < 1) return fail(-1, "orr_create: num_robots must be >= 1");
   if (cfg->action_repeat < 1 || cfg->solver_iters < 1) return fail(-1, "orr_create: action_repeat / solver_iters must be >= 1");
+  // the quaternion update uses series for sin / cos of half the rotation of one sub-step (exact to float precision below 0.2 rad):
+  // |w| <= sqrt(3) max_coord_velocity after the coordinate-velocity clamp
+  if (!(cfg->max_coord_velocity > 0.0f) || !(cfg->sim_dt > 0.0f) || 0.5f * 1.7320508f * cfg->max_coord_velocity * cfg->sim_dt >= 0.2f)
+    return fail(-1, "orr_create: max_coord_velocity * sim_dt too large (the base may turn at most 0.4 rad per sub-step)");
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev < 1) return fail(-3, "orr_create: no HIP device available (this library has no CPU fallback)", e);

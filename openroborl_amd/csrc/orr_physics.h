@@ -604,27 +604,43 @@ __device__ __forceinline__ void pgs_sweeps_bank_a(int iters, const Row& A, const
   HI                                                                \
   "v_max_f32_dpp %[l" #R "], %[" #FROM "], %[zero]" ORR_RB(S)       \
   "v_fmac_f32 %[" #TO "], %[a" #R "], %[l" #R "]\n\t"
-  asm("v_mov_b32 %[zero], 0\n"
+  // one sweep; F0 / F20: fillers of rows 0 and 20 (the rows without a deferred broadcast of this sweep in front of them), TAIL: the
+  // broadcast of row 27's impulse, or nothing when the next sweep's row 0 takes it as its filler
+#define ORR_SWEEP(F0, F20, TAIL)                                    \
+      ORR_ROW(m0, 0, F0, 0)                                         \
+      ORR_ROW(m1, 1, ORR_LAM(0, m0, 0), 1)                          \
+      ORR_ROW(m0, 2, ORR_LAM(1, m1, 1), 2)                          \
+      ORR_ROW(m1, 3, ORR_LAM(2, m0, 2), 3)                          \
+      ORR_NRM(t0, y, 16, 4, ORR_LAM(3, m1, 3))                      \
+      ORR_NRM(y, t0, 17, 5, "v_fma_f32 %[hi], %[mun0], %[l16], %[hic]\n\t") \
+      ORR_NRM(t0, y, 18, 6, "v_fmac_f32 %[hi], %[mun1], %[l17]\n\t") \
+      ORR_NRM(y, t0, 19, 7, "v_fmac_f32 %[hi], %[mun2], %[l18]\n\t") \
+      "v_fmac_f32 %[hi], %[mun3], %[l19]\n\t"                      \
+      ORR_ROW(m0, 20, F20, 8)                                       \
+      ORR_ROW(m1, 21, ORR_LAM(20, m0, 8), 9)                        \
+      ORR_ROW(m0, 22, ORR_LAM(21, m1, 9), 10)                       \
+      ORR_ROW(m1, 23, ORR_LAM(22, m0, 10), 11)                      \
+      ORR_ROW(m0, 24, ORR_LAM(23, m1, 11), 12)                      \
+      ORR_ROW(m1, 25, ORR_LAM(24, m0, 12), 13)                      \
+      ORR_ROW(m0, 26, ORR_LAM(25, m1, 13), 14)                      \
+      ORR_ROW(m1, 27, ORR_LAM(26, m0, 14), 15)                      \
+      TAIL
+  // three sweeps per loop iteration (a taken branch costs a lone wave as much as five multiply-adds), then the remaining ones singly
+  asm("v_mov_b32 %[zero], 0\n\t"
+      "s_cmp_lt_u32 %[it], 3\n\t"
+      "s_cbranch_scc1 3f\n"
       "1:\n\t"
-      ORR_ROW(m0, 0, "s_sub_u32 %[it], %[it], 1\n\t", 0)
-      ORR_ROW(m1, 1, ORR_LAM(0, m0, 0), 1)
-      ORR_ROW(m0, 2, ORR_LAM(1, m1, 1), 2)
-      ORR_ROW(m1, 3, ORR_LAM(2, m0, 2), 3)
-      ORR_NRM(t0, y, 16, 4, ORR_LAM(3, m1, 3))
-      ORR_NRM(y, t0, 17, 5, "v_fma_f32 %[hi], %[mun0], %[l16], %[hic]\n\t")
-      ORR_NRM(t0, y, 18, 6, "v_fmac_f32 %[hi], %[mun1], %[l17]\n\t")
-      ORR_NRM(y, t0, 19, 7, "v_fmac_f32 %[hi], %[mun2], %[l18]\n\t")
-      "v_fmac_f32 %[hi], %[mun3], %[l19]\n\t"
-      ORR_ROW(m0, 20, "s_cmp_eq_u32 %[it], 0\n\t", 8)
-      ORR_ROW(m1, 21, ORR_LAM(20, m0, 8), 9)
-      ORR_ROW(m0, 22, ORR_LAM(21, m1, 9), 10)
-      ORR_ROW(m1, 23, ORR_LAM(22, m0, 10), 11)
-      ORR_ROW(m0, 24, ORR_LAM(23, m1, 11), 12)
-      ORR_ROW(m1, 25, ORR_LAM(24, m0, 12), 13)
-      ORR_ROW(m0, 26, ORR_LAM(25, m1, 13), 14)
-      ORR_ROW(m1, 27, ORR_LAM(26, m0, 14), 15)
-      ORR_LAM(27, m1, 15)
-      "s_cbranch_scc0 1b"
+      ORR_SWEEP("s_sub_u32 %[it], %[it], 3\n\t", "s_cmp_ge_u32 %[it], 3\n\t", "")
+      ORR_SWEEP(ORR_LAM(27, m1, 15), "s_nop 0\n\t", "")
+      ORR_SWEEP(ORR_LAM(27, m1, 15), "s_nop 0\n\t", ORR_LAM(27, m1, 15))
+      "s_cbranch_scc1 1b\n"
+      "3:\n\t"
+      "s_cmp_eq_u32 %[it], 0\n\t"
+      "s_cbranch_scc1 4f\n"
+      "2:\n\t"
+      ORR_SWEEP("s_sub_u32 %[it], %[it], 1\n\t", "s_cmp_eq_u32 %[it], 0\n\t", ORR_LAM(27, m1, 15))
+      "s_cbranch_scc0 2b\n"
+      "4:"
       : [y] "+v"(y), [hi] "+v"(hi), [it] "+s"(it), [zero] "=&v"(zero), [t0] "=&v"(t0), [m0] "=&v"(m0), [m1] "=&v"(m1),
         [l0] "+v"(lam[0]), [l1] "+v"(lam[1]), [l2] "+v"(lam[2]), [l3] "+v"(lam[3]),
         [l16] "+v"(lam[16]), [l17] "+v"(lam[17]), [l18] "+v"(lam[18]), [l19] "+v"(lam[19]),
@@ -640,6 +656,7 @@ __device__ __forceinline__ void pgs_sweeps_bank_a(int iters, const Row& A, const
 #undef ORR_ROW
 #undef ORR_LAM
 #undef ORR_NRM
+#undef ORR_SWEEP
 }
 
 // The same with the joint-limit bank: every row update also moves yB (bank B's unclamped values), and the joint-limit rows
@@ -925,16 +942,9 @@ __device__ static int physics_substep(const KParams& P, Shared& S, const LegCons
     // quaternion: exponential map of the world angular velocity (DOFs 0..2, broadcast from their lanes), then normalise
     const float w0 = bcast_lane<0>(v0, sub), w1 = bcast_lane<1>(v0, sub), w2 = bcast_lane<2>(v0, sub);
     const float ww = w0 * w0 + w1 * w1 + w2 * w2, h2 = 0.25f * dt * dt * ww;  // h = |w| dt / 2
-    float sc, ch;  // sin(h) / |w| and cos(h)
-    if (h2 < 0.04f) {  // always, unless max_coord_velocity is raised a lot: Taylor series exact to float precision
-      sc = 0.5f * dt * fmaf(h2, fmaf(h2, fmaf(h2, -1.0f / 5040.0f, 1.0f / 120.0f), -1.0f / 6.0f), 1.0f);
-      ch = fmaf(h2, fmaf(h2, fmaf(h2, fmaf(h2, 1.0f / 40320.0f, -1.0f / 720.0f), 1.0f / 24.0f), -0.5f), 1.0f);
-    } else {
-      const float wn = sqrtf(ww);
-      float sh;
-      sincosf(0.5f * wn * dt, &sh, &ch);
-      sc = sh / wn;
-    }
+    // sin(h) / |w| and cos(h) by their series: h < 0.2 (orr_create checks max_coord_velocity * sim_dt), exact to float precision there
+    const float sc = 0.5f * dt * fmaf(h2, fmaf(h2, fmaf(h2, -1.0f / 5040.0f, 1.0f / 120.0f), -1.0f / 6.0f), 1.0f);
+    const float ch = fmaf(h2, fmaf(h2, fmaf(h2, fmaf(h2, 1.0f / 40320.0f, -1.0f / 720.0f), 1.0f / 24.0f), -0.5f), 1.0f);
     const float dq[4] = {w0 * sc, w1 * sc, w2 * sc, ch};
     float qn[4];
     qmul(dq, &S.s[O(QUAT)], qn);
