@@ -136,24 +136,26 @@ struct alignas(16) LinkCache {  // per movable link, written by the lane that ow
   float ow[3];      // link origin, world
   float s[3], sv[3];  // motion axis of the joint in front of the link, about the base COM: (axis; (origin - base) x axis)
 };
+// Index 3 of the per-part arrays below (and lc[12..15], W[kMaxRows], ustar[18..21]) are DUMP slots for the lanes that own no link /
+// joint / row: every lane then stores unconditionally -- a divergent `if` costs a lone wave 20-35 ticks (profiles/r02_issue_costs.txt).
 struct alignas(16) LegExchange {  // per leg, hand-over between the lanes (parts) of a leg inside leg_dynamics
-  float F[3][6];      // F_k = Ic_k S_k of joint k, written by part k
-  float Hc[3][4];     // Hc[k][i] = S_i . F_k (valid for i <= k)
+  float F[4][6];      // F_k = Ic_k S_k of joint k, written by part k
+  float Hc[4][4];     // Hc[k][i] = S_i . F_k (valid for i <= k)
   float b[4];         // tau_k - C_k
 };
-struct alignas(16) LegSolve {   // per leg: column k of T written by the leg's part-k lane, Hi by part 0; read by the row lanes
-  float T[3][6];    // F H^-1: column k = base wrench (angular; linear, world axes, about the base COM) per unit of joint k
+struct alignas(16) LegSolve {   // per leg: column k of T written by the leg's part-k lane, Hi by all of them; read by the row lanes
+  float T[4][6];    // F H^-1: column k = base wrench (angular; linear, world axes, about the base COM) per unit of joint k
   float Hi[6];      // H^-1 of the leg's 3x3 joint-space inertia (00 11 22 01 02 12)
 };
 
 constexpr int kPhaseSlots = 40;   // phase timers of the -DORR_PHASE_TIMERS build (tools/phase_cycles.py)
 constexpr int kWStride = 20;   // 18 DOFs, padded to a multiple of 16 bytes
 struct alignas(16) DynamicsBuf {           // leg dynamics -> row setup hand-over (dead once the impulse responses are written)
-  LinkCache lc[12];
+  LinkCache lc[16];           // 12 links + the part-3 lanes' dump slots
   LegExchange legx[4];
 };
 union alignas(16) SubstepBuf {            // live only inside a physics sub-step
-  float W[kMaxRows][kWStride];  // M^-1 J^T per row slot (18 used): written by the impulse responses, read until the velocity update
+  float W[kMaxRows + 1][kWStride];  // M^-1 J^T per row slot (18 used): written by the impulse responses, read until the velocity update
   DynamicsBuf dyn;            // shares its space: written by the next sub-step's dynamics, last read by the row setup
 };
 struct alignas(16) StepEndBuf {           // live only at reset / end of step
@@ -178,8 +180,8 @@ struct alignas(16) Shared {
   LegSolve leg[4];
   alignas(16) float Rb[9];     // kinematic base frame -> world
   alignas(16) float IA0inv[36];  // inverse of the base's effective 6x6 inertia (world axes, about the base COM)
-  alignas(16) float tau[12];   // joint torques (internal sign convention), joint order
-  alignas(16) float ustar[18];
+  alignas(16) float tau[16];   // joint torques (internal sign convention), joint order; 12..15: dump slots of the lanes that own no motor
+  alignas(16) float ustar[24];
   alignas(16) float co[20];    // control (latency-delayed) observation
   alignas(16) PhaseBuf ph;
 #ifdef ORR_PHASE_TIMERS
@@ -515,6 +517,13 @@ __device__ __forceinline__ float q_norm_angle(const float q[4]) {
     ang += (ang >= 0.0f) ? -2.0f * ORR_PI_F : 2.0f * ORR_PI_F;
   }
   return ang;
+}
+// x[lane & 3] as a two-level select on the bits of the lane (a chain of `lane == k ? ... :` on one variable is turned into a switch by
+// the optimiser, which the back end lowers to nested divergent branches: 20-35 ticks each for a lone wave)
+__device__ __forceinline__ float pick4(int lane, float x0, float x1, float x2, float x3) {
+  const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;
+  const float lo = b0 ? x1 : x0, hi = b0 ? x3 : x2;
+  return b1 ? hi : lo;
 }
 __device__ __forceinline__ float map_pi(float a) {  // pose3d.MapToMinusPiToPi (pose3d.py:358-374)
   // fmod(a, 2 pi) without libm's loop and branches (a taken or skipped branch costs a lone wave 3-6 multiply-adds): whole turns

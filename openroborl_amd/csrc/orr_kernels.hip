@@ -102,8 +102,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
     if (lane < 12) { const int j = S.m.joint_of_motor[lane]; S.tau[j] = S.m.tau_sign[j] * actions[(size_t)robot * 12 + lane]; }
     WSYNC();
     int fall = 0;
+    OwnCoord X;
+    load_own_coord(S, lane, X);
     for (int s = 0; s < nsub; s++) {
-      fall = physics_substep(P, S, K, lane, sub, true);
+      fall = physics_substep(P, S, K, lane, sub, true, X);
       float rel[4], Rb[9];
       base_rotation(S, lane, rel, Rb);
       WSYNC();
@@ -142,18 +144,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
   const bool m_has_prev = geti(S, O(FILTER_VALID)) != 0;
   int action_counter = geti(S, O(STATE_ACTION_COUNTER));
   RingCursor ring = {geti(S, O(RING_HEAD)), geti(S, O(RING_LEN))};
+  OwnCoord X;
+  load_own_coord(S, lane, X);
   for (int sstep = 0; sstep < c.action_repeat; sstep++) {
     if (kLanes != 16 && sstep > 0) ctrl_obs(P, rec, S, lane);
-    if (lane < 12) {
+    {  // every lane (no divergent `if`: it would cost more than it skips); lanes 12..15 repeat motor 0 and store into dump slots
       const float lerp = (float)(sstep + 1) * inv_repeat;  // process_action (minitaur.py:438-460)
-      const float cur = map_pi(S.co[lane]);
+      const float cur = map_pi(S.co[ml]);
       const float prev = m_has_prev ? m_prev : cur;
       float cmd = prev + lerp * (m_target - prev);
       cmd = fminf(fmaxf(cmd, cur - c.max_angle_change), cur + c.max_angle_change);  // _clip_motor_commands (:706-723)
       const float qm = (S.s[O(Q) + mj] - m_off) * m_dir;  // pd latency 0 (:359-363)
       const float qdm = S.s[O(QD) + mj] * m_dir;
       // MotorModel.convert_to_torque, POSITION mode (minitaur_motor.py:163-171)
-      S.tau[mj] = m_gain * (-1.0f * (m_kp * (qm - cmd)) - m_kd * qdm);
+      S.tau[lane < 12 ? mj : lane] = m_gain * (-1.0f * (m_kp * (qm - cmd)) - m_kd * qdm);
     }
     WSYNC();
     action_counter++;  // robot_step bookkeeping (minitaur.py:287-293); written back after the loop
@@ -169,10 +173,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
         WSYNC();
         fall = RP.fall[robot];
       } else
-      fall = physics_substep(P, S, K, lane, sub, sstep == c.action_repeat - 1);
+      fall = physics_substep(P, S, K, lane, sub, sstep == c.action_repeat - 1, X);
       ring_push_and_ctrl_obs(rec, S, lane, valid, F, ring, (S.s[O(Q) + mj] - m_off) * m_dir);
     } else {
-      fall = physics_substep(P, S, K, lane, sub, sstep == c.action_repeat - 1);
+      fall = physics_substep(P, S, K, lane, sub, sstep == c.action_repeat - 1, X);
       receive_obs(rec, S, lane, valid);
     }
     PT(10);
@@ -480,6 +484,7 @@ int32_t orr_set_model(orr_handle* h, int32_t robot_type, const orr_model* m) {
     H.motor_of_joint[j] = i;
     H.kp[i] = m->kp[i];
     H.kd[i] = m->kd[i];
+    if (fabsf(fabsf(m->motor_dir[i]) - 1.0f) > 1e-6f) return fail(-1, "orr_set_model: motor_dir must be +1 or -1");
     H.jdir[j] = m->motor_dir[i] * axsgn[j];
     H.joff[j] = m->motor_offset[i];
     H.tau_sign[j] = axsgn[j];

@@ -54,7 +54,18 @@ struct LegConst {
   float jdir_own, joff_own;         // the lane's own joint (part < 3; jdir 0 for part 3): scalars, NOT selects over jdir[] / joff[] --
                                     // the compiler turns such a select into a dynamically indexed load, which pushes the whole
                                     // struct out of registers (into LDS via promote-alloca)
+  float int_c0, int_c1;             // integration (lane l owns DOF l and, l < 2, DOF 16 + l): d(coordinate) / d(velocity) -- 0 for the
+                                    // angular base DOFs (the quaternion is integrated separately), 1 for the base position, jdir
+                                    // (= +-1, orr_set_model checks) for a joint
 };
+// The coordinates a lane integrates, carried in registers over the sub-steps of a launch (the LDS copy is written every sub-step for the
+// other lanes, never read back by the owner): x0 = base position component (lanes 3..5) or joint angle (lanes 6..15: joints 0..9),
+// x1 = joint 10 + lane (lanes 0, 1).
+struct OwnCoord { float x0, x1; };
+__device__ __forceinline__ void load_own_coord(const Shared& S, int lane, OwnCoord& X) {
+  X.x0 = lane < 3 ? 0.0f : (lane < 6 ? S.s[O(POS) + lane - 3] : S.s[O(Q) + lane - 6]);
+  X.x1 = lane < 2 ? S.s[O(Q) + 10 + lane] : 0.0f;
+}
 __device__ static void load_leg_const(const Shared& S, int lane, LegConst& K) {
   const int leg = lane & 3, part = (lane >> 2) & 3, own = 3 * leg + (part < 3 ? part : 2);
 #pragma unroll
@@ -79,6 +90,8 @@ __device__ static void load_leg_const(const Shared& S, int lane, LegConst& K) {
   K.joff_own = S.m.joff[own];
   K.damp_l = base ? S.s[O(BASE_DAMPING)] : 0.0f;
   K.damp_a = base ? S.s[O(BASE_DAMPING) + 1] : 0.0f;
+  K.int_c0 = lane < 3 ? 0.0f : (lane < 6 ? 1.0f : S.m.jdir[lane < 6 ? 0 : lane - 6]);
+  K.int_c1 = lane < 2 ? S.m.jdir[10 + lane] : 0.0f;
 }
 
 // ================================================================================================
@@ -176,7 +189,6 @@ __device__ __forceinline__ float part_suffix_sum(float x) {
 
 __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst& K, int lane) {
   const int leg = lane & 3, part = (lane >> 2) & 3;
-  const bool first = lane < 4;            // the leg's results are written by its part-0 lane
   float Rb[9];  // kinematic base frame -> world: kept current by base_rotation() (after every change of the quaternion)
 #pragma unroll
   for (int i = 0; i < 9; i++) Rb[i] = S.Rb[i];
@@ -218,8 +230,8 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
     svo[i] = part == 0 ? sv0[i] : (part == 1 ? sv1[i] : (part == 2 ? sv2[i] : 0.0f));
   }
   const float ado = part == 0 ? ad0 : (part == 1 ? ad1 : ad2);
-  if (lane < 12) {  // pose and joint axis of the own link for the constraint rows
-    LinkCache& L = S.ph.sub.dyn.lc[3 * leg + part];
+  {  // pose and joint axis of the own link for the constraint rows (part-3 lanes: dump slot)
+    LinkCache& L = S.ph.sub.dyn.lc[part < 3 ? 3 * leg + part : 12 + leg];
 #pragma unroll
     for (int i = 0; i < 9; i++) L.Rw[i] = Rw[i];
 #pragma unroll
@@ -273,7 +285,7 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
     bo = S.tau[3 * leg + (part < 3 ? part : 2)] - (dot3(so, &f[0]) + dot3(svo, &f[3]));
     const float hc0 = dot3(s0, &Fo[0]) + dot3(sv0, &Fo[3]), hc1 = dot3(s1, &Fo[0]) + dot3(sv1, &Fo[3]);
     const float hc2 = dot3(s2, &Fo[0]) + dot3(sv2, &Fo[3]);
-    if (lane < 12) {
+    {  // part-3 lanes: index 3 = dump slot
       LegExchange& X = S.ph.sub.dyn.legx[leg];
 #pragma unroll
       for (int i = 0; i < 6; i++) X.F[part][i] = Fo[i];
@@ -309,14 +321,12 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
   float Tq[6];  // column `part` of T = F H^-1
 #pragma unroll
   for (int i = 0; i < 6; i++) Tq[i] = F[0][i] * hq0 + F[1][i] * hq1 + F[2][i] * hq2;
-  if (lane < 12) {
+  {  // part-3 lanes: T[3] = dump slot; H^-1 is the same in all lanes of the leg, every one of them stores it
     LegSolve& Q = S.leg[leg];
 #pragma unroll
     for (int i = 0; i < 6; i++) Q.T[part][i] = Tq[i];
-    if (first) {
 #pragma unroll
-      for (int i = 0; i < 6; i++) Q.Hi[i] = Hi[i];
-    }
+    for (int i = 0; i < 6; i++) Q.Hi[i] = Hi[i];
   }
   // this lane's term of the elimination: -T_k F_k^T on the matrix, +T_k b_k on the force (Fo is zero in the part-3 lanes)
 #define TFT(i, j) (Tq[i] * Fo[j])
@@ -361,10 +371,8 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
 #pragma unroll
     for (int i = 0; i < 6; i++) e[i] = (i == col) ? 1.0f : 0.0f;
     chol6_solve(Lc, idg, e, x);
-    if (lane < 6) {
 #pragma unroll
-      for (int i = 0; i < 6; i++) S.IA0inv[i * 6 + col] = x[i];
-    }
+    for (int i = 0; i < 6; i++) S.IA0inv[i * 6 + col] = x[i];   // lanes >= 6 store the same column again (col = lane % 6)
   }
   // joint accelerations qdd = H^-1 (b - F^T a0): row `part` of H^-1 for the lane's own joint; written as the unconstrained
   // velocity u* = u + dt udot by the lane that owns the joint (it has the joint rate)
@@ -374,10 +382,11 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
 #pragma unroll
     for (int k = 0; k < 3; k++)
       g[k] = b[k] - (F[k][0] * a0[0] + F[k][1] * a0[1] + F[k][2] * a0[2] + F[k][3] * a0[3] + F[k][4] * a0[4] + F[k][5] * a0[5]);
-    if (lane < 12) S.ustar[6 + 3 * leg + part] = ado + dt * (hq0 * g[0] + hq1 * g[1] + hq2 * g[2]);
+    S.ustar[part < 3 ? 6 + 3 * leg + part : 18 + leg] = ado + dt * (hq0 * g[0] + hq1 * g[1] + hq2 * g[2]);   // part 3: dump slot
   }
-  if (lane == 0) {
-    // classical base acceleration (Bullet: vdot = a_lin + w x v); gravity = uniform-field offset
+  {
+    // classical base acceleration (Bullet: vdot = a_lin + w x v); gravity = uniform-field offset.  The same in every lane: all of
+    // them store it (no divergent `if`)
     float wxv[3];
     cross3(wb, vb, wxv);
     S.ustar[0] = wb[0] + dt * a0[0]; S.ustar[1] = wb[1] + dt * a0[1]; S.ustar[2] = wb[2] + dt * a0[2];
@@ -538,19 +547,22 @@ __device__ __forceinline__ void row_response(Shared& S, const orr_config& cfg, R
   }
 #pragma unroll
   for (int i = 0; i < 6; i++) diag += R.Jb[i] * a0[i];
-  if (R.active) {
+  // an inactive row stores too (zeros: its Jacobian is zero; its impulse stays zero anyway)
 #pragma unroll
-    for (int i = 0; i < 6; i++) S.ph.sub.W[slot][i] = a0[i];
+  for (int i = 0; i < 6; i++) S.ph.sub.W[slot][i] = a0[i];
 #pragma unroll
-    for (int i = 0; i < 12; i++) S.ph.sub.W[slot][6 + i] = mq[i];
-  }
+  for (int i = 0; i < 12; i++) S.ph.sub.W[slot][6 + i] = mq[i];
 #pragma unroll
   for (int i = 0; i < 6; i++) R.wa[i] = a0[i];
 #pragma unroll
   for (int i = 0; i < 12; i++) R.wq[i] = mq[i];
   R.jdi = R.active ? __builtin_amdgcn_rcpf(diag) : 0.0f;
   R.rhs *= R.jdi;
-  R.lam = (R.active && R.warm >= 0) ? cfg.warmstart_factor * S.s[O(LAMBDA) + R.warm] : 0.0f;
+  {
+    float prev = S.s[O(LAMBDA) + (R.warm >= 0 ? R.warm : 0)];   // every lane loads (opaque, so that the load is not put behind a branch)
+    asm volatile("" : "+v"(prev));
+    R.lam = (R.active && R.warm >= 0) ? cfg.warmstart_factor * prev : 0.0f;
+  }
 }
 
 // compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N)
@@ -846,7 +858,7 @@ __device__ __forceinline__ void delassus_columns(const Shared& S, unsigned int m
 }
 
 // One physics sub-step.  Returns the fall-proxy flag (wave-uniform) when want_fall.
-__device__ static int physics_substep(const KParams& P, Shared& S, const LegConst& K, int lane, int sub, bool want_fall) {
+__device__ static int physics_substep(const KParams& P, Shared& S, const LegConst& K, int lane, int sub, bool want_fall, OwnCoord& X) {
   const orr_config& cfg = P.cfg;
   const float dt = cfg.sim_dt, inv_dt = 1.0f / cfg.sim_dt, erp_dt = cfg.contact_erp / cfg.sim_dt;
   leg_dynamics(P, S, K, lane);  // -> link poses, leg solves, unconstrained velocities u*
@@ -891,7 +903,7 @@ __device__ static int physics_substep(const KParams& P, Shared& S, const LegCons
   PT(5);
   // ---------------- impulse responses M^-1 J^T, diagonal, warm start ----------------
   row_response(S, cfg, A, rowlane ? (lane < 4 ? lane : lane + 12) : 0);
-  if (anyB) row_response(S, cfg, B, (rowlane && lane >= 4) ? lane : 4);
+  if (anyB) row_response(S, cfg, B, (rowlane && lane >= 4) ? lane : kMaxRows);   // lanes without a joint-limit row: dump slot
   WSYNC();
   PT(6);
   // Delassus columns, then the Gauss-Seidel sweeps; two instantiations: with and without the joint-limit bank
@@ -907,7 +919,8 @@ __device__ static int physics_substep(const KParams& P, Shared& S, const LegCons
   }
   PT(8);
   // contact impulses are remembered for the next sub-step's warm start (0 for open contacts)
-  if (lane == 0) {  // warm-start slot 3 leg + d: normal (slot 16 + leg), then the two friction rows (20 + 2 leg, 21 + 2 leg)
+  {  // warm-start slot 3 leg + d: normal (slot 16 + leg), then the two friction rows (20 + 2 leg, 21 + 2 leg); lam[] is the same in
+     // every lane of the robot, all of them store it
 #pragma unroll
     for (int g = 0; g < 4; g++) {
       S.s[O(LAMBDA) + 3 * g] = lam[16 + g];
@@ -949,25 +962,23 @@ __device__ static int physics_substep(const KParams& P, Shared& S, const LegCons
     float qn[4];
     qmul(dq, &S.s[O(QUAT)], qn);
     const float nn = rsqrtf(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+    // coordinates: the internal joint angle a = jdir (q - joff) advances by dt v, i.e. q by jdir dt v (jdir = +-1); the owner lane
+    // integrates its register copy (OwnCoord) and publishes it.  Every lane stores five words without a divergent `if` (dump slots
+    // where it has nothing to store): velocity and coordinate of DOF l, of DOF 16 + l (lanes 0, 1), one quaternion component (lanes 0..3)
+    X.x0 = fmaf(dt * v0, K.int_c0, X.x0);
+    X.x1 = fmaf(dt * v1, K.int_c1, X.x1);
+    float* const dump = &S.ustar[22];
+    float* const pv0 = &S.s[lane < 3 ? O(ANGVEL) + lane : (lane < 6 ? O(LINVEL) + lane - 3 : O(QD) + lane - 6)];
+    float* const px0 = lane < 3 ? dump : &S.s[lane < 6 ? O(POS) + lane - 3 : O(Q) + lane - 6];
+    float* const pv1 = lane < 2 ? &S.s[O(QD) + 10 + lane] : dump;
+    float* const px1 = lane < 2 ? &S.s[O(Q) + 10 + lane] : dump;
+    float* const pq = lane < 4 ? &S.s[O(QUAT) + lane] : dump;
     WSYNC();
-    if (lane < 3) {
-      S.s[O(ANGVEL) + lane] = v0;
-    } else if (lane < 6) {
-      S.s[O(LINVEL) + lane - 3] = v0;
-      S.s[O(POS) + lane - 3] += dt * v0;
-    } else {
-      const int j = lane - 6;
-      const float a = S.m.jdir[j] * (S.s[O(Q) + j] - S.m.joff[j]) + dt * v0;
-      S.s[O(Q) + j] = a * S.m.jdir[j] + S.m.joff[j];
-      S.s[O(QD) + j] = v0 * S.m.jdir[j];
-    }
-    if (lane < 2) {
-      const int j = 10 + lane;
-      const float a = S.m.jdir[j] * (S.s[O(Q) + j] - S.m.joff[j]) + dt * v1;
-      S.s[O(Q) + j] = a * S.m.jdir[j] + S.m.joff[j];
-      S.s[O(QD) + j] = v1 * S.m.jdir[j];
-    }
-    if (lane < 4) S.s[O(QUAT) + lane] = (lane == 0 ? qn[0] : (lane == 1 ? qn[1] : (lane == 2 ? qn[2] : qn[3]))) * nn;
+    *pv0 = lane < 6 ? v0 : v0 * K.int_c0;
+    *px0 = X.x0;
+    *pv1 = v1 * K.int_c1;
+    *px1 = X.x1;
+    *pq = pick4(lane, qn[0], qn[1], qn[2], qn[3]) * nn;
   } else {
     // wider lane groups (tuning builds): through LDS
     if (lane < 18) S.ustar[lane] = v0;

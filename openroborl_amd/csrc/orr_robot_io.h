@@ -60,10 +60,8 @@ __device__ __forceinline__ void base_rotation(Shared& S, int lane, float rel[4],
   qinv(S.m.init_quat, qi);
   qmul(&S.s[O(QUAT)], qi, rel);
   q_to_mat(rel, Rb);
-  if (lane == 0) {
 #pragma unroll
-    for (int i = 0; i < 9; i++) S.Rb[i] = Rb[i];
-  }
+  for (int i = 0; i < 9; i++) S.Rb[i] = Rb[i];   // the same in every lane: all of them store it (no divergent `if`)
 }
 
 // Minitaur.receive_obs + get_true_obs (minitaur.py:304-334): push the true observation.  entry: optional copy of the pushed
@@ -146,18 +144,18 @@ __device__ __forceinline__ void ring_push_and_ctrl_obs(float* rec, Shared& S, in
   mtv3(Rb, &S.s[O(ANGVEL)], rate);  // get_true_base_rpy_rate (minitaur.py:640-672): angular velocity in the base frame
   // word `lane`: motor angles 0..11 (get_true_motor_angles, :543-553), relative quaternion 12..15;
   // word 16 + lane (lanes 0..3): rate 16..18, pad 19
-  const float va = lane < 12 ? mang : (lane == 12 ? rel[0] : (lane == 13 ? rel[1] : (lane == 14 ? rel[2] : rel[3])));
-  const float vb = lane == 0 ? rate[0] : (lane == 1 ? rate[1] : (lane == 2 ? rate[2] : 0.0f));
+  const float va = lane < 12 ? mang : pick4(lane, rel[0], rel[1], rel[2], rel[3]);
+  const float vb = pick4(lane, rate[0], rate[1], rate[2], 0.0f);   // lanes >= 4: never stored
   const float a0 = F.new0 ? va : F.e0[0], a1 = F.new1 ? va : F.e1[0];
   const float b0 = F.new0 ? vb : F.e0[1], b1 = F.new1 ? vb : F.e1[1];
   S.co[lane] = F.same ? a0 : (1.0f - F.al) * a0 + F.al * a1;
-  if (lane < 3) S.co[16 + lane] = F.same ? b0 : (1.0f - F.al) * b0 + F.al * b1;
+  S.co[lane < 3 ? 16 + lane : 19] = F.same ? b0 : (1.0f - F.al) * b0 + F.al * b1;   // lanes >= 3: the pad word (no divergent `if`)
   WSYNC();
   // the push is stored AFTER the prefetched entries were consumed: loads and stores share one in-order counter (vmcnt) on this
   // target, so a wait for the (long finished) prefetch behind a fresh store would sit out the store's whole round trip
   float* dst = rec + O(RING) + C.head * ORR_RING_ENTRY;
   if (valid) {
     dst[lane] = va;
-    if (lane < 4) dst[16 + lane] = vb;
+    dst[lane < 4 ? 16 + lane : lane] = lane < 4 ? vb : va;   // lanes >= 4 repeat their first store (one branch instead of two)
   }
 }
