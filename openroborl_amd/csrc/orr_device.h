@@ -474,6 +474,45 @@ __device__ __forceinline__ void joint_sincos(float a, float* sn, float* cs) {
 #endif
 }
 
+// Inverse trigonometric functions without branches (libm's atan2f / asinf / acosf cost a lone wave several taken or skipped
+// branches each, 13-30 ticks apiece: profiles/r02_issue_costs.txt).  atan2: octant reduction to t = min / max in [0, 1], then the
+// Cephes atanf kernel on [0, tan(pi/8)] (t -> (t - 1) / (t + 1) above it); absolute error < 3e-7 (checked against float64 on 2 M
+// random arguments).  -DORR_LIBM_TRIG switches back to libm.
+__device__ __forceinline__ float atan2_bf(float y, float x) {
+#ifdef ORR_LIBM_TRIG
+  return atan2f(y, x);
+#else
+  const float ax = fabsf(x), ay = fabsf(y);
+  const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+  const float t = mx > 0.0f ? mn * __builtin_amdgcn_rcpf(mx) : 0.0f;
+  const bool big = t > 0.41421356237f;
+  const float u = big ? (t - 1.0f) * __builtin_amdgcn_rcpf(t + 1.0f) : t;
+  const float z = u * u;
+  float p = fmaf(z, 8.05374449538e-2f, -1.38776856032e-1f);
+  p = fmaf(p, z, 1.99777106478e-1f);
+  p = fmaf(p, z, -3.33329491539e-1f);
+  float r = fmaf(p * z, u, u);
+  r = big ? r + 0.78539816339744831f : r;
+  r = ay > ax ? 1.57079632679489662f - r : r;
+  r = x < 0.0f ? 3.14159265358979324f - r : r;
+  return y < 0.0f ? -r : r;
+#endif
+}
+__device__ __forceinline__ float asin_bf(float x) {   // |x| <= 1
+#ifdef ORR_LIBM_TRIG
+  return asinf(x);
+#else
+  return atan2_bf(x, __builtin_amdgcn_sqrtf(fmaxf((1.0f - x) * (1.0f + x), 0.0f)));
+#endif
+}
+__device__ __forceinline__ float acos_bf(float x) {   // |x| <= 1
+#ifdef ORR_LIBM_TRIG
+  return acosf(x);
+#else
+  return atan2_bf(__builtin_amdgcn_sqrtf(fmaxf((1.0f - x) * (1.0f + x), 0.0f)), x);
+#endif
+}
+
 // transformations.quaternion_multiply(a, b): Hamilton product (pose3d.py:228-230)
 __device__ __forceinline__ void qmul(const float a[4], const float b[4], float o[4]) {
   float x1 = a[0], y1 = a[1], z1 = a[2], w1 = a[3], x0 = b[0], y0 = b[1], z0 = b[2], w0 = b[3];
@@ -496,28 +535,30 @@ __device__ __forceinline__ void qrot(const float p[3], const float q[4], float o
   o[0] = r[0]; o[1] = r[1]; o[2] = r[2];
 }
 __device__ __forceinline__ void qstd(float q[4]) {  // pose3d.py:289-301
-  if (q[3] < 0.0f) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
+  const float sg = q[3] < 0.0f ? -1.0f : 1.0f;
+  q[0] *= sg; q[1] *= sg; q[2] *= sg; q[3] *= sg;
 }
 __device__ __forceinline__ float qheading(const float q[4]) {  // pose3d.py:325-341
   float x[3] = {1.0f, 0.0f, 0.0f}, r[3];
   qrot(x, q, r);
-  return atan2f(r[1], r[0]);
+  return atan2_bf(r[1], r[0]);
 }
 __device__ __forceinline__ void q_about_z(float ang, float o[4]) {
   float s, c;
-  sincosf(0.5f * ang, &s, &c);
+  joint_sincos(0.5f * ang, &s, &c);
   o[0] = 0.0f; o[1] = 0.0f; o[2] = s; o[3] = c;
 }
 // |angle| of pose3d.QuaternionToAxisAngle + normalize_rotation_angle (pose3d.py:139-187,304-322)
 __device__ __forceinline__ float q_norm_angle(const float q[4]) {
-  float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
-  float ang = 2.0f * atan2f(n, q[3]);
-  if (fabsf(ang) > ORR_PI_F) {
-    ang = fmodf(ang, 2.0f * ORR_PI_F);
-    ang += (ang >= 0.0f) ? -2.0f * ORR_PI_F : 2.0f * ORR_PI_F;
-  }
-  return ang;
+  const float n = __builtin_amdgcn_sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+  const float ang = 2.0f * atan2_bf(n, q[3]);   // in [0, 2 pi] (n >= 0)
+  // beyond pi: fmod(ang, 2 pi) (= ang here, or 0 at exactly 2 pi) minus a full turn
+  const float m = ang >= 2.0f * ORR_PI_F ? ang - 2.0f * ORR_PI_F : ang;
+  return ang > ORR_PI_F ? m - 2.0f * ORR_PI_F : ang;
 }
+// 1 / sqrt(x) for a normal positive x (sums of squares of unit-ish quaternions, pivots of the base inertia): the bare hardware
+// instruction (1 ulp); libm's rsqrtf wraps it in a denormal-range rescaling, five more instructions per call
+__device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 // x[lane & 3] as a two-level select on the bits of the lane (a chain of `lane == k ? ... :` on one variable is turned into a switch by
 // the optimiser, which the back end lowers to nested divergent branches: 20-35 ticks each for a lone wave)
 __device__ __forceinline__ float pick4(int lane, float x0, float x1, float x2, float x3) {
@@ -535,7 +576,7 @@ __device__ __forceinline__ float map_pi(float a) {  // pose3d.MapToMinusPiToPi (
   return m;
 }
 __device__ __forceinline__ void q_to_mat(const float qin[4], float R[9]) {
-  float n = rsqrtf(qin[0] * qin[0] + qin[1] * qin[1] + qin[2] * qin[2] + qin[3] * qin[3]);
+  float n = rsq(qin[0] * qin[0] + qin[1] * qin[1] + qin[2] * qin[2] + qin[3] * qin[3]);
   float x = qin[0] * n, y = qin[1] * n, z = qin[2] * n, w = qin[3] * n;
   R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w); R[2] = 2 * (x * z + y * w);
   R[3] = 2 * (x * y + z * w); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
@@ -546,33 +587,29 @@ __device__ __forceinline__ void euler_from_quat(const float q[4], float rpy[3]) 
   float x = q[0], y = q[1], z = q[2], w = q[3];
   float sqx = x * x, sqy = y * y, sqz = z * z, sqw = w * w;
   float sarg = -2.0f * (x * z - w * y);
-  rpy[0] = atan2f(2.0f * (y * z + w * x), -sqx - sqy + sqz + sqw);
-  rpy[1] = sarg <= -1.0f ? -0.5f * ORR_PI_F : (sarg >= 1.0f ? 0.5f * ORR_PI_F : asinf(sarg));
-  rpy[2] = atan2f(2.0f * (x * y + w * z), sqx - sqy - sqz + sqw);
+  rpy[0] = atan2_bf(2.0f * (y * z + w * x), -sqx - sqy + sqz + sqw);
+  rpy[1] = asin_bf(fminf(fmaxf(sarg, -1.0f), 1.0f));     // = -+ pi / 2 at the clamped ends
+  rpy[2] = atan2_bf(2.0f * (x * y + w * z), sqx - sqy - sqz + sqw);
 }
 // transformations.quaternion_slerp (shortest path)
 __device__ __forceinline__ void qslerp(const float a[4], const float b[4], float f, float o[4]) {
   const float EPS = 1.1920929e-07f * 4.0f;
-  float n0 = rsqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3]);
-  float n1 = rsqrtf(b[0] * b[0] + b[1] * b[1] + b[2] * b[2] + b[3] * b[3]);
+  float n0 = rsq(a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3]);
+  float n1 = rsq(b[0] * b[0] + b[1] * b[1] + b[2] * b[2] + b[3] * b[3]);
   float q0[4] = {a[0] * n0, a[1] * n0, a[2] * n0, a[3] * n0};
   float q1[4] = {b[0] * n1, b[1] * n1, b[2] * n1, b[3] * n1};
   float d = q0[0] * q1[0] + q0[1] * q1[1] + q0[2] * q1[2] + q0[3] * q1[3];
-  float s0 = 1.0f, s1 = 0.0f;
-  if (f == 0.0f) { s0 = 1.0f; s1 = 0.0f; }
-  else if (f == 1.0f) { s0 = 0.0f; s1 = 1.0f; }
-  else if (fabsf(fabsf(d) - 1.0f) < EPS) { s0 = 1.0f; s1 = 0.0f; }
-  else {
-    float sgn = 1.0f;
-    if (d < 0.0f) { d = -d; sgn = -1.0f; }
-    float ang = acosf(d);
-    if (fabsf(ang) < EPS) { s0 = 1.0f; s1 = 0.0f; }
-    else {
-      float isin = 1.0f / sinf(ang);
-      s0 = sinf((1.0f - f) * ang) * isin;
-      s1 = sgn * sinf(f * ang) * isin;
-    }
-  }
+  // no branches: the general formula is evaluated always and the special cases of the reference are selected afterwards
+  const float sgn = d < 0.0f ? -1.0f : 1.0f, da = fminf(fabsf(d), 1.0f);
+  const float ang = acos_bf(da);
+  float sa, sb, unused;
+  joint_sincos((1.0f - f) * ang, &sa, &unused);
+  joint_sincos(f * ang, &sb, &unused);
+  const float isin = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(fmaxf((1.0f - da) * (1.0f + da), 1e-30f)));   // 1 / sin(acos(|d|))
+  const bool first = f == 0.0f, second = f == 1.0f;
+  const bool same = fabsf(fabsf(d) - 1.0f) < EPS || fabsf(ang) < EPS;   // the ends coincide
+  const float s0 = first ? 1.0f : (second ? 0.0f : (same ? 1.0f : sa * isin));
+  const float s1 = first ? 0.0f : (second ? 1.0f : (same ? 0.0f : sgn * sb * isin));
 #pragma unroll
   for (int i = 0; i < 4; i++) o[i] = q0[i] * s0 + q1[i] * s1;
 }

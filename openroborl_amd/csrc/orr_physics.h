@@ -16,7 +16,7 @@ __device__ __forceinline__ void chol6(const float A[36], float L[21], float invd
 #pragma unroll
       for (int k = 0; k < j; k++) s -= L[i * (i + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
       if (i == j) {
-        const float rs = rsqrtf(s);
+        const float rs = rsq(s);
         L[i * (i + 1) / 2 + j] = s * rs;
         invdiag[i] = rs;
       } else {
@@ -961,7 +961,7 @@ __device__ static int physics_substep(const KParams& P, Shared& S, const LegCons
     const float dq[4] = {w0 * sc, w1 * sc, w2 * sc, ch};
     float qn[4];
     qmul(dq, &S.s[O(QUAT)], qn);
-    const float nn = rsqrtf(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+    const float nn = rsq(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
     // coordinates: the internal joint angle a = jdir (q - joff) advances by dt v, i.e. q by jdir dt v (jdir = +-1); the owner lane
     // integrates its register copy (OwnCoord) and publishes it.  Every lane stores five words without a divergent `if` (dump slots
     // where it has nothing to store): velocity and coordinate of DOF l, of DOF 16 + l (lanes 0, 1), one quaternion component (lanes 0..3)
@@ -990,7 +990,7 @@ __device__ static int physics_substep(const KParams& P, Shared& S, const LegCons
     else { float sh; sincosf(half, &sh, &ch); sc = sh / wn; }
     float dq[4] = {w0 * sc, w1 * sc, w2 * sc, ch}, qn[4];
     qmul(dq, &S.s[O(QUAT)], qn);
-    const float nn = rsqrtf(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+    const float nn = rsq(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
     WSYNC();
     for (int i = lane; i < 22; i += kLanes) {
       if (i < 3) S.s[O(ANGVEL) + i] = S.ustar[i];

@@ -178,9 +178,10 @@ __device__ static void target_obs(const KParams& P, const float* rec, Shared& S,
     euler_from_quat(&S.co[12], rpy);
     // robot.get_base_orientation (minitaur.py:630-638) = quaternion of the delayed rpy; its heading is the
     // direction of the rotated x axis = atan2(sin(yaw) cos(pitch), cos(yaw) cos(pitch))
-    float sy, cy, cpch = cosf(rpy[1]);
-    sincosf(rpy[2], &sy, &cy);
-    const float heading = atan2f(sy * cpch, cy * cpch);
+    float sy, cy, spch, cpch;
+    joint_sincos(rpy[1], &spch, &cpch);
+    joint_sincos(rpy[2], &sy, &cy);
+    const float heading = atan2_bf(sy * cpch, cy * cpch);
     float ih[4], p[3], pr[3], q[4];
     q_about_z(-heading, ih);
     const float* pose = S.ph.end.pose[lane];
