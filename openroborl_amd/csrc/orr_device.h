@@ -175,6 +175,7 @@ union PhaseBuf {
 struct alignas(16) Shared {
   alignas(16) float s[kHead];  // state head (float / int bit patterns)
   alignas(16) ModelHot m;      // robot model (hot part)
+  alignas(16) DevClip clip;    // header of the robot's motion clip (copied once per launch: its fields are read many times at the end of a step)
   alignas(16) float mass[13];  // after randomisation ratios
   alignas(16) float Ic[13][6];
   LegSolve leg[4];

@@ -194,13 +194,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
   sensors_push(S, lane, false);
   PT(11);
   // ---- reward -> update -> done (quadruped_gym_env.py:230-233) ----
-  float rew = calc_reward(P, S, lane, MODE == 2 ? RP.eff + (size_t)robot * 48 : nullptr);
-  const DevClip& clip = P.tab->clip[geti(S, O(CLIP_ID))];
+  // the frames of the new reference poses are fetched while the reward is computed (their round trip to L2 is not waited for)
+  const DevClip& clip = S.clip;
   const float t = motion_time(P, S);
   const float step_dt = c.sim_dt * c.action_repeat;
   float tl = t;
   if (lane >= 1 && lane <= 4) tl = t + c.tar_frame_steps[lane - 1] * step_dt;
-  sample_poses(P, S, lane, tl, true);
+  PoseLoads PL;
+  sample_poses_issue(P, S, lane, tl, PL);
+  float rew = calc_reward(P, S, lane, MODE == 2 ? RP.eff + (size_t)robot * 48 : nullptr);
+  sample_poses_finish(P, S, lane, tl, true, PL);
   {
     // _update_ref_motion (imitation_task.py:734-761) with _sync_ref_origin (:1020-1055)
     const float ph = clip_phase(clip, t);

@@ -16,13 +16,47 @@ __device__ static void refresh_mass(const DevModel& gm, Shared& S, int lane) {
   }
 }
 
+// the same in two halves (reset_robot): the loads are issued early and consumed once the new ratios have been drawn
+struct MassLoads { int g; float m, in[6], pa[6]; };
+__device__ __forceinline__ void mass_prefetch(const DevModel& gm, int lane, MassLoads& L) {
+  typedef const float __attribute__((address_space(1))) * gptr;    // the table lives in global memory: plain global loads, not FLAT
+  typedef const int __attribute__((address_space(1))) * giptr;
+  const int b = lane < 13 ? lane : 12;
+  L.g = ((giptr)gm.group)[b];
+  L.m = ((gptr)gm.mass)[b];
+#pragma unroll
+  for (int k = 0; k < 6; k++) { L.in[k] = ((gptr)&gm.inertia[b][0])[k]; L.pa[k] = ((gptr)&gm.inertia_pa[b][0])[k]; }
+}
+__device__ __forceinline__ void refresh_mass_from(const MassLoads& L, Shared& S, int lane) {
+  if (lane < 13) {
+    const float mr = S.s[O(MASS_RATIO) + L.g], ir = S.s[O(INERTIA_RATIO) + L.g];
+    S.mass[lane] = L.m * mr;
+#pragma unroll
+    for (int k = 0; k < 6; k++) S.Ic[lane][k] = L.in[k] * ir + L.pa[k] * mr;
+  }
+}
+
 __device__ static void load_robot(const KParams& P, const float* rec, Shared& S, int lane) {
   for (int i = lane; i < kHead; i += kLanes) S.s[i] = rec[i];
   WSYNC();
   const DevModel& gm = P.tab->model[geti(S, O(ROBOT_TYPE))];
+  {
+    static_assert(sizeof(DevClip) % 4 == 0 && sizeof(DevClip) / 4 <= kLanes, "one word of the clip header per lane");
+    const unsigned int* cg = reinterpret_cast<const unsigned int*>(&P.tab->clip[geti(S, O(CLIP_ID))]);
+    unsigned int* cl = reinterpret_cast<unsigned int*>(&S.clip);
+    if (lane < (int)(sizeof(DevClip) / 4)) cl[lane] = cg[lane];
+  }
   const float* mp = reinterpret_cast<const float*>(&gm.hot);
   float* dst = reinterpret_cast<float*>(&S.m);
-  for (int i = lane; i < kModelLdsWords; i += kLanes) dst[i] = mp[i];
+  {
+    // all words of the model in flight at once (a rolled copy loop waits for every group of loads: six round trips to L2 per launch)
+    constexpr int kIter = (kModelLdsWords + kLanes - 1) / kLanes;
+    float tmp[kIter];
+#pragma unroll
+    for (int k = 0; k < kIter; k++) { const int i = lane + k * kLanes; tmp[k] = mp[i < kModelLdsWords ? i : kModelLdsWords - 1]; }
+#pragma unroll
+    for (int k = 0; k < kIter; k++) { const int i = lane + k * kLanes; if (i < kModelLdsWords) dst[i] = tmp[k]; }
+  }
   refresh_mass(gm, S, lane);
   WSYNC();
 }

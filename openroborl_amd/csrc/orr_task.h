@@ -54,45 +54,55 @@ __device__ static void cycle_offset(const DevClip& c, int count, float pos[3], f
 // coalesced row loads (lanes 0..18 read one 19-float frame row), then lanes 0..nt-1 blend serially.
 // Result: S.ph.end.pose[l] = raw (no origin offset) pose; if with_vel, S.vel = raw frame velocity at time of lane 0.
 // Warm-up poses (imitation_task.py:985-1009) are substituted where `warm` and -warmup <= t < 0.
-__device__ static void sample_poses(const KParams& P, Shared& S, int lane, float t_lane, bool with_vel, int pt_slot = 32) {
+// Two halves, so that the round trip of the frame loads can be covered by independent work of the caller: sample_poses_issue
+// computes the frame indices and issues the loads (into registers), sample_poses_finish stages and blends them.
+struct PoseLoads {
+  float lo[11], hi[11], v0[2], v1[2];   // frame rows: word `lane` and, for lanes 0..2, word 16 + lane; frame velocities of lane 0's time
+  Sample sm;
+};
+__device__ static void sample_poses_issue(const KParams& P, Shared& S, int lane, float t_lane, PoseLoads& L, int pt_slot = 32) {
   constexpr int nt = 5;   // update time + the four target times (compile-time: the staging arrays below must stay in registers)
-  const DevClip& c = P.tab->clip[geti(S, O(CLIP_ID))];
-  const bool warm_ep = geti(S, O(WARMUP)) != 0;
-  Sample sm = clip_index(c, lane < nt ? t_lane : 0.0f);
+  const DevClip& c = S.clip;
+  const Sample sm = clip_index(c, lane < nt ? t_lane : 0.0f);
+  L.sm = sm;
   if (lane < nt) { S.ph.end.red[2 * lane] = __int_as_float(sm.f0); S.ph.end.red[2 * lane + 1] = __int_as_float(sm.f1); }
   WSYNC();
   PT(pt_slot);
   {
-    // The clip pointers come out of a device table, i.e. as generic pointers: loads through them would be FLAT instructions,
-    // which also count on the LDS counter, so every LDS access in between would wait for the previous frame to arrive (13
-    // serialised round trips).  They point to global memory (orr_set_motion takes device pointers): say so, fetch all rows
-    // first (frame row = 19 words: lane i and, for lanes 0..2, word 16 + i), then stage them.
+    // The clip pointers come out of a table, i.e. as generic pointers: loads through them would be FLAT instructions, which also
+    // count on the LDS counter, so every LDS access in between would wait for the previous frame to arrive (13 serialised round
+    // trips).  They point to global memory (orr_set_motion takes device pointers): say so, fetch all rows at once (frame row = 19
+    // words: lane i and, for lanes 0..2, word 16 + i).
     typedef const float __attribute__((address_space(1))) * gptr;
     const gptr frames = (gptr)c.frames, vels = (gptr)c.vels;
     constexpr int kMaxE = 2 * nt;
-    float lo[kMaxE + 1], hi[kMaxE + 1], v0[2], v1[2];
     const int w1 = lane < 3 ? 16 + lane : lane;
 #pragma unroll
     for (int e = 0; e < kMaxE; e++) {
       const int f = __float_as_int(S.ph.end.red[e]);
-      lo[e] = frames[f * 19 + lane]; hi[e] = frames[f * 19 + w1];
+      L.lo[e] = frames[f * 19 + lane]; L.hi[e] = frames[f * 19 + w1];
     }
-    lo[kMaxE] = frames[lane]; hi[kMaxE] = frames[w1];                       // frame 0 (warm-up heading)
-    {
-      const int f0 = __float_as_int(S.ph.end.red[0]), f1 = __float_as_int(S.ph.end.red[1]);
-      const int w2 = lane < 2 ? 16 + lane : lane;
-      v0[0] = vels[f0 * 18 + lane]; v0[1] = vels[f0 * 18 + w2];
-      v1[0] = vels[f1 * 18 + lane]; v1[1] = vels[f1 * 18 + w2];
-    }
+    L.lo[kMaxE] = frames[lane]; L.hi[kMaxE] = frames[w1];                       // frame 0 (warm-up heading)
+    const int f0 = __float_as_int(S.ph.end.red[0]), f1 = __float_as_int(S.ph.end.red[1]);
+    const int w2 = lane < 2 ? 16 + lane : lane;
+    L.v0[0] = vels[f0 * 18 + lane]; L.v0[1] = vels[f0 * 18 + w2];
+    L.v1[0] = vels[f1 * 18 + lane]; L.v1[1] = vels[f1 * 18 + w2];
+  }
+  WSYNC();   // red[] may be reused by the caller from here on
+}
+__device__ static void sample_poses_finish(const KParams& P, Shared& S, int lane, float t_lane, bool with_vel, const PoseLoads& L, int pt_slot = 32) {
+  constexpr int nt = 5, kMaxE = 2 * nt;
+  const DevClip& c = S.clip;
+  const bool warm_ep = geti(S, O(WARMUP)) != 0;
+  const Sample sm = L.sm;
 #pragma unroll
-    for (int e = 0; e <= kMaxE; e++) {
-      S.ph.end.frames[e][lane] = lo[e];
-      if (lane < 3) S.ph.end.frames[e][16 + lane] = hi[e];
-    }
-    if (with_vel) {
-      S.ph.end.fvel[0][lane] = v0[0]; S.ph.end.fvel[1][lane] = v1[0];
-      if (lane < 2) { S.ph.end.fvel[0][16 + lane] = v0[1]; S.ph.end.fvel[1][16 + lane] = v1[1]; }
-    }
+  for (int e = 0; e <= kMaxE; e++) {
+    S.ph.end.frames[e][lane] = L.lo[e];
+    if (lane < 3) S.ph.end.frames[e][16 + lane] = L.hi[e];
+  }
+  if (with_vel) {
+    S.ph.end.fvel[0][lane] = L.v0[0]; S.ph.end.fvel[1][lane] = L.v1[0];
+    if (lane < 2) { S.ph.end.fvel[0][16 + lane] = L.v0[1]; S.ph.end.fvel[1][16 + lane] = L.v1[1]; }
   }
   WSYNC();
   PT(pt_slot + 1);
@@ -149,6 +159,11 @@ __device__ static void sample_poses(const KParams& P, Shared& S, int lane, float
     }
   }
   WSYNC();
+}
+__device__ static void sample_poses(const KParams& P, Shared& S, int lane, float t_lane, bool with_vel, int pt_slot = 32) {
+  PoseLoads L;
+  sample_poses_issue(P, S, lane, t_lane, L, pt_slot);
+  sample_poses_finish(P, S, lane, t_lane, with_vel, L, pt_slot);
 }
 
 // apply the origin offset (imitation_task.py:938-951) to S.ph.end.pose[l] in place (lane l < nt)
@@ -376,22 +391,9 @@ __device__ static void reset_robot(const KParams& P, float* rec, Shared& S, int 
   }
   WSYNC();
   PT(16);
-  // ring entries #1 and #2 of the new episode are kept (LDS) so that the control observations of the reset are blended from them
-  // directly: reading the ring back would be a store -> load round trip through memory each time
-  float* e1 = S.ph.end.red;            // 20 words each; red[] is free here (sample_poses uses red[0..9] later: e1 is consumed before)
-  receive_obs(rec, S, lane, valid, e1);  // ring entry #1
-  // 3. sensor histories <- 3 copies of the current readings (minitaur.py:270-271; sensor_wrappers.py:122-129)
-  PT(17);
-  WSYNC();
-  for (int i = lane; i < 19; i += kLanes) S.co[i] = e1[i];   // one entry in the ring: _get_delay_obs returns it (minitaur.py:345-346)
-  WSYNC();
-  PT(29);
-  sensors_push(S, lane, true);
-  const float e1_keep[2] = {e1[lane], e1[lane < 3 ? 16 + lane : lane]};   // ring entry #1: words lane and (lanes 0..2) 16 + lane
-  PT(18);
-  // 4. randomiser (controllable_env_randomizer_from_config.py:92-122), sorted-name draw order:
-  //    inertia 2 | joint friction 8 | latency 1 | lateral friction 1 | mass 2 | motor strength 12
-  // all 28 draws of the episode (0..25 randomiser, 26 ref-state-init, 27 time offset) = 7 Philox blocks: lane b < 7 evaluates
+  // Order of the stages below: what needs global memory is started first (the episode's draws fix the start time, hence the clip
+  // frames; the model's mass table), the stages that need nothing from memory run while those loads are in flight.
+  // 4a. all 28 draws of the episode (0..25 randomiser, 26 ref-state-init, 27 time offset) = 7 Philox blocks: lane b < 7 evaluates
   // block b once and parks its four numbers in LDS
   float* draws = S.ph.end.red + 24;    // 28 words
   static_assert(kLanes == 16, "reset_robot / sample_poses assume 16 lanes per robot");
@@ -403,24 +405,8 @@ __device__ static void reset_robot(const KParams& P, float* rec, Shared& S, int 
   }
   WSYNC();
   PT(24);
-  if (c.flags & ORR_FLAG_RANDOMIZER) {
-    for (int i = lane; i < 26; i += kLanes) {
-      const float u = draws[i];
-      if (i < 2) S.s[O(INERTIA_RATIO) + i] = 0.5f + u * 1.0f;
-      else if (i < 10) { if (((i - 2) & 1) == 0) S.s[O(KNEE_FRICTION) + ((i - 2) >> 1)] = u * 0.05f; }
-      else if (i == 10) S.s[O(LATENCY)] = u * 0.04f;
-      else if (i == 11) S.s[O(FOOT_MU)] = 0.5f + u * 0.75f;
-      else if (i < 14) S.s[O(MASS_RATIO) + i - 12] = 0.8f + u * 0.4f;
-      else S.s[O(STRENGTH) + i - 14] = 0.8f + u * 0.4f;
-    }
-    WSYNC();
-    PT(25);
-    refresh_mass(P.tab->model[geti(S, O(ROBOT_TYPE))], S, lane);
-    WSYNC();
-  }
-  PT(19);
-  // 5. task reset (imitation_task.py:183-199, 694-732, 1103-1110)
-  const DevClip& clip = P.tab->clip[geti(S, O(CLIP_ID))];
+  // 5a. task reset (imitation_task.py:183-199, 694-732, 1103-1110): start time -> frame loads issued
+  const DevClip& clip = S.clip;
   {
     const float u1 = draws[26], u2 = draws[27];
     const bool ref_init = u1 < c.ref_state_init_prob;
@@ -438,7 +424,43 @@ __device__ static void reset_robot(const KParams& P, float* rec, Shared& S, int 
   float tl = t;
   if (lane >= 1 && lane <= 4) tl = t + c.tar_frame_steps[lane - 1] * step_dt;
   PT(20);
-  sample_poses(P, S, lane, tl, true, 26);
+  PoseLoads PL;
+  sample_poses_issue(P, S, lane, tl, PL, 26);     // uses red[0..9] until it returns
+  MassLoads ML;
+  if (c.flags & ORR_FLAG_RANDOMIZER) mass_prefetch(P.tab->model[geti(S, O(ROBOT_TYPE))], lane, ML);
+  PT(19);
+  // ring entries #1 and #2 of the new episode are kept (LDS) so that the control observations of the reset are blended from them
+  // directly: reading the ring back would be a store -> load round trip through memory each time
+  float* e1 = S.ph.end.red;            // 20 words each
+  receive_obs(rec, S, lane, valid, e1);  // ring entry #1
+  // 3. sensor histories <- 3 copies of the current readings (minitaur.py:270-271; sensor_wrappers.py:122-129)
+  PT(17);
+  WSYNC();
+  for (int i = lane; i < 19; i += kLanes) S.co[i] = e1[i];   // one entry in the ring: _get_delay_obs returns it (minitaur.py:345-346)
+  WSYNC();
+  PT(29);
+  sensors_push(S, lane, true);
+  const float e1_keep[2] = {e1[lane], e1[lane < 3 ? 16 + lane : lane]};   // ring entry #1: words lane and (lanes 0..2) 16 + lane
+  PT(18);
+  // 4b. randomiser (controllable_env_randomizer_from_config.py:92-122), sorted-name draw order:
+  //    inertia 2 | joint friction 8 | latency 1 | lateral friction 1 | mass 2 | motor strength 12
+  if (c.flags & ORR_FLAG_RANDOMIZER) {
+    for (int i = lane; i < 26; i += kLanes) {
+      const float u = draws[i];
+      if (i < 2) S.s[O(INERTIA_RATIO) + i] = 0.5f + u * 1.0f;
+      else if (i < 10) { if (((i - 2) & 1) == 0) S.s[O(KNEE_FRICTION) + ((i - 2) >> 1)] = u * 0.05f; }
+      else if (i == 10) S.s[O(LATENCY)] = u * 0.04f;
+      else if (i == 11) S.s[O(FOOT_MU)] = 0.5f + u * 0.75f;
+      else if (i < 14) S.s[O(MASS_RATIO) + i - 12] = 0.8f + u * 0.4f;
+      else S.s[O(STRENGTH) + i - 14] = 0.8f + u * 0.4f;
+    }
+    WSYNC();
+    refresh_mass_from(ML, S, lane);
+    WSYNC();
+  }
+  PT(25);
+  // 5b. the reference poses of the start time
+  sample_poses_finish(P, S, lane, tl, true, PL, 26);
   PT(21);
   if (lane == 0) {
     // origin offset: position first (with identity rotation), then rotation; position is NOT recomputed

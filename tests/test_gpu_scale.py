@@ -78,7 +78,7 @@ def test_episode_log_row_j():
     env.reset(); orc.reset()
     orc.state[:] = gpu_state64(env)
     rng = np.random.RandomState(2)
-    ret_g, len_g, ret_o = np.zeros(n), np.zeros(n, dtype=int), np.zeros(n)
+    ret_g, len_g, ret_o, len_o = np.zeros(n), np.zeros(n, dtype=int), np.zeros(n), np.zeros(n, dtype=int)
     exp_g, exp_o = [], []               # episodes reconstructed from the per-step (reward, done) outputs
     agree = np.ones(n, dtype=bool)      # done history identical on both sides so far
     pairs = []                          # (robot, device return, oracle return, length) of episodes with identical done history
@@ -87,19 +87,22 @@ def test_episode_log_row_j():
         og, rg, dg, _ = env.step(torch.from_numpy(a).to(env.device))
         oo, ro, do = orc.step(a.astype(np.float64))
         rg, dg = rg.cpu().numpy().astype(np.float64), dg.cpu().numpy().astype(bool)
-        ret_g += rg; len_g += 1; ret_o += ro
+        ret_g += rg; len_g += 1; ret_o += ro; len_o += 1
         for i in np.nonzero(dg)[0]:
             exp_g.append((len_g[i], ret_g[i]))
         for i in np.nonzero(do)[0]:
-            exp_o.append((len_g[i], ret_o[i]))
+            exp_o.append((len_o[i], ret_o[i]))
         for i in np.nonzero(dg & do & agree)[0]:
             pairs.append((i, ret_g[i], ret_o[i], len_g[i]))
         agree &= (dg == do)
-        fin = dg | do
-        ret_g[fin] = 0; len_g[fin] = 0; ret_o[fin] = 0
-        # after a disagreement the two sides are in different episodes: re-synchronise the oracle to the device
+        ret_g[dg] = 0; len_g[dg] = 0          # each side's episodes end on its own done flags
+        ret_o[do] = 0; len_o[do] = 0
+        # after a disagreement the two sides are in different episodes: re-synchronise the oracle to the device (state and episode
+        # bookkeeping: the state record carries the episode step counter and the running return)
         if (dg != do).any():
             orc.state[:] = gpu_state64(env)
+            dis = dg != do
+            ret_o[dis] = ret_g[dis]; len_o[dis] = len_g[dis]
     torch.cuda.synchronize()
     n_eps = int(env.counters[_abi.CNT_EPISODES].item())
     assert n_eps == len(exp_g) and n_eps >= n          # 20-step limit: every robot finishes at least once in 25 steps

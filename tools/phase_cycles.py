@@ -46,14 +46,14 @@ for n, v in zip(NAMES, buf[:16]):
     print("  %-22s %9.0f  %5.1f%%" % (n, v / steps, 100.0 * v / tot))
 print("steps with a reset in the instrumented wave: %d of %d (robot resets: %s); cycles per such step in 'episode end/reset': %.0f"
       % (events, steps, dones.tolist(), buf[14] / max(events, 1)))
-RESET = ["state defaults", "ring entry #1", "ctrl obs + sensor fill", "randomiser draws", "task draws", "clip sampling", "origin + teleport",
-         "ring entry #2 + time limit"]
-print("stages of reset_robot, cycles per reset of robot 0 of the wave (the last stage, target observation, is timed inside 'episode end/reset'):")
-for n, v in zip(RESET, buf[16:24]):
-    print("  %-28s %9.0f" % (n, v / max(int(dones[0]), 1)))
-FINE = {24: "  philox blocks (inside randomiser draws, up to here)", 25: "  scatter of the draws", 26: "  clip_index (inside clip sampling)",
-        27: "  frame loads + staging", 29: "  ctrl obs copy (inside ctrl obs + sensor fill)", 30: "target observation",
-        31: "episode log + entry (before reset_robot)"}
-print("finer marks (cycles per reset of robot 0; a mark closes the interval since the previous mark of any kind):")
-for k in sorted(FINE):
-    print("  %-60s %9.0f" % (FINE[k], buf[k] / max(int(dones[0]), 1)))
+print("stages of reset_robot in program order, cycles per reset of robot 0 of the wave (a mark closes the interval since the previous one):")
+RESET = [(16, "state defaults"), (24, "Philox blocks (28 draws)"), (20, "task draws: start time"), (26, "frame indices (clip_index)"),
+         (19, "frame + mass-table loads issued"), (17, "ring entry #1"), (29, "control observation copy"), (18, "sensor histories"),
+         (25, "randomiser scatter + mass refresh"), (27, "frames staged to LDS"), (21, "pose blend"), (22, "origin + teleport"),
+         (23, "ring entry #2 + time limit"), (30, "target observation"), (31, "episode log + entry (before reset_robot)")]
+tot_r = 0.0
+for k, n in RESET:
+    v = buf[k] / max(int(dones[0]), 1)
+    tot_r += v
+    print("  %-40s %9.0f" % (n, v))
+print("  %-40s %9.0f" % ("sum", tot_r))
