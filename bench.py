@@ -151,7 +151,7 @@ def main():
     torch.cuda.set_device(dev)
     env_kw, n, workload = CONFIGS[args.config]
     n = args.robots_per_gpu or n
-    env = VecQuadrupedEnv(num_robot=n, mode="train", enable_randomizer=True, auto_reset=True, seed=0, device=dev,
+    env = VecQuadrupedEnv(num_robot=n, mode="train", enable_randomizer=True, auto_reset=True, seed=int(os.environ.get("ORR_BENCH_SEED", "0")), device=dev,
                           num_procs=world, robot_index_offset=rank * n, **env_kw)
     # action = (target joint pose -> motor space) - init + noise; the joint -> motor permutation and direction signs are one
     # 12x12 matrix per robot type, noise and constant terms are pre-combined: one (batched) GEMM launch per step

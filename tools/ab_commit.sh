@@ -15,6 +15,7 @@ if [ "$1" = build ]; then
 fi
 R=${2:-3}
 for i in $(seq 1 $R); do
+  export ORR_BENCH_SEED=$((i - 1))    # a different episode stream per round: changes of numerics move the workload (contacts, joint limits, resets) by +-1 %
   for W in old new; do
     if [ $W = old ]; then export ORR_LIB_PATH=$ROOT/openroborl_amd/lib_ab_old.so; else unset ORR_LIB_PATH; fi
     python3 $ROOT/bench.py --steps 1500 --warmup 100 --no-cpu-baseline 2>/dev/null | python3 -c "

@@ -76,12 +76,23 @@ __global__ __launch_bounds__(64) void k(long long* out, float* sink) {
     T0(); asm volatile(REP256("ds_write_b32 %0, %1\n\tds_read_b32 v100, %0\n\ts_waitcnt lgkmcnt(0)\n\tv_add_u32 %0, %0, v100\n\t") : "+v"(addr) : "v"(0.0f) : "memory", "v100"); T1(36);
     T0(); asm volatile(REP256("ds_bpermute_b32 v100, %0, %1\n\ts_waitcnt lgkmcnt(0)\n\tv_add_f32 %1, %1, v100\n\t") : "+v"(addr), "+v"(a) : : "memory", "v100"); T1(37);
   }
+  {
+    v2f p1 = {1.5f, 2.5f}, p2 = {0.5f, 0.25f}, p3 = {3.0f, 4.0f};
+    T0(); asm volatile(REP256("v_pk_fma_f32 %0, %1, %2, %0\n\t") : "+v"(p) : "v"(p1), "v"(p2)); T1(38);                       // 3 distinct 64-bit sources
+    T0(); asm volatile(REP256("v_pk_fma_f32 %0, %2, %3, %0\n\tv_pk_fma_f32 %1, %2, %3, %1\n\t") : "+v"(p), "+v"(p3) : "v"(p1), "v"(p2)); T1(39);   // two independent
+    T0(); asm volatile(REP256("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]\n\t") : "+v"(p) : "v"(p1), "v"(p2)); T1(40);     // scalar splat
+    T0(); asm volatile(REP256("v_pk_mul_f32 %0, %1, %0\n\t") : "+v"(p) : "v"(p1)); T1(41);
+    T0(); asm volatile(REP256("v_pk_add_f32 %0, %1, %0\n\t") : "+v"(p) : "v"(p1)); T1(42);
+    T0(); asm volatile(REP256("v_fma_f32 %0, %1, %2, %0\n\t") : "+v"(a) : "v"(b), "v"(c)); T1(43);                               // scalar, 3 distinct sources
+    T0(); asm volatile(REP256("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]\n\t") : "+v"(p) : "v"(p1), "v"(p2)); T1(44);
+    sink[threadIdx.x + 64] = p1.x + p2.x + p3.x;
+  }
   sink[threadIdx.x] = a + b + c + d + (float)addr + (float)s0 + p.x + q.x;
 }
 
 int main() {
   long long* out; float* sink;
-  (void)hipMalloc(&out, 64 * sizeof(long long)); (void)hipMalloc(&sink, 64 * sizeof(float));
+  (void)hipMalloc(&out, 64 * sizeof(long long)); (void)hipMalloc(&sink, 128 * sizeof(float));
   (void)hipMemset(out, 0, 64 * sizeof(long long));
   const char* names[] = {"empty (timer overhead)", "v_fma dependent chain", "2 independent v_fma (per pair)", "v_fma + s_nop 0", "v_fma + s_nop 1",
                          "v_fma + s_add", "v_fma + s_nop 1 + v_mov_dpp", "v_pk_fma_f32 dependent", "ds_read_b32 dependent round trip (+waitcnt +v_add)",
@@ -92,13 +103,15 @@ int main() {
                          "saveexec(sgpr mask) + v_fma + s_or exec", "saveexec + cbranch_execz (not taken) + v_fma + s_or", "v_cmp + saveexec(vcc) + v_fma + s_or",
                          "s_mov exec + v_fma + s_mov exec", "saveexec + cbranch_execz (TAKEN) + s_or", "s_cmp + s_cbranch_scc (not taken) + v_fma",
                          "s_cmp + s_cbranch_scc (TAKEN over 1) + v_fma", "v_cndmask with sgpr mask", "ds_read2_b32 round trip", "ds_read_b64 round trip",
-                         "ds_write + ds_read same address round trip", "ds_bpermute round trip"};
+                         "ds_write + ds_read same address round trip", "ds_bpermute round trip",
+                         "v_pk_fma_f32, 3 distinct sources (dependent)", "2 independent v_pk_fma_f32 (per pair)", "v_pk_fma_f32 with op_sel splat",
+                         "v_pk_mul_f32 dependent", "v_pk_add_f32 dependent", "v_fma_f32, 3 distinct sources", "v_pk_fma_f32 with op_sel swap + neg"};
   for (int rep = 0; rep < 2; rep++) {
     hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, out, sink);
     (void)hipDeviceSynchronize();
   }
   long long h[64];
   (void)hipMemcpy(h, out, sizeof(h), hipMemcpyDeviceToHost);
-  for (int i = 0; i < 38; i++) printf("%-52s %8.2f cycles per repetition\n", names[i], (double)(h[i] - h[0]) / 256.0);
+  for (int i = 0; i < 45; i++) printf("%-52s %8.2f cycles per repetition\n", names[i], (double)(h[i] - h[0]) / 256.0);
   return 0;
 }
