@@ -229,6 +229,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
   PT(12);
   // _terminal_condition (imitation_task.py:518-572) + time limit (wrapper_env.py:79) + non-finite guard
   int reason = 0;
+  unsigned long long log_slot;   // deliberately not initialised: a merged value would make the compiler wait for the atomic right away
   {
     const float* rp = &S.s[O(REF_POSE)];
     float pe = 0.0f, qc[4], dq[4];
@@ -247,6 +248,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
     if (!(fabsf(rew) < 1e30f)) { reason |= ORR_DONE_NAN; rew = 0.0f; }
     const int ep_step = geti(S, O(EP_STEP)) + 1;  // quadruped_gym_env.py:237
     if (ep_step >= geti(S, O(MAX_EP_STEPS))) reason |= ORR_DONE_TIME_LIMIT;
+    // episode log (imitation_runners.py:185-197): the slot comes from a returning atomic on a counter shared by the whole device (a
+    // round trip of several microseconds).  It is issued HERE, as soon as the end of the episode is known, and consumed after the
+    // reset: the observation, the target observation and the first stages of the reset run while it is in flight
+    if (lane == 0 && valid && reason != 0) log_slot = atomicAdd((unsigned long long*)&P.counters[ORR_CNT_EPISODES], 1ull);
     WSYNC();
     if (lane == 0) {
       seti(S, O(EP_STEP), ep_step);
@@ -264,12 +269,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
   }
   PT(13);
   if (reason != 0) {
-    // episode log (imitation_runners.py:185-197): the slot comes from a returning atomic; it is issued first and consumed after
-    // the reset, so its round trip to L2 overlaps the reset instead of stalling in front of it
-    unsigned long long slot;   // deliberately not initialised: a merged value would make the compiler wait for the atomic right away
     float log_ret = 0.0f, log_len = 0.0f;
     const bool logs = lane == 0 && valid;
-    if (logs) slot = atomicAdd((unsigned long long*)&P.counters[ORR_CNT_EPISODES], 1ull);
+    const unsigned long long slot = log_slot;
     if (lane == 0) {
       log_ret = S.s[O(EP_RETURN)]; log_len = (float)geti(S, O(EP_STEP));
       S.s[O(LAST_EP_RETURN)] = log_ret;
