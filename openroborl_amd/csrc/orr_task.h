@@ -422,7 +422,12 @@ __device__ static void reset_robot(const KParams& P, float* rec, Shared& S, int 
   const float t = motion_time(P, S);
   const float step_dt = c.sim_dt * c.action_repeat;
   float tl = t;
-  if (lane >= 1 && lane <= 4) tl = t + c.tar_frame_steps[lane - 1] * step_dt;
+  {  // lanes 1..4: the four target times.  Selects over the four scalars: indexing the kernel argument with the lane makes the
+     // compiler read it from memory with a vector load, whose wait also drains every store and atomic issued before it
+    const int k = lane - 1;
+    const int steps = (k & 2) ? ((k & 1) ? c.tar_frame_steps[3] : c.tar_frame_steps[2]) : ((k & 1) ? c.tar_frame_steps[1] : c.tar_frame_steps[0]);
+    if (lane >= 1 && lane <= 4) tl = t + steps * step_dt;
+  }
   PT(20);
   PoseLoads PL;
   sample_poses_issue(P, S, lane, tl, PL, 26);     // uses red[0..9] until it returns
