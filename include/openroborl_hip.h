@@ -131,7 +131,7 @@ typedef struct orr_config {
   float contact_erp;         /* 0.2 */
   float contact_margin;      /* 0.02 contact breaking threshold */
   float warmstart_factor;    /* 0.85 */
-  float max_coord_velocity;  /* 100 */
+  float max_coord_velocity;  /* 100; orr_create refuses sqrt(3) * max_coord_velocity * sim_dt / 2 >= 0.2 (the base may turn at most 0.4 rad per sub-step) */
   float plane_friction;      /* 1.0 plane_implicit.urdf */
   float limit_activation;    /* 0.1 rad: a joint-limit row exists iff the joint is this close */
   float max_angle_change;    /* 0.2: laikago.py:71 MAX_MOTOR_ANGLE_CHANGE_PER_STEP */
@@ -150,7 +150,7 @@ typedef struct orr_model {
   float init_pos[3];                    /* laikago.py:48 / mini_cheetah.py:49 */
   float init_quat[4];                   /* laikago.py:49 / mini_cheetah.py:50 */
   float init_motor_angles[ORR_NUM_MOTORS]; /* motor order; laikago.py:62 */
-  float motor_dir[ORR_NUM_MOTORS];      /* JOINT_DIRECTIONS, motor order */
+  float motor_dir[ORR_NUM_MOTORS];      /* JOINT_DIRECTIONS, motor order; +1 or -1 (orr_set_model refuses anything else) */
   float motor_offset[ORR_NUM_MOTORS];   /* JOINT_OFFSETS, motor order */
   int32_t joint_of_motor[ORR_NUM_MOTORS]; /* URDF joint index driven by motor m (MOTOR_NAMES order) */
   float kp[ORR_NUM_MOTORS];             /* motor order; laikago.py:65 */

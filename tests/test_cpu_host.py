@@ -99,6 +99,11 @@ def test_bad_arguments_are_reported_not_thrown():
     cfg = config.make_config(4)
     cfg.num_robots = 0
     assert L.orr_create(C.byref(cfg), C.byref(h)) < 0
+    # the quaternion step of the kernel is a series in the rotation of one sub-step: a velocity clamp that would let the base turn
+    # more than 0.4 rad per sub-step is refused
+    cfg = config.make_config(4)
+    cfg.max_coord_velocity = 1000.0
+    assert L.orr_create(C.byref(cfg), C.byref(h)) < 0 and b"max_coord_velocity" in L.orr_last_error()
     # no GPU in the build container: creation must fail loudly instead of falling back to the CPU
     import torch
     if not torch.cuda.is_available():

@@ -226,3 +226,21 @@ def test_done_disagreements_are_threshold_cases(robot):
     assert n_done > n // 20, n_done               # the sample really contains terminations
     assert n_dis <= max(3, n_done // 20), (n_dis, n_done)
     env.close(); orc.close()
+
+
+def test_model_and_config_preconditions_of_the_kernel_are_checked():
+    """The step kernel integrates a joint angle as q += jdir dt v and stores rotations as series in the turn of one sub-step: the
+    host entry points refuse a model with |motor_dir| != 1 (the reference's directions are +-1) and keep working otherwise."""
+    import ctypes as C
+    from openroborl_amd import _lib, robots
+    from openroborl_amd.env import VecQuadrupedEnv
+    env = VecQuadrupedEnv(task_name="imitation_learning_laikago", num_robot=8, seed=1)
+    t = next(i for i, mod in enumerate(env.models) if mod is not None)
+    m = robots.to_struct(env.models[t])
+    good = m.motor_dir[3]
+    m.motor_dir[3] = 0.5
+    rc = env.L.orr_set_model(env.h, t, C.byref(m))
+    assert rc < 0 and b"motor_dir" in env.L.orr_last_error()
+    m.motor_dir[3] = good
+    assert env.L.orr_set_model(env.h, t, C.byref(m)) == 0
+    env.close()
