@@ -86,6 +86,15 @@ __global__ __launch_bounds__(64) void k(long long* out, float* sink) {
     T0(); asm volatile(REP256("v_fma_f32 %0, %1, %2, %0\n\t") : "+v"(a) : "v"(b), "v"(c)); T1(43);                               // scalar, 3 distinct sources
     T0(); asm volatile(REP256("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]\n\t") : "+v"(p) : "v"(p1), "v"(p2)); T1(44);
     sink[threadIdx.x + 64] = p1.x + p2.x + p3.x;
+    // LDS issue cost by width: independent operations (no wait inside the block), 4 VALU between them
+    T0(); asm volatile(REP256("ds_read_b32 v100, %0\n\t") : : "v"(addr) : "memory", "v100"); T1(45);
+    T0(); asm volatile(REP256("ds_read_b64 v[100:101], %0\n\t") : : "v"(addr & ~7) : "memory", "v100", "v101"); T1(46);
+    T0(); asm volatile(REP256("ds_read_b128 v[100:103], %0\n\t") : : "v"(addr & ~15) : "memory", "v100", "v101", "v102", "v103"); T1(47);
+    T0(); asm volatile(REP256("ds_read2_b32 v[100:101], %0 offset1:8\n\t") : : "v"(addr) : "memory", "v100", "v101"); T1(48);
+    T0(); asm volatile(REP256("ds_write_b64 %0, %1\n\t") : : "v"(addr & ~7), "v"(p1) : "memory"); T1(49);
+    T0(); asm volatile(REP256("ds_write_b128 %0, %1\n\t") : : "v"(addr & ~15), "v"(q) : "memory"); T1(50);
+    T0(); asm volatile(REP256("ds_read_b128 v[100:103], %1\n\tv_fma_f32 %0, %0, %2, %0\n\tv_fma_f32 %0, %0, %2, %0\n\tv_fma_f32 %0, %0, %2, %0\n\tv_fma_f32 %0, %0, %2, %0\n\t") : "+v"(a) : "v"(addr & ~15), "v"(kf) : "memory", "v100", "v101", "v102", "v103"); T1(51);
+    T0(); asm volatile(REP256("ds_read_b32 v100, %1\n\tv_fma_f32 %0, %0, %2, %0\n\tv_fma_f32 %0, %0, %2, %0\n\tv_fma_f32 %0, %0, %2, %0\n\tv_fma_f32 %0, %0, %2, %0\n\t") : "+v"(a) : "v"(addr), "v"(kf) : "memory", "v100"); T1(52);
   }
   sink[threadIdx.x] = a + b + c + d + (float)addr + (float)s0 + p.x + q.x;
 }
@@ -105,13 +114,15 @@ int main() {
                          "s_cmp + s_cbranch_scc (TAKEN over 1) + v_fma", "v_cndmask with sgpr mask", "ds_read2_b32 round trip", "ds_read_b64 round trip",
                          "ds_write + ds_read same address round trip", "ds_bpermute round trip",
                          "v_pk_fma_f32, 3 distinct sources (dependent)", "2 independent v_pk_fma_f32 (per pair)", "v_pk_fma_f32 with op_sel splat",
-                         "v_pk_mul_f32 dependent", "v_pk_add_f32 dependent", "v_fma_f32, 3 distinct sources", "v_pk_fma_f32 with op_sel swap + neg"};
+                         "v_pk_mul_f32 dependent", "v_pk_add_f32 dependent", "v_fma_f32, 3 distinct sources", "v_pk_fma_f32 with op_sel swap + neg",
+                         "ds_read_b32 back to back (issue)", "ds_read_b64 back to back", "ds_read_b128 back to back", "ds_read2_b32 back to back",
+                         "ds_write_b64 back to back", "ds_write_b128 back to back", "ds_read_b128 + 4 v_fma (no wait)", "ds_read_b32 + 4 v_fma (no wait)"};
   for (int rep = 0; rep < 2; rep++) {
     hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, out, sink);
     (void)hipDeviceSynchronize();
   }
   long long h[64];
   (void)hipMemcpy(h, out, sizeof(h), hipMemcpyDeviceToHost);
-  for (int i = 0; i < 45; i++) printf("%-52s %8.2f cycles per repetition\n", names[i], (double)(h[i] - h[0]) / 256.0);
+  for (int i = 0; i < 53; i++) printf("%-52s %8.2f cycles per repetition\n", names[i], (double)(h[i] - h[0]) / 256.0);
   return 0;
 }
