@@ -143,7 +143,9 @@ def model_from_urdf(text, template, names):
                 m["link_mass"][j], m["link_com"][j], m["link_inertia"][j] = ld["mass"], c, _sym6(I)
                 m["link_inertia_pa"][j] = 0.0
             else:      # lower leg + fixed toe merged for the dynamics (robots.py _build)
-                td = joints[names["toes"][leg]]
+                td = joints.get(names["toes"][leg])
+                if td is None:    # other naming: the fixed joint behind the lower leg (robots/laikago.py:45 `jtoe\d*`, mini_cheetah.py:45 `toe_`)
+                    td = next(jj for jj in joints.values() if jj["parent"] == jd["child"] and jj["type"] == "fixed")
                 tl = links[td["child"]]
                 Wt = Wc @ td["R"]
                 c_t = Wc @ td["xyz"] + Wt @ tl["com"]
