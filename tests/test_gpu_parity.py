@@ -491,3 +491,26 @@ def test_shipped_minicheetah_policy_probe():
     assert 100.0 < mean_len < 450.0        # measured 158 (no robot finishes); far from the 600 the Laikago policy reaches
     assert rps > 0.4                       # while it is up it tracks the clip
     env.close()
+
+
+@pytest.mark.parametrize("n", [1, 5, 7])
+def test_robot_counts_that_do_not_fill_a_wavefront(n):
+    """Four robots share a wavefront; when N is not a multiple of four the spare lane groups shadow robot 0 and must neither store
+    nor disturb their neighbours (every lane stores into LDS unconditionally since round 2): reset + two env steps with auto-reset
+    against the oracle, and the buffers behind the last robot stay untouched."""
+    import torch
+    env, orc = make_pair("laikago", n=n, randomizer=True, auto_reset=True, mode="train", seed=13)
+    og = env.reset().cpu().numpy(); oo = orc.reset()
+    np.testing.assert_allclose(og, oo, atol=5e-4)
+    orc.state[:] = gpu_state64(env)
+    rng = np.random.RandomState(n)
+    for _ in range(2):
+        a = rng.uniform(-0.2, 0.2, (n, 12)).astype(np.float32)
+        og, rg, dg, _ = env.step(torch.from_numpy(a).to(env.device))
+        oo, ro, do = orc.step(a.astype(np.float64))
+        assert og.shape == (n, 160) and rg.shape == (n,) and np.isfinite(og.cpu().numpy()).all()
+        np.testing.assert_allclose(rg.cpu().numpy(), ro, atol=3e-3)
+        np.testing.assert_allclose(og.cpu().numpy()[:, 12:84], oo[:, 12:84], atol=5e-4)
+        orc.state[:] = gpu_state64(env)
+    assert int(env.counters[_abi.CNT_TOTAL_TIMESTEPS].item()) == 2 * n      # the padding groups are not counted
+    env.close(); orc.close()
