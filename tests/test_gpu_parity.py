@@ -514,3 +514,29 @@ def test_robot_counts_that_do_not_fill_a_wavefront(n):
         orc.state[:] = gpu_state64(env)
     assert int(env.counters[_abi.CNT_TOTAL_TIMESTEPS].item()) == 2 * n      # the padding groups are not counted
     env.close(); orc.close()
+
+
+@pytest.mark.parametrize("iters", [1, 2, 4, 7])
+def test_physics_substep_parity_other_solver_iteration_counts(iters):
+    """The Gauss-Seidel loop of the kernel runs three sweeps per iteration and the remaining ones singly: iteration counts that are not
+    the reference's 9 (numSolverIterations, quadruped_gym_env.py:165) take the other entry and exit paths of that loop."""
+    import torch
+    from openroborl_amd.env import VecQuadrupedEnv
+    from tests.parity_inputs import substep_parity_inputs
+    n = 64
+    env = VecQuadrupedEnv(num_robot=n, seed=3, robot="laikago", motion_file=CLIP["laikago"], mode="test", enable_randomizer=False,
+                          auto_reset=False, config_overrides=dict(solver_iters=iters))
+    assert env.cfg.solver_iters == iters
+    orc = ol.OracleEnv(env.cfg, env.models, env.clips, n, robot_type=env.robot_type, clip_id=env.clip_id, threads=8)
+    env.reset(); orc.reset()
+    _, _, _, st, tau = substep_parity_inputs("laikago", n)
+    push_state(env, st); orc.state[:] = st
+    tg = torch.tensor(tau, dtype=torch.float32, device=env.device)
+    env.debug_physics(tg, 4)
+    for i in range(n):
+        for _ in range(4):
+            orc.L.orc_physics_substep(orc.h, ol.P(orc.state[i]), ol.P(np.ascontiguousarray(tau[i])))
+    compare_fields(env, orc, ["POS", "QUAT", "Q"], atol=5e-5, rtol=5e-5, what="iters=%d" % iters)
+    compare_fields(env, orc, ["LINVEL", "ANGVEL", "QD"], atol=1e-3, rtol=1e-3, what="iters=%d" % iters)
+    compare_fields(env, orc, ["LAMBDA"], atol=5e-3, what="iters=%d" % iters)
+    env.close(); orc.close()
