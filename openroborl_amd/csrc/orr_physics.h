@@ -924,6 +924,7 @@ __device__ static int physics_substep(const KParams& P, Shared& S, const LegCons
     delassus_columns<true>(S, mask, lane, sub, A, B, G, AcA, AcB, lam);
     PT(7);
     pgs_sweeps<true>(cfg.solver_iters, mask, lane, sub, A, B, AcA, AcB, lam);
+    PT(34);    // sweeps with the joint-limit bank, separately (tools/phase_cycles.py)
   } else {
     delassus_columns<false>(S, mask, lane, sub, A, B, G, AcA, AcB, lam);
     PT(7);

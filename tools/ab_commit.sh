@@ -6,10 +6,17 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 if [ "$1" = build ]; then
   C=${2:-HEAD}; TMP=$(mktemp -d)
   git -C "$ROOT" archive "$C" openroborl_amd/csrc include | tar -x -C "$TMP"
-  HIPCC=/opt/rocm/bin/hipcc
-  FL="--offload-arch=gfx950 -O2 -fPIC -std=c++17 -Wno-unused-value -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=iterative-ilp"
-  $HIPCC $FL -c -o $TMP/k.o $TMP/openroborl_amd/csrc/orr_kernels.hip && $HIPCC --offload-arch=gfx950 -O3 -fPIC -std=c++17 -c -o $TMP/p.o $TMP/openroborl_amd/csrc/orr_policy.hip && \
-    $HIPCC --offload-arch=gfx950 -shared -fPIC -o $ROOT/openroborl_amd/lib_ab_old.so $TMP/k.o $TMP/p.o && echo "built lib_ab_old.so from $C"
+  # the SAME compiler flags as the shipped library (openroborl_amd/_lib.py HIPCC_FLAGS)
+  python3 - "$ROOT" "$TMP" <<'PY' && echo "built lib_ab_old.so from $C"
+import subprocess, sys
+root, tmp = sys.argv[1], sys.argv[2]
+sys.path.insert(0, root)
+from openroborl_amd import _lib
+fl = [f for f in _lib.HIPCC_FLAGS if f != "-shared"]
+subprocess.check_call([_lib.HIPCC] + fl + ["-c", "-o", tmp + "/k.o", tmp + "/openroborl_amd/csrc/orr_kernels.hip"])
+subprocess.check_call([_lib.HIPCC, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-c", "-o", tmp + "/p.o", tmp + "/openroborl_amd/csrc/orr_policy.hip"])
+subprocess.check_call([_lib.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", root + "/openroborl_amd/lib_ab_old.so", tmp + "/k.o", tmp + "/p.o"])
+PY
   python3 -c "import sys; sys.path.insert(0, '$ROOT'); from openroborl_amd import _lib; _lib.build()" && echo "working-tree library up to date"
   exit 0
 fi

@@ -96,6 +96,21 @@ __global__ __launch_bounds__(64) void k(long long* out, float* sink) {
     T0(); asm volatile(REP256("ds_read_b128 v[100:103], %1\n\tv_fma_f32 %0, %0, %2, %0\n\tv_fma_f32 %0, %0, %2, %0\n\tv_fma_f32 %0, %0, %2, %0\n\tv_fma_f32 %0, %0, %2, %0\n\t") : "+v"(a) : "v"(addr & ~15), "v"(kf) : "memory", "v100", "v101", "v102", "v103"); T1(51);
     T0(); asm volatile(REP256("ds_read_b32 v100, %1\n\tv_fma_f32 %0, %0, %2, %0\n\tv_fma_f32 %0, %0, %2, %0\n\tv_fma_f32 %0, %0, %2, %0\n\tv_fma_f32 %0, %0, %2, %0\n\t") : "+v"(a) : "v"(addr), "v"(kf) : "memory", "v100"); T1(52);
   }
+  {
+    // VGPR banks (register number mod 4): three sources from one bank vs from three banks; explicit registers
+    asm volatile("v_mov_b32 v100, 1.0\n\tv_mov_b32 v104, 0.5\n\tv_mov_b32 v108, 0.25\n\tv_mov_b32 v101, 0.5\n\tv_mov_b32 v102, 0.25\n\tv_mov_b32 v103, 2.0\n\tv_mov_b32 v112, 0\n\tv_mov_b32 v113, 0"
+                 ::: "v100", "v101", "v102", "v103", "v104", "v108", "v112", "v113");
+    T0(); asm volatile(REP256("v_fma_f32 v112, v100, v104, v108\n\t") ::: "v112"); T1(53);                  // sources in banks 0,0,0 (independent)
+    T0(); asm volatile(REP256("v_fma_f32 v112, v100, v101, v102\n\t") ::: "v112"); T1(54);                  // sources in banks 0,1,2
+    T0(); asm volatile(REP256("v_fma_f32 v112, v100, v104, v112\n\t") ::: "v112"); T1(55);                  // dependent, banks 0,0,0
+    T0(); asm volatile(REP256("v_fma_f32 v113, v100, v102, v113\n\t") ::: "v113"); T1(56);                  // dependent, banks 0,2,1
+    T0(); asm volatile(REP256("v_fmac_f32 v112, v100, v104\n\t") ::: "v112"); T1(57);                       // fmac dependent, banks 0,0,(0)
+    T0(); asm volatile(REP256("v_fmac_f32 v113, v100, v102\n\t") ::: "v113"); T1(58);                       // fmac dependent, banks 0,2,(1)
+    T0(); asm volatile(REP256("v_fmac_f32_dpp v113, v100, v102 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t") ::: "v113"); T1(59);
+    T0(); asm volatile(REP256("v_fmac_f32_dpp v112, v100, v104 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t") ::: "v112"); T1(60);
+    T0(); asm volatile(REP256("v_med3_f32 v113, v100, v104, v108\n\t") ::: "v113"); T1(61);
+    T0(); asm volatile(REP256("v_med3_f32 v113, v100, v101, v102\n\t") ::: "v113"); T1(62);
+  }
   sink[threadIdx.x] = a + b + c + d + (float)addr + (float)s0 + p.x + q.x;
 }
 
@@ -116,13 +131,16 @@ int main() {
                          "v_pk_fma_f32, 3 distinct sources (dependent)", "2 independent v_pk_fma_f32 (per pair)", "v_pk_fma_f32 with op_sel splat",
                          "v_pk_mul_f32 dependent", "v_pk_add_f32 dependent", "v_fma_f32, 3 distinct sources", "v_pk_fma_f32 with op_sel swap + neg",
                          "ds_read_b32 back to back (issue)", "ds_read_b64 back to back", "ds_read_b128 back to back", "ds_read2_b32 back to back",
-                         "ds_write_b64 back to back", "ds_write_b128 back to back", "ds_read_b128 + 4 v_fma (no wait)", "ds_read_b32 + 4 v_fma (no wait)"};
+                         "ds_write_b64 back to back", "ds_write_b128 back to back", "ds_read_b128 + 4 v_fma (no wait)", "ds_read_b32 + 4 v_fma (no wait)",
+                         "v_fma, sources in VGPR banks 0,0,0", "v_fma, sources in banks 0,1,2", "v_fma dependent, banks 0,0,0", "v_fma dependent, banks 0,2,1",
+                         "v_fmac dependent, banks 0,0,0", "v_fmac dependent, banks 0,2,1", "v_fmac_dpp dependent, banks 0,2,1", "v_fmac_dpp dependent, banks 0,0,0",
+                         "v_med3, banks 0,0,0", "v_med3, banks 0,1,2"};
   for (int rep = 0; rep < 2; rep++) {
     hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, out, sink);
     (void)hipDeviceSynchronize();
   }
   long long h[64];
   (void)hipMemcpy(h, out, sizeof(h), hipMemcpyDeviceToHost);
-  for (int i = 0; i < 53; i++) printf("%-52s %8.2f cycles per repetition\n", names[i], (double)(h[i] - h[0]) / 256.0);
+  for (int i = 0; i < 63; i++) printf("%-52s %8.2f cycles per repetition\n", names[i], (double)(h[i] - h[0]) / 256.0);
   return 0;
 }

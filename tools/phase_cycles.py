@@ -46,6 +46,7 @@ for n, v in zip(NAMES, buf[:16]):
     print("  %-22s %9.0f  %5.1f%%" % (n, v / steps, 100.0 * v / tot))
 print("steps with a reset in the instrumented wave: %d of %d (robot resets: %s); cycles per such step in 'episode end/reset': %.0f"
       % (events, steps, dones.tolist(), buf[14] / max(events, 1)))
+print("PGS sweeps in sub-steps with the joint-limit bank (not in the table above): %.0f cycles per env step" % (buf[34] / steps))
 print("stages of reset_robot in program order, cycles per reset of robot 0 of the wave (a mark closes the interval since the previous one):")
 RESET = [(16, "state defaults"), (24, "Philox blocks (28 draws)"), (20, "task draws: start time"), (26, "frame indices (clip_index)"),
          (19, "frame + mass-table loads issued"), (17, "ring entry #1"), (29, "control observation copy"), (18, "sensor histories"),
