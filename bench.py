@@ -197,9 +197,10 @@ def main():
     eager_steps(0, args.warmup)
     odist.gather_env_episodes(env, args.warmup)
     dist_info = odist.describe()
-    # HIP events around the step kernel of every EV_STRIDE-th timed launch (every launch when K is small): each record is a
-    # packet on the launch stream, so bracketing all 3000 launches would itself cost ~1 % of the measured rate
-    ev_stride = 1 if args.steps <= 64 else int(os.environ.get("ORR_BENCH_EVENT_STRIDE", "8"))
+    # HIP events around the step kernel of every EV_STRIDE-th timed launch (every launch for K <= 8, every 4th for K <= 64): each
+    # record is a packet on the launch stream (~6 us of stream time per bracketed launch), so bracketing all launches would itself
+    # cost 2-4 % of the measured rate
+    ev_stride = int(os.environ.get("ORR_BENCH_EVENT_STRIDE", "0")) or (1 if args.steps <= 8 else (4 if args.steps <= 64 else 8))
     ev = {k: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for k in range(0, args.steps, ev_stride)}
     stream = torch.cuda.current_stream(dev)
     sync_all()
