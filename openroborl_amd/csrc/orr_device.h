@@ -127,7 +127,7 @@ struct KParams {
 };
 
 // ------------------------------------------------------------------------------------------------
-// LDS image of one robot: ~6.3 KB, four per wave
+// LDS image of one robot: ~6.6 KB, four per wave
 // ------------------------------------------------------------------------------------------------
 // The LDS structures are 16-byte aligned and sized in multiples of 16 bytes so that runs of consecutive words are moved
 // with ds_read_b128 / ds_write_b128 (a quarter of the LDS instructions of the 4-byte-aligned layout).
