@@ -148,6 +148,18 @@ struct alignas(16) LegSolve {   // per leg: column k of T written by the leg's p
   float Hi[6];      // H^-1 of the leg's 3x3 joint-space inertia (00 11 22 01 02 12)
 };
 
+// Code alignment of the hand-written loops.  A lone wave pays for instruction fetch: an 8-byte instruction (VOP3, DPP) that starts on an
+// odd dword costs ~0.7 ticks more than an aligned one (shifting the whole kernel by one dword changes its run time by 2.5 %; DESIGN.md
+// section 6), and the Gauss-Seidel loops are almost entirely 8-byte instructions with a few 4-byte ones in between -- with the wrong
+// start parity 45 of the 57 eight-byte instructions of a sweep are misaligned, with the right one 11.  Left alone, that parity is decided
+// by whatever code happens to precede the loop.  The loops therefore align themselves to 8 bytes and add one 4-byte s_nop if their bit of
+// ORR_PARITY is set (bit 12: sweeps without the joint-limit bank, bit 13: with it); chosen on the GPU (tools/parity_search.py:
+// bit 12 = 0.244 ms, clear = 0.249 ms; bit 13 and the parity of the compiler-generated phases make no measurable difference).
+#ifndef ORR_PARITY
+#define ORR_PARITY 0x1000
+#endif
+#define ORR_STR2(x) #x
+#define ORR_STR(x) ORR_STR2(x)
 constexpr int kPhaseSlots = 40;   // phase timers of the -DORR_PHASE_TIMERS build (tools/phase_cycles.py)
 constexpr int kWStride = 20;   // 18 DOFs, padded to a multiple of 16 bytes
 struct alignas(16) DynamicsBuf {           // leg dynamics -> row setup hand-over (dead once the impulse responses are written)

@@ -655,6 +655,7 @@ __device__ __forceinline__ void pgs_sweeps_bank_a(int iters, const Row& A, const
   asm("v_mov_b32 %[zero], 0\n\t"
       "s_cmp_lt_u32 %[it], 3\n\t"
       "s_cbranch_scc1 3f\n"
+      ".p2align 3\n\t.if ((" ORR_STR(ORR_PARITY) ") >> 12) & 1\n\ts_nop 0\n\t.endif\n"
       "1:\n\t"
       ORR_SWEEP("s_sub_u32 %[it], %[it], 3\n\t", "s_cmp_ge_u32 %[it], 3\n\t", "")
       ORR_SWEEP(ORR_LAM(27, m1, 15), "s_nop 0\n\t", "")
@@ -725,6 +726,7 @@ __device__ __forceinline__ void pgs_sweeps_bank_ab(int iters, unsigned int mask,
   "v_fmac_f32 %[ya], %[a" #R "], %[l" #R "]\n"                       \
   "2:\n\t"
   asm("v_mov_b32 %[zero], 0\n"
+      ".p2align 3\n\t.if ((" ORR_STR(ORR_PARITY) ") >> 13) & 1\n\ts_nop 0\n\t.endif\n"
       "1:\n\t"
       ORR_ROW(0, 0) ORR_ROW(1, 1) ORR_ROW(2, 2) ORR_ROW(3, 3)
       "s_and_b32 %[tmp], %[msk], 0x70\n\ts_cbranch_scc0 3f\n\t" ORR_LIM(4) ORR_LIM(5) ORR_LIM(6) "3:\n\t"            // leg by leg first
