@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """Headline benchmark: env steps/sec at N parallel robots (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W [--config laikago4096|minicheetah4096|mixed8192]
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  python bench.py --gpus N --steps K --warmup W [--config laikago4096|minicheetah4096|mixed8192] [--no-randomizer] [--repeats R]
+  N > 1 without a launcher around it (WORLD_SIZE unset): this process touches no GPU, starts
+  `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...` as a fresh
+  child (one rank per GPU over RCCL, like the reference's `mpiexec -n 8 python3 OpenRoboRL/run.py`, README.md:27), forwards rank 0's
+  JSON line and exits with the child's return code.  Under an external torchrun (the driver's N > 1 command) it is a rank.
 
 Workload (default = BASELINE.json configs[1]): imitation_learning_laikago, 4096 robots per GPU, laikago_pace clip,
 train semantics (domain randomiser on, 20->600 step curriculum, per-robot auto-reset).  --config selects configs[2]
@@ -26,6 +29,7 @@ north star asks; DESIGN.md section 6 explains why the kernel is VALU-issue bound
 import argparse
 import json
 import os
+import re
 import sys
 import tempfile
 import time
@@ -42,6 +46,11 @@ WARMUP_FLOOR = int(os.environ.get("ORR_BENCH_WARMUP_FLOOR", "6000"))
 # reward 4 + done 1 = 693; state head 307 words read + written = 2456; latency ring 33 entries written
 # (2640) + 35 distinct entries read (2660).  Model tables and clip frames are shared and L2-resident.
 B_ALG = 693 + 2456 + 2640 + 2660
+# --no-randomizer (the reference's test-mode latency: fixed 2 ms = the entries 2 and 3 sub-steps back, SURVEY.md section 8d second
+# row): only the last 4 ring entries of a step are ever read again (4 x 80 B written) and 3 entries of the previous step are read
+# (3 x 76 B); the other 29 entries a step pushes are dead stores as far as the algorithm goes (the kernel still makes them: the
+# PMC traffic says what that costs)
+B_ALG_FIXED_LATENCY = 693 + 2456 + 320 + 228
 HBM_PEAK_GBS = 8000.0
 
 CONFIGS = {
@@ -127,6 +136,46 @@ def cpu_baseline(env):
             "rows": rows}
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launcher_argv(n_ranks, child_args, port=None):
+    """argv of the child that runs this file as `n_ranks` ranks (one per GPU) under torch.distributed.run."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+            "--master-addr", "127.0.0.1", "--master-port", str(port or _free_port()), os.path.abspath(__file__)] + list(child_args)
+
+
+def launch_ranks(n_ranks, child_args):
+    """Parent side of a self-launched multi-rank run.  Nothing here imports torch or touches the GPU: the ranks are FRESH
+    child processes (never an exec of a process that has initialised HIP).  stdout of the children is filtered: the one JSON
+    result line goes to stdout, everything else to stderr.  Returns the child's exit code (non-zero if any rank failed; torchrun
+    tears the other ranks down) - no retry."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.Popen(launcher_argv(n_ranks, child_args), stdout=subprocess.PIPE, env=env, text=True)
+    lines = 0
+    for line in proc.stdout:
+        if line.startswith("{") and '"metric"' in line:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+            lines += 1
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if rc == 0 and lines != 1:
+        sys.stderr.write("bench.py launcher: expected one result line from rank 0, got %d\n" % lines)
+        rc = 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -135,23 +184,33 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="laikago4096")
     ap.add_argument("--robots-per-gpu", type=int, default=0, help="override the config's robots per GPU (experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-randomizer", action="store_true",
+                    help="second row of SURVEY 8d: domain randomiser off, fixed 2 ms control latency (run.py:205-206, laikago.py:27)")
+    ap.add_argument("--repeats", type=int, default=1, help="time R regions of K steps each and report the median (SURVEY 8d: 5)")
+    ap.add_argument("--spawn", action="store_true", help="go through the rank launcher even for --gpus 1")
+    ap.add_argument("--launch-dry-run", action="store_true", help="print the launcher's argv as JSON and exit")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn or args.launch_dry_run):
+        child_args = [a for a in sys.argv[1:] if a not in ("--spawn", "--launch-dry-run")]
+        if args.launch_dry_run:
+            print(json.dumps({"argv": launcher_argv(args.gpus, child_args), "ranks": args.gpus}))
+            return 0
+        return launch_ranks(args.gpus, child_args)
 
     import torch
     from openroborl_amd import dist as odist
     from openroborl_amd.env import VecQuadrupedEnv
 
     rank, world, local = odist.init_from_env()
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus > 1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
     # ORR_BENCH_SINGLE_DEVICE=1 (+ ORR_DIST_BACKEND=gloo): multi-rank rehearsal on a one-GPU box, never a measurement
     dev = torch.device("cuda", 0 if os.environ.get("ORR_BENCH_SINGLE_DEVICE") else local)
     torch.cuda.set_device(dev)
     env_kw, n, workload = CONFIGS[args.config]
     n = args.robots_per_gpu or n
-    env = VecQuadrupedEnv(num_robot=n, mode="train", enable_randomizer=True, auto_reset=True, seed=int(os.environ.get("ORR_BENCH_SEED", "0")), device=dev,
+    env = VecQuadrupedEnv(num_robot=n, mode="train", enable_randomizer=not args.no_randomizer, auto_reset=True, seed=int(os.environ.get("ORR_BENCH_SEED", "0")), device=dev,
                           num_procs=world, robot_index_offset=rank * n, **env_kw)
     # action = (target joint pose -> motor space) - init + noise; the joint -> motor permutation and direction signs are one
     # 12x12 matrix per robot type, noise and constant terms are pre-combined: one (batched) GEMM launch per step
@@ -201,79 +260,115 @@ def main():
     # record is a packet on the launch stream (~6 us of stream time per bracketed launch), so bracketing all launches would itself
     # cost 2-4 % of the measured rate
     ev_stride = int(os.environ.get("ORR_BENCH_EVENT_STRIDE", "0")) or (1 if args.steps <= 8 else (4 if args.steps <= 64 else 8))
-    ev = {k: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for k in range(0, args.steps, ev_stride)}
     stream = torch.cuda.current_stream(dev)
-    sync_all()
-
-    # ---- timed region: exactly args.steps env steps (action GEMM + step kernel) + the rollout-boundary gathers ----
-    t0 = time.perf_counter()
-    gather_s, since, n_eps = 0.0, 0, 0
-    for k in range(args.steps):
-        act = make_action(env.obs, k)
-        e = ev.get(k)
-        if e is not None:
-            e[0].record(stream)
-        env.step(act)
-        if e is not None:
-            e[1].record(stream)
-        since += 1
-        if since >= ROLLOUT or k == args.steps - 1:
-            torch.cuda.synchronize(dev)                         # drain the queued steps first: that wait is kernel time, not gather time
-            g0 = time.perf_counter()
-            stats = odist.gather_env_episodes(env, since)
-            torch.cuda.synchronize(dev)
-            q0 = time.perf_counter()
-            n_eps += stats.sums[0]
-            since = 0
-            gather_s += q0 - g0
-    sync_all()
-    elapsed = time.perf_counter() - t0
     gloo = world > 1 and torch.distributed.get_backend() == "gloo"
-    el = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if gloo else dev)
-    if world > 1:
-        torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
-    elapsed = float(el.item())
+
+    def timed_region(k0):
+        """EXACTLY args.steps env steps (action GEMM + step kernel) + the rollout-boundary gathers, between barrier + synchronize
+        on both sides; returns the MAX over ranks of the elapsed time and rank-local details."""
+        ev = {k: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for k in range(0, args.steps, ev_stride)}
+        sync_all()
+        t0 = time.perf_counter()
+        gather_s, since, n_eps = 0.0, 0, 0
+        for k in range(args.steps):
+            act = make_action(env.obs, k0 + k)
+            e = ev.get(k)
+            if e is not None:
+                e[0].record(stream)
+            env.step(act)
+            if e is not None:
+                e[1].record(stream)
+            since += 1
+            if since >= ROLLOUT or k == args.steps - 1:
+                torch.cuda.synchronize(dev)                         # drain the queued steps first: that wait is kernel time, not gather time
+                g0 = time.perf_counter()
+                stats = odist.gather_env_episodes(env, since)
+                torch.cuda.synchronize(dev)
+                q0 = time.perf_counter()
+                n_eps += stats.sums[0]
+                since = 0
+                gather_s += q0 - g0
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        el = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if gloo else dev)
+        if world > 1:
+            torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
+        return {"elapsed": float(el.item()), "gather_s": gather_s, "episodes": n_eps,
+                "kern_ms": sum(a.elapsed_time(b) for a, b in ev.values()) / len(ev), "launches_timed": len(ev)}
+
+    # ---- timed: --repeats regions of exactly --steps env steps each; the reported one is the median by elapsed time ----
+    regions = [timed_region(r * args.steps) for r in range(max(1, args.repeats))]
+    mid = sorted(regions, key=lambda r: r["elapsed"])[len(regions) // 2]
+    elapsed, gather_s, n_eps, n_ev = mid["elapsed"], mid["gather_s"], mid["episodes"], mid["launches_timed"]
 
     # dominant kernel: HIP events on the launch stream around every timed launch
-    kern_ms = sum(a.elapsed_time(b) for a, b in ev.values()) / len(ev)
+    kern_ms = mid["kern_ms"]
     kern_total_ms = kern_ms * args.steps
     # cross-check: back-to-back launches without the action kernels in between (C-ABI helper, same stream)
     act = make_action(env.obs, 0).contiguous()
     torch.cuda.synchronize(dev)
     kern_b2b_ms = env.time_steps(act, 50) / 50.0
-    achieved = B_ALG * n / (kern_ms * 1e-3) / 1e9
+    b_alg = B_ALG_FIXED_LATENCY if args.no_randomizer else B_ALG
+    achieved = b_alg * n / (kern_ms * 1e-3) / 1e9
 
     if rank == 0:
         # PMC numbers come from separate rocprofv3 --pmc passes over this same command (tools/profile_gpu.sh), committed under
         # profiles/.  FETCH_SIZE x2: gfx950 tallies 128-B read requests at 64 B (MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact.
-        traffic, valu = None, {}
-        for name in ("r02_%s_pmc_summary.json" % args.config,):
+        traffic, valu, issue = None, {}, None
+        clock_hz = 1e3 * float(getattr(torch.cuda.get_device_properties(dev), "clock_rate", 2.4e6))   # kHz -> Hz (2.4 GHz)
+        tag = args.config + ("_norand" if args.no_randomizer else "")
+        for rnd in ("r03", "r02"):
+            name = "%s_%s_pmc_summary.json" % (rnd, tag)
             pmc = os.path.join(ROOT, "profiles", name)
             if not os.path.exists(pmc) or n != CONFIGS[args.config][1]:
                 continue
             try:
                 d = json.load(open(pmc))
                 traffic = d.get("hbm_bytes_per_launch_fetch_x2")
+                waves = d["SQ_WAVES"]["mean_per_launch"]
                 valu = {"source": "profiles/" + name,
                         "valu_insts_per_robot_step": d["SQ_INSTS_VALU"]["mean_per_launch"] / n,
                         "valu_active_frac_of_wave_cycles": d["SQ_ACTIVE_INST_VALU"]["mean_per_launch"] / d["SQ_WAVE_CYCLES"]["mean_per_launch"],
-                        "waves_per_simd": d["SQ_WAVES"]["mean_per_launch"] / 1024.0}
+                        "wait_any_frac_of_wave_cycles": d["SQ_WAIT_ANY"]["mean_per_launch"] / d["SQ_WAVE_CYCLES"]["mean_per_launch"],
+                        "waves_per_simd": waves / 1024.0}
+                # THE BOUND THAT BINDS: VALU issue of the waves resident on a SIMD.  A lone wave issues at most one VALU instruction
+                # per 4 cycles (MI355X_MICROARCH.md: dependent-issue cadence of a single wave), a SIMD with >= 2 waves one per 2.
+                # `rounds` = how many waves a SIMD runs one after the other (4096 robots: 1; 8192: 2).
+                ipw = d["SQ_INSTS_VALU"]["mean_per_launch"] / waves
+                rounds = max(1.0, waves / 1024.0)
+                kcyc = kern_ms * 1e-3 * clock_hz
+                issue = {"source": "profiles/" + name + " (instruction counts) x this run's kernel_ms",
+                         "insts_per_wave": ipw, "waves_per_simd_in_series": rounds, "cycles_per_inst_lone_wave": 4,
+                         "shader_clock_ghz": clock_hz / 1e9, "kernel_cycles": kcyc,
+                         "frac_of_lone_wave_ceiling": ipw * rounds * 4.0 / kcyc, "frac_of_simd_peak": ipw * rounds * 2.0 / kcyc,
+                         "tail_frac": None}
+                for rnd2 in ("r03", "r02"):
+                    tl = os.path.join(ROOT, "profiles", "%s_wave_timeline.txt" % rnd2)
+                    if args.config == "laikago4096" and not args.no_randomizer and os.path.exists(tl):
+                        rows = {m.group(1).strip(): float(m.group(2)) for m in (re.match(r"^(.*\S)\s+([0-9.]+)$", ln.rstrip()) for ln in open(tl)) if m}
+                        end, mean = rows.get("latest wave end = launch length (us)"), rows.get("mean wave duration (us)")
+                        if end and mean:
+                            issue["tail_frac"] = 1.0 - mean / end
+                            issue["tail_source"] = "profiles/%s_wave_timeline.txt (1 - mean wave duration / launch length)" % rnd2
+                            break
                 break
-            except Exception:       # noqa: BLE001
-                traffic, valu = None, {}
+            except Exception as e:       # noqa: BLE001
+                traffic, valu, issue = None, {"error": repr(e)}, None
         out = {
             "metric": "env steps/sec at N parallel robots", "value": world * n * args.steps / elapsed, "unit": "env steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_internal": WARMUP_FLOOR,
-            "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step": 1e3 * elapsed / args.steps, "repeats": len(regions),
+            "repeat_values": [world * n * args.steps / r["elapsed"] for r in regions],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "dtype_ref": "f64", "data": "synthetic",
             "config": {"workload": workload % n, "name": args.config,
                        "robots_per_gpu": n, "total_robots": world * n, "substeps_per_step": 33, "solver_iters": 9,
-                       "randomizer": True, "auto_reset": True, "actions": "reference pose + N(0,0.125^2), on device (one GEMM launch per step, timed)",
+                       "randomizer": not args.no_randomizer, "control_latency_s": "U(0, 0.04) per episode" if not args.no_randomizer else 0.002,
+                       "auto_reset": True, "actions": "reference pose + N(0,0.125^2), on device (one GEMM launch per step, timed)",
                        "launch": "eager", "collective": "all_gather of episode returns every %d steps and at the end" % ROLLOUT,
                        "episodes_gathered": n_eps},
             "timed_breakdown": {"kernel_ms_total": kern_total_ms, "gather_ms": 1e3 * gather_s,
                                 "other_ms": 1e3 * elapsed - kern_total_ms - 1e3 * gather_s,
-                                "kernel_launches_timed": len(ev),
+                                "kernel_launches_timed": n_ev,
                                 "note": "rank 0; kernel = mean HIP-event duration of the bracketed orr_step_kernel launches x steps; gather = host time "
                                         "from the last queued kernel's end to the end of each rollout-boundary gather; other = action "
                                         "GEMMs, launch gaps, barriers"},
@@ -281,8 +376,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "orr_step_kernel<0>", "kernel_ms": kern_ms, "kernel_ms_back_to_back": kern_b2b_ms,
-                         "alg_bytes_per_robot_step": B_ALG, "alg_bytes_per_launch": B_ALG * n,
-                         "pmc": valu,
+                         "alg_bytes_per_robot_step": b_alg, "alg_bytes_per_launch": b_alg * n,
+                         "pmc": valu, "valu_issue": issue,
                          "note": "instruction-issue-bound serial chain of a lone wave (33 x (leg dynamics + rows + 9 PGS sweeps)); HBM fraction is reported "
                                  "because the north star asks for it, see DESIGN.md section 6"},
         }
@@ -295,4 +390,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

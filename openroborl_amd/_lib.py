@@ -38,8 +38,23 @@ EXPORTS = [
 ]
 
 
-def source_hash():
-    """sha256 over the sources the library is built from (file names + contents) and the compiler flags."""
+HASH_MARKER = b"ORR_SRC_HASH="      # the library embeds "ORR_SRC_HASH=<32 hex>" (orr_kernels.hip); read WITHOUT dlopen, see library_hash
+
+
+def tuning_defines():
+    """-D flags taken from the environment (tuning experiments).  They are part of the hash: a library built with them is not the
+    shipped library, and setting them makes the in-tree library stale."""
+    defs = []
+    for var in ("ORR_WAVES_PER_EU", "ORR_LANES_PER_ROBOT"):
+        if os.environ.get(var):
+            defs.append("-D%s=%d" % (var, int(os.environ[var])))
+    for d in os.environ.get("ORR_EXTRA_DEFS", "").split():
+        defs.append("-D" + d)
+    return defs
+
+
+def source_hash(extra_flags=()):
+    """sha256 over the sources the library is built from (file names + contents), the compiler flags and every -D the build adds."""
     import hashlib
     h = hashlib.sha256()
     for d in sorted(DEPS):
@@ -47,19 +62,30 @@ def source_hash():
         with open(d, "rb") as f:
             h.update(f.read())
     h.update(" ".join(HIPCC_FLAGS).encode())
+    extra = tuning_defines() + list(extra_flags)
+    if extra:
+        h.update(("|" + " ".join(extra)).encode())
     return h.hexdigest()[:32]
 
 
-def library_hash(path=LIB_PATH):
-    """The source hash embedded in a built library (orr_source_hash()), or None."""
-    if not os.path.exists(path):
-        return None
+def library_hash(path=None):
+    """The source hash embedded in a built library, or None.  The file is scanned for the marker, NOT dlopen'ed: ctypes never
+    dlcloses, and glibc hands a later CDLL(path) of a replaced file the handle of the old mapping, so a check that loads the
+    stale library would make this process run it after the rebuild."""
+    path = path or LIB_PATH
     try:
-        L = C.CDLL(path)
-        L.orr_source_hash.restype = C.c_char_p
-        return L.orr_source_hash().decode()
-    except (OSError, AttributeError):
+        with open(path, "rb") as f:
+            blob = f.read()
+    except OSError:
         return None
+    i = blob.find(HASH_MARKER)
+    if i < 0:
+        return None
+    j = i + len(HASH_MARKER)
+    digest = blob[j:j + 32]
+    if len(digest) != 32 or any(c not in b"0123456789abcdef" for c in digest):
+        return None
+    return digest.decode()
 
 
 def needs_build():
@@ -82,13 +108,8 @@ def build(force=False, verbose=False, out_path=None, extra_flags=()):
         try:
             if not dev_build and not force and not needs_build():
                 return LIB_PATH              # another rank built it while this one waited for the lock
-            flags = [f for f in HIPCC_FLAGS if f != "-shared"] + ["-c", '-DORR_SOURCE_HASH="%s"' % source_hash()]
-            for var in ("ORR_WAVES_PER_EU", "ORR_LANES_PER_ROBOT"):      # tuning experiments only
-                if os.environ.get(var):
-                    flags.append("-D%s=%d" % (var, int(os.environ[var])))
-            for d in os.environ.get("ORR_EXTRA_DEFS", "").split():
-                flags.append("-D" + d)
-            flags += list(extra_flags)
+            flags = [f for f in HIPCC_FLAGS if f != "-shared"] + ["-c", '-DORR_SOURCE_HASH="%s"' % source_hash(extra_flags)]
+            flags += tuning_defines() + list(extra_flags)
             tag = ".%d" % os.getpid()
             obj_env = os.path.join(PKG_DIR, "csrc", "orr_kernels%s.o" % tag)
             obj_pol = os.path.join(PKG_DIR, "csrc", "orr_policy%s.o" % tag)
@@ -137,6 +158,12 @@ def load():
     L.orr_last_error.restype = C.c_char_p
     L.orr_abi_version.restype = C.c_int32
     L.orr_source_hash.restype = C.c_char_p
+    if path == LIB_PATH and not os.environ.get("ORR_ALLOW_STALE_LIB"):
+        # what this process actually mapped (not what is on disk): must be the build of the sources on disk
+        got, want = L.orr_source_hash().decode(), source_hash()
+        if got != want:
+            raise RuntimeError("loaded libopenroborl_hip.so was built from %s, the sources are %s (a stale mapping of a replaced "
+                               "file?); set ORR_ALLOW_STALE_LIB=1 to run it anyway" % (got, want))
     L.orr_create.restype = C.c_int32
     L.orr_create.argtypes = [C.POINTER(_abi.OrrConfig), C.POINTER(vp)]
     L.orr_destroy.argtypes = [vp]

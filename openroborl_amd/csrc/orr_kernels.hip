@@ -403,7 +403,9 @@ extern "C" {
 #endif
 const char* orr_last_error(void) { return g_err; }
 int32_t orr_abi_version(void) { return ORR_ABI_VERSION; }
-const char* orr_source_hash(void) { return ORR_SOURCE_HASH; }
+// "ORR_SRC_HASH=<hex>" is also what the host loader scans the FILE for (openroborl_amd/_lib.py: a stale-build check that must not dlopen)
+static const char g_src_hash[] = "ORR_SRC_HASH=" ORR_SOURCE_HASH;
+const char* orr_source_hash(void) { return g_src_hash + 13; }
 int32_t orr_state_stride(void) { return ORR_STATE_STRIDE; }
 int32_t orr_layout_count(void) { return (int32_t)(sizeof(g_fields) / sizeof(g_fields[0])); }
 const char* orr_layout_name(int32_t i) { return g_fields[i].name; }

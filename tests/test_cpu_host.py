@@ -157,3 +157,41 @@ def test_policy_abi_argument_checks_without_gpu():
     assert b"orr_policy_forward" in L.orr_last_error()
     assert L.orr_gae(None, None, None, None, 4, 4, 0.95, 0.95, 1, 0.0, None, None, None) == -1
     assert b"orr_gae" in L.orr_last_error()
+
+
+def test_stale_library_is_rebuilt_and_the_new_build_is_what_gets_loaded(tmp_path):
+    """Loader regression: the stale-library check must not dlopen the stale file (ctypes never dlcloses and glibc
+    returns the old mapping for the same path).  A copy of the package with an edited dependency and the OLD library in place:
+    load() in one fresh process must rebuild, and the library it has mapped must carry the NEW hash."""
+    import shutil
+    import subprocess
+    import sys
+    assert _lib.library_hash() == _lib.source_hash(), "in-tree library is stale"
+    pkg = tmp_path / "openroborl_amd"
+    shutil.copytree(os.path.join(ROOT, "openroborl_amd"), pkg, ignore=shutil.ignore_patterns("__pycache__", "data", "*.o", "lib_ab_old.so"))
+    shutil.copytree(os.path.join(ROOT, "include"), tmp_path / "include")
+    with open(pkg / "csrc" / "orr_task.h", "a") as f:
+        f.write("\n// edited by the loader test\n")
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from openroborl_amd import _lib\n"
+            "old = _lib.library_hash(); want = _lib.source_hash()\n"
+            "assert old is not None and old != want and _lib.needs_build()\n"
+            "L = _lib.load()\n"
+            "got = L.orr_source_hash().decode()\n"
+            "assert got == want == _lib.library_hash(), (got, want, old)\n"
+            "print('LOADED', got, 'OLD', old)\n" % str(tmp_path))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                         env={k: v for k, v in os.environ.items() if not k.startswith("ORR_")})
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "LOADED" in out.stdout and _lib.source_hash() in out.stdout.split("OLD")[1]
+
+
+def test_tuning_defines_are_part_of_the_source_hash(monkeypatch):
+    base = _lib.source_hash()
+    monkeypatch.setenv("ORR_EXTRA_DEFS", "ORR_SOMETHING=1")
+    assert _lib.source_hash() != base and _lib.needs_build()
+    monkeypatch.delenv("ORR_EXTRA_DEFS")
+    monkeypatch.setenv("ORR_WAVES_PER_EU", "2")
+    assert _lib.source_hash() != base
+    monkeypatch.delenv("ORR_WAVES_PER_EU")
+    assert _lib.source_hash() == base and _lib.source_hash(("-DX",)) != base

@@ -63,3 +63,35 @@ def test_single_process_path_needs_no_group():
     assert r.tolist() == [1.0, 2.0] and l.tolist() == [20.0, 21.0] and ts == 77 and dr == 0
     buf = odist.pack_episode_stats(torch.tensor([1.0, 2.0]), torch.tensor([20.0, 21.0]), 77, 0, 8)
     assert buf.numel() == odist.HEADER + 16
+
+
+def test_bench_self_launch_dry_run_argv():
+    """`python bench.py --gpus N` with no launcher around it starts torch.distributed.run itself: the argv."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--launch-dry-run"],
+                         capture_output=True, text=True, env=env, timeout=120)
+    assert out.returncode == 0, out.stderr
+    d = json.loads(out.stdout)
+    argv = d["argv"]
+    assert d["ranks"] == 2 and argv[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert argv[argv.index("--nproc-per-node") + 1] == "2" and argv[argv.index("--master-addr") + 1] == "127.0.0.1"
+    k = argv.index(os.path.join(ROOT, "bench.py"))
+    assert argv[k + 1:] == ["--gpus", "2", "--steps", "20", "--warmup", "5"]     # same arguments, launcher-only flags removed
+    assert 1024 < int(argv[argv.index("--master-port") + 1]) < 65536
+
+
+def test_bench_self_launch_runs_ranks_and_propagates_failure():
+    """The launcher really starts N fresh rank processes and exits non-zero when they fail.  Without a GPU every rank dies in
+    VecQuadrupedEnv ("no HIP device": there is no CPU fallback), after torch.distributed (gloo) came up with world size 2."""
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("CPU-side check of the failure path")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["ORR_DIST_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0"],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode != 0
+    assert out.stdout.strip() == ""                    # no result line
+    assert "ChildFailedError" in out.stderr or "exitcode" in out.stderr, out.stderr[-2000:]
