@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ORR_ABI_VERSION 2
+#define ORR_ABI_VERSION 3
 
 #define ORR_NUM_MOTORS 12 /* laikago.py:29, mini_cheetah.py:29 */
 #define ORR_NUM_LEGS 4
@@ -215,9 +215,12 @@ int32_t orr_set_seed(orr_handle* h, uint64_t seed);
 int32_t orr_set_model(orr_handle* h, int32_t robot_type, const orr_model* model_host);
 
 /* replaces MotionData.load results (motion_data.py:72-112): frames [F,19] and frame velocities
- * [F,18] are DEVICE pointers to post-processed data; cycle_delta = {dx, dy, dz(=0), dheading}. */
+ * [F,18] are DEVICE pointers to post-processed data; cycle_delta = {dx, dy, dz(=0), dheading}.
+ * frame_dt = the clip's "FrameDuration" as a DOUBLE (ABI v3): the sampler keeps the motion time in float64 like the reference
+ * (shipped clips use 1/24 s and 0.03 s; 20 s into an episode a float32 frame time misplaces the blend factor by 1e-5, which
+ * the O(100) jumps of the finite-difference frame velocities turn into 1e-3). */
 int32_t orr_set_motion(orr_handle* h, int32_t clip_id, const float* frames_dev, const float* frame_vels_dev,
-                       int32_t num_frames, float frame_dt, int32_t clip_flags, const float cycle_delta[4]);
+                       int32_t num_frames, double frame_dt, int32_t clip_flags, const float cycle_delta[4]);
 
 /* bind caller-owned device buffers: state [N, ORR_STATE_STRIDE] words, counters int64[8],
  * episode log float[ep_log_capacity][2] = (return, length) (may be NULL / 0). */

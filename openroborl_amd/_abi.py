@@ -1,7 +1,7 @@
 """ctypes mirror of include/openroborl_hip.h (struct layouts and constants only)."""
 import ctypes as C
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 NUM_MOTORS = 12
 POSE_DIM = 19
 VEL_DIM = 18

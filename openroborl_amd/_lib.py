@@ -172,7 +172,7 @@ def load():
     L.orr_set_model.restype = C.c_int32
     L.orr_set_model.argtypes = [vp, C.c_int32, C.POINTER(_abi.OrrModel)]
     L.orr_set_motion.restype = C.c_int32
-    L.orr_set_motion.argtypes = [vp, C.c_int32, vp, vp, C.c_int32, C.c_float, C.c_int32, C.POINTER(C.c_float)]
+    L.orr_set_motion.argtypes = [vp, C.c_int32, vp, vp, C.c_int32, C.c_double, C.c_int32, C.POINTER(C.c_float)]
     L.orr_bind.restype = C.c_int32
     L.orr_bind.argtypes = [vp, vp, vp, vp, C.c_int32]
     L.orr_reset.restype = C.c_int32

@@ -54,14 +54,20 @@ static_assert(kLanes == 16 || kLanes == 32 || kLanes == 64, "a robot needs 16 ro
 constexpr int kMaxRows = 28;  // 4 knee-friction + <=12 joint-limit + 12 contact rows
 constexpr int kHead = 320;    // words of the state record staged in LDS (everything before the ring)
 
+// Clip header (16 words: one per lane when it is staged into LDS).  Times are DOUBLES: the motion time reaches 20 s by the end of a
+// 600-step episode, where float32 resolves 2e-6 s = 1e-4 of a frame, and the frame velocities jump by O(10) between frames
+// (tests/test_gpu_clips.py).  The sampler runs twice per env step, so its few dozen f64 instructions are free.  dt_d / sim_dt_d
+// are the DECIMAL constants of the clip file / yaml (0.01667, 0.001), recovered from the float32 ABI values on the host (dec7).
 struct DevClip {
   const float* frames;
   const float* vels;
   int F, flags;
-  float dt, dur;
+  double dt_d, dur_d;   // FrameDuration, FrameDuration * (F - 1): motion_data.py:198-208
+  double sim_dt_d;      // cfg.sim_dt (the same for every clip; kept here because the clip header is what the sampler has in LDS)
   float cdp[3];
   float cdh;
 };
+static_assert(sizeof(DevClip) == 64, "clip header = 16 words");
 
 // Compact, kernel-facing robot model; built on the host by orr_set_model from orr_model.
 // All joints are required to turn about coordinate axes of the kinematic frame: the hip (k = 0) about
@@ -606,21 +612,29 @@ __device__ __forceinline__ void euler_from_quat(const float q[4], float rpy[3]) 
 }
 // transformations.quaternion_slerp (shortest path)
 __device__ __forceinline__ void qslerp(const float a[4], const float b[4], float f, float o[4]) {
-  const float EPS = 1.1920929e-07f * 4.0f;
+  // the reference's "the ends coincide" threshold is 4 x the float64 epsilon on |d| - 1 (and on the angle), i.e. an angle below
+  // 4e-8 rad: consecutive frames of the slow clips (inplace_steps, sidesteps: 1e-3 rad apart) ARE interpolated.  In float32 the dot
+  // product cannot resolve 1 - |d| = angle^2 / 2 there, so 1 - |d| is taken from the difference quaternion (exact subtraction of
+  // nearby values), and the angle and its sine come from the same number: s0 + s1 = 1 + O(angle^2) whatever its rounding
+  // (round 2 used float32's epsilon and acos(|d|): up to 5e-4 off on those clips, tests/test_gpu_clips.py)
+  const float EPS = 2.220446049250313e-16f * 4.0f;
   float n0 = rsq(a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3]);
   float n1 = rsq(b[0] * b[0] + b[1] * b[1] + b[2] * b[2] + b[3] * b[3]);
   float q0[4] = {a[0] * n0, a[1] * n0, a[2] * n0, a[3] * n0};
   float q1[4] = {b[0] * n1, b[1] * n1, b[2] * n1, b[3] * n1};
   float d = q0[0] * q1[0] + q0[1] * q1[1] + q0[2] * q1[2] + q0[3] * q1[3];
   // no branches: the general formula is evaluated always and the special cases of the reference are selected afterwards
-  const float sgn = d < 0.0f ? -1.0f : 1.0f, da = fminf(fabsf(d), 1.0f);
-  const float ang = acos_bf(da);
+  const float sgn = d < 0.0f ? -1.0f : 1.0f;
+  const float e0 = q1[0] - sgn * q0[0], e1 = q1[1] - sgn * q0[1], e2 = q1[2] - sgn * q0[2], e3 = q1[3] - sgn * q0[3];
+  const float omd = fminf(0.5f * (e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3), 1.0f);        // 1 - |d|
+  const float sn = __builtin_amdgcn_sqrtf(fmaxf(omd * (2.0f - omd), 1e-36f));            // sin(angle), angle = acos |d| in [0, pi/2]
+  const float ang = atan2_bf(sn, 1.0f - omd);
   float sa, sb, unused;
   joint_sincos((1.0f - f) * ang, &sa, &unused);
   joint_sincos(f * ang, &sb, &unused);
-  const float isin = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(fmaxf((1.0f - da) * (1.0f + da), 1e-30f)));   // 1 / sin(acos(|d|))
+  const float isin = __builtin_amdgcn_rcpf(sn);
   const bool first = f == 0.0f, second = f == 1.0f;
-  const bool same = fabsf(fabsf(d) - 1.0f) < EPS || fabsf(ang) < EPS;   // the ends coincide
+  const bool same = omd < EPS || ang < EPS;   // the ends coincide
   const float s0 = first ? 1.0f : (second ? 0.0f : (same ? 1.0f : sa * isin));
   const float s1 = first ? 0.0f : (second ? 1.0f : (same ? 0.0f : sgn * sb * isin));
 #pragma unroll

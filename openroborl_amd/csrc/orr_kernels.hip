@@ -196,9 +196,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
   // ---- reward -> update -> done (quadruped_gym_env.py:230-233) ----
   // the frames of the new reference poses are fetched while the reward is computed (their round trip to L2 is not waited for)
   const DevClip& clip = S.clip;
-  const float t = motion_time(P, S);
-  const float step_dt = c.sim_dt * c.action_repeat;
-  float tl = t;
+  const double t = motion_time(P, S);                       // f64: see DevClip
+  const double step_dt = clip.sim_dt_d * c.action_repeat;
+  double tl = t;
   {  // lanes 1..4: the four target times.  Selects over the four scalars: indexing the kernel argument with the lane makes the
      // compiler read it from memory with a vector load, whose wait also drains every store and atomic issued before it
     const int k = lane - 1;
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
     if (geti(S, O(STEP_COUNTER)) > 0 && fall) reason |= ORR_DONE_CONTACT_FALL;
     if (pe > c.dist_fail_threshold * c.dist_fail_threshold) reason |= ORR_DONE_ROOT_POS;
     if (fabsf(ang) > c.rot_fail_threshold) reason |= ORR_DONE_ROOT_ROT;
-    if (!(clip.flags & ORR_CLIP_WRAP) && t >= clip.dur) reason |= ORR_DONE_MOTION_OVER;  // is_motion_over (:224-233)
+    if (!(clip.flags & ORR_CLIP_WRAP) && t >= clip.dur_d) reason |= ORR_DONE_MOTION_OVER;  // is_motion_over (:224-233)
     bool bad = false;
     for (int i = lane; i < 37; i += kLanes) bad = bad || !(fabsf(S.s[O(POS) + i]) < 1e30f);
     if (((__ballot(bad) >> (sub * kLanes)) & ((1ull << (kLanes - 1)) * 2ull - 1ull)) != 0ull) reason |= ORR_DONE_NAN;
@@ -396,6 +396,15 @@ static const field_t g_fields[] = {
 #undef ORR_X_F
 };
 
+// The ABI carries times as float32; the reference computes with the DECIMAL constants of its sources in float64 (FrameDuration
+// 0.01667, sim_time_step 0.001).  The shortest decimal (<= 7 significant digits) that rounds to the given float, else its exact value.
+static double dec7(float x) {
+  char b[40];
+  snprintf(b, sizeof(b), "%.7g", (double)x);
+  const double d = strtod(b, nullptr);
+  return (float)d == x ? d : (double)x;
+}
+
 extern "C" {
 
 #ifndef ORR_SOURCE_HASH
@@ -535,14 +544,14 @@ int32_t orr_set_model(orr_handle* h, int32_t robot_type, const orr_model* m) {
 }
 
 int32_t orr_set_motion(orr_handle* h, int32_t clip_id, const float* frames_dev, const float* frame_vels_dev, int32_t num_frames,
-                       float frame_dt, int32_t clip_flags, const float cycle_delta[4]) {
+                       double frame_dt, int32_t clip_flags, const float cycle_delta[4]) {
   if (!h || !frames_dev || !frame_vels_dev || !cycle_delta) return fail(-1, "orr_set_motion: null argument");
   if (clip_id < 0 || clip_id >= ORR_MAX_CLIPS) return fail(-1, "orr_set_motion: clip_id out of range");
   if (num_frames < 2) return fail(-1, "orr_set_motion: need at least 2 frames");
-  if (!(frame_dt > 0.0f)) return fail(-1, "orr_set_motion: Frame duration must be positive.");
+  if (!(frame_dt > 0.0)) return fail(-1, "orr_set_motion: Frame duration must be positive.");
   DevClip c;
   c.frames = frames_dev; c.vels = frame_vels_dev; c.F = num_frames; c.flags = clip_flags;
-  c.dt = frame_dt; c.dur = frame_dt * (num_frames - 1);
+  c.dt_d = frame_dt; c.dur_d = c.dt_d * (num_frames - 1); c.sim_dt_d = dec7(h->cfg.sim_dt);
   c.cdp[0] = cycle_delta[0]; c.cdp[1] = cycle_delta[1]; c.cdp[2] = cycle_delta[2]; c.cdh = cycle_delta[3];
   h->tab_host.clip[clip_id] = c;
   HIPCHK(hipMemcpy(&h->tab_dev->clip[clip_id], &c, sizeof(DevClip), hipMemcpyHostToDevice), "orr_set_motion: hipMemcpy");

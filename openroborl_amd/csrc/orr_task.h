@@ -9,26 +9,28 @@ struct Sample {
   int f0, f1, count;
   float blend, phase;
 };
-__device__ __forceinline__ float clip_phase(const DevClip& c, float t) {  // motion_data.py:210-232
-  float ph = t / c.dur;
-  if (c.flags & ORR_CLIP_WRAP) ph -= floorf(ph);
-  else ph = fminf(fmaxf(ph, 0.0f), 1.0f);
+__device__ __forceinline__ double clip_phase_d(const DevClip& c, double t) {  // motion_data.py:210-232
+  double ph = t / c.dur_d;
+  if (c.flags & ORR_CLIP_WRAP) ph -= floor(ph);
+  else ph = fmin(fmax(ph, 0.0), 1.0);
   return ph;
 }
-__device__ __forceinline__ Sample clip_index(const DevClip& c, float t) {  // motion_data.py:234-253,682-718
+__device__ __forceinline__ float clip_phase(const DevClip& c, double t) { return (float)clip_phase_d(c, t); }
+__device__ __forceinline__ Sample clip_index(const DevClip& c, double t) {  // motion_data.py:234-253,682-718
   Sample s;
   const bool wrap = c.flags & ORR_CLIP_WRAP;
-  s.count = (int)floorf(t / c.dur);
+  s.count = (int)floor(t / c.dur_d);
   if (!wrap) s.count = s.count < 0 ? 0 : (s.count > 1 ? 1 : s.count);
-  s.phase = clip_phase(c, t);
-  if (!wrap && t <= 0.0f) { s.f0 = 0; s.f1 = 0; s.blend = 0.0f; }
-  else if (!wrap && t >= c.dur) { s.f0 = c.F - 1; s.f1 = c.F - 1; s.blend = 0.0f; }
+  const double ph = clip_phase_d(c, t);
+  s.phase = (float)ph;
+  if (!wrap && t <= 0.0) { s.f0 = 0; s.f1 = 0; s.blend = 0.0f; }
+  else if (!wrap && t >= c.dur_d) { s.f0 = c.F - 1; s.f1 = c.F - 1; s.blend = 0.0f; }
   else {
-    s.f0 = (int)(s.phase * (c.F - 1));
+    s.f0 = (int)(ph * (c.F - 1));
     s.f0 = s.f0 > c.F - 1 ? c.F - 1 : s.f0;
     s.f1 = s.f0 + 1 < c.F - 1 ? s.f0 + 1 : c.F - 1;
-    const float nt = s.phase * c.dur, t0 = s.f0 * c.dt, t1 = s.f1 * c.dt;
-    s.blend = s.f1 == s.f0 ? 0.0f : (nt - t0) / (t1 - t0);
+    const double nt = ph * c.dur_d, t0 = s.f0 * c.dt_d, t1 = s.f1 * c.dt_d;
+    s.blend = s.f1 == s.f0 ? 0.0f : (float)((nt - t0) / (t1 - t0));
   }
   return s;
 }
@@ -60,10 +62,10 @@ struct PoseLoads {
   float lo[11], hi[11], v0[2], v1[2];   // frame rows: word `lane` and, for lanes 0..2, word 16 + lane; frame velocities of lane 0's time
   Sample sm;
 };
-__device__ static void sample_poses_issue(const KParams& P, Shared& S, int lane, float t_lane, PoseLoads& L, int pt_slot = 32) {
+__device__ static void sample_poses_issue(const KParams& P, Shared& S, int lane, double t_lane, PoseLoads& L, int pt_slot = 32) {
   constexpr int nt = 5;   // update time + the four target times (compile-time: the staging arrays below must stay in registers)
   const DevClip& c = S.clip;
-  const Sample sm = clip_index(c, lane < nt ? t_lane : 0.0f);
+  const Sample sm = clip_index(c, lane < nt ? t_lane : 0.0);
   L.sm = sm;
   if (lane < nt) { S.ph.end.red[2 * lane] = __int_as_float(sm.f0); S.ph.end.red[2 * lane + 1] = __int_as_float(sm.f1); }
   WSYNC();
@@ -90,7 +92,7 @@ __device__ static void sample_poses_issue(const KParams& P, Shared& S, int lane,
   }
   WSYNC();   // red[] may be reused by the caller from here on
 }
-__device__ static void sample_poses_finish(const KParams& P, Shared& S, int lane, float t_lane, bool with_vel, const PoseLoads& L, int pt_slot = 32) {
+__device__ static void sample_poses_finish(const KParams& P, Shared& S, int lane, double t_lane, bool with_vel, const PoseLoads& L, int pt_slot = 32) {
   constexpr int nt = 5, kMaxE = 2 * nt;
   const DevClip& c = S.clip;
   const bool warm_ep = geti(S, O(WARMUP)) != 0;
@@ -107,7 +109,7 @@ __device__ static void sample_poses_finish(const KParams& P, Shared& S, int lane
   WSYNC();
   PT(pt_slot + 1);
   if (lane < nt) {
-    const bool warm_pose = warm_ep && t_lane >= -P.cfg.warmup_time && t_lane < 0.0f;
+    const bool warm_pose = warm_ep && t_lane >= -(double)P.cfg.warmup_time && t_lane < 0.0;
     float out[19];
     if (warm_pose) {
       // default pose rotated to the heading of frame(0) (imitation_task.py:985-1009, 1245-1252)
@@ -160,7 +162,7 @@ __device__ static void sample_poses_finish(const KParams& P, Shared& S, int lane
   }
   WSYNC();
 }
-__device__ static void sample_poses(const KParams& P, Shared& S, int lane, float t_lane, bool with_vel, int pt_slot = 32) {
+__device__ static void sample_poses(const KParams& P, Shared& S, int lane, double t_lane, bool with_vel, int pt_slot = 32) {
   PoseLoads L;
   sample_poses_issue(P, S, lane, t_lane, L, pt_slot);
   sample_poses_finish(P, S, lane, t_lane, with_vel, L, pt_slot);
@@ -178,9 +180,9 @@ __device__ static void apply_origin(Shared& S, int lane, int nt) {
   WSYNC();
 }
 
-__device__ __forceinline__ float motion_time(const KParams& P, const Shared& S) {  // imitation_task.py:831-848
-  float t = geti(S, O(STATE_ACTION_COUNTER)) * P.cfg.sim_dt + S.s[O(TIME_OFFSET)];
-  if (geti(S, O(WARMUP))) t -= P.cfg.warmup_time;
+__device__ __forceinline__ double motion_time(const KParams& P, const Shared& S) {  // imitation_task.py:831-848
+  double t = geti(S, O(STATE_ACTION_COUNTER)) * S.clip.sim_dt_d + (double)S.s[O(TIME_OFFSET)];
+  if (geti(S, O(WARMUP))) t -= (double)P.cfg.warmup_time;   // 0.25: exact in float32
   return t;
 }
 
@@ -413,15 +415,15 @@ __device__ static void reset_robot(const KParams& P, float* rec, Shared& S, int 
     const bool warm = (!ref_init) && c.warmup_time > 0.0f;
     if (lane == 0) {
       seti(S, O(WARMUP), warm ? 1 : 0);
-      S.s[O(TIME_OFFSET)] = warm ? u2 * c.warmup_time : u2 * clip.dur;
+      S.s[O(TIME_OFFSET)] = warm ? u2 * c.warmup_time : u2 * (float)clip.dur_d;
       S.s[O(ORIGIN_POS)] = 0.0f; S.s[O(ORIGIN_POS) + 1] = 0.0f; S.s[O(ORIGIN_POS) + 2] = 0.0f;
       S.s[O(ORIGIN_ROT)] = 0.0f; S.s[O(ORIGIN_ROT) + 1] = 0.0f; S.s[O(ORIGIN_ROT) + 2] = 0.0f; S.s[O(ORIGIN_ROT) + 3] = 1.0f;
     }
     WSYNC();
   }
-  const float t = motion_time(P, S);
-  const float step_dt = c.sim_dt * c.action_repeat;
-  float tl = t;
+  const double t = motion_time(P, S);
+  const double step_dt = S.clip.sim_dt_d * c.action_repeat;
+  double tl = t;
   {  // lanes 1..4: the four target times.  Selects over the four scalars: indexing the kernel argument with the lane makes the
      // compiler read it from memory with a vector load, whose wait also drains every store and atomic issued before it
     const int k = lane - 1;

@@ -83,6 +83,22 @@ def lib():
 
 
 _lib_f32 = None
+_lib_f32p = None
+
+
+def _declare_f32(L):
+    assert L.orc_sizeof_real() == 4
+    fp = C.POINTER(C.c_float)
+    L.orc_create.restype = C.c_void_p
+    L.orc_create.argtypes = [C.POINTER(_abi.OrrConfig)]
+    L.orc_destroy.argtypes = [C.c_void_p]
+    L.orc_set_threads.argtypes = [C.c_void_p, C.c_int]
+    L.orc_set_model.argtypes = [C.c_void_p, C.c_int, C.POINTER(_abi.OrrModel)]
+    L.orc_set_motion.argtypes = [C.c_void_p, C.c_int, fp, fp, C.c_int, C.c_float, C.c_int, fp]
+    L.orc_bind.argtypes = [C.c_void_p, C.POINTER(C.c_int64), fp, C.c_int]
+    L.orc_reset.argtypes = [C.c_void_p, fp, C.c_int, C.c_void_p, fp]
+    L.orc_step.argtypes = [C.c_void_p, fp, C.c_int, fp, fp, fp, C.c_void_p, fp]
+    return L
 
 
 def lib_f32(build_dir=None):
@@ -92,20 +108,21 @@ def lib_f32(build_dir=None):
     if _lib_f32 is None:
         so = os.path.join(build_dir or ORACLE_DIR, "liborr_oracle_f32.so")
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s", "-B", "f32native", "OUT=" + so])
-        L = C.CDLL(so)
-        assert L.orc_sizeof_real() == 4
-        fp = C.POINTER(C.c_float)
-        L.orc_create.restype = C.c_void_p
-        L.orc_create.argtypes = [C.POINTER(_abi.OrrConfig)]
-        L.orc_destroy.argtypes = [C.c_void_p]
-        L.orc_set_threads.argtypes = [C.c_void_p, C.c_int]
-        L.orc_set_model.argtypes = [C.c_void_p, C.c_int, C.POINTER(_abi.OrrModel)]
-        L.orc_set_motion.argtypes = [C.c_void_p, C.c_int, fp, fp, C.c_int, C.c_float, C.c_int, fp]
-        L.orc_bind.argtypes = [C.c_void_p, C.POINTER(C.c_int64), fp, C.c_int]
-        L.orc_reset.argtypes = [C.c_void_p, fp, C.c_int, C.c_void_p, fp]
-        L.orc_step.argtypes = [C.c_void_p, fp, C.c_int, fp, fp, fp, C.c_void_p, fp]
-        _lib_f32 = L
+        _lib_f32 = _declare_f32(C.CDLL(so))
     return _lib_f32
+
+
+def lib_f32p():
+    """The float32 build with the parity flags (make f32: -O2 -ffp-contract=off, no -march=native): the float32 noise floor the
+    drift calibration compares the HIP path with (tests/test_gpu_drift.py)."""
+    global _lib_f32p
+    if _lib_f32p is None:
+        so = os.path.join(ORACLE_DIR, "liborr_oracle_f32p.so")
+        src = os.path.join(ORACLE_DIR, "orr_oracle.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", ORACLE_DIR, "-s", "f32"])
+        _lib_f32p = _declare_f32(C.CDLL(so))
+    return _lib_f32p
 
 
 _layout = None
@@ -123,7 +140,8 @@ class OracleEnv(object):
 
     def __init__(self, cfg, models, clips, n, robot_type=0, clip_id=0, robot_index=None, threads=1,
                  ep_log_capacity=0, f32=False, build_dir=None):
-        self.L = lib_f32(build_dir) if f32 else lib()
+        # f32: False = the float64 parity oracle; True = -O3 -march=native float32 (timing row); "parity" = float32, parity flags
+        self.L = lib_f32p() if f32 == "parity" else (lib_f32(build_dir) if f32 else lib())
         dt = self.dt = np.float32 if f32 else np.float64
         ptr = C.POINTER(C.c_float if f32 else C.c_double)
 
