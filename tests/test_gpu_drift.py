@@ -1,0 +1,107 @@
+"""Float32 drift of the HIP path, calibrated against the float32 build of the oracle.
+
+"How much of (HIP - float64 oracle) after k env steps is float32 and how much would be a bug?"  The same C source compiled with
+`real = float` and the parity flags (make -C oracle f32) IS a float32 implementation of the algorithm; its distance from the
+float64 oracle is the noise floor (contact dynamics amplify rounding: the floor itself reaches 0.1 rad/s on joint rates after ONE
+env step in the worst robot of 1024).  The test asserts that the HIP path's error quantiles stay within a fixed factor of that
+floor, per field and horizon, and writes the table (gpurun_out/drift_<robot>.json; DESIGN.md section 7 quotes it).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from openroborl_amd import _abi, state as statemod
+from tests import drift, oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLIP = {"laikago": "laikago_pace", "mini_cheetah": "minicheetah_trot"}
+
+FACTOR, FLOOR = drift.FACTOR, drift.FLOOR
+
+
+def _three(robot, n, seed, randomizer=True, mode="train"):
+    import torch
+    from openroborl_amd.env import VecQuadrupedEnv
+    env = VecQuadrupedEnv(num_robot=n, seed=seed, robot=robot, motion_file=CLIP[robot], mode=mode, enable_randomizer=randomizer,
+                          auto_reset=False, config_overrides=dict(ep_len_start=600))      # no 20-step time limit inside the horizon
+    o64 = ol.OracleEnv(env.cfg, env.models, env.clips, n, robot_type=env.robot_type, clip_id=env.clip_id, threads=16)
+    o32 = ol.OracleEnv(env.cfg, env.models, env.clips, n, robot_type=env.robot_type, clip_id=env.clip_id, threads=16, f32="parity")
+    obs = env.reset().cpu().numpy()
+    o64.reset(); o32.reset()
+    st = statemod.to_float64(env.layout, env.state.detach().cpu().numpy())      # ONE float32-representable start for all three
+    o64.state[:] = st
+    o32.state[:] = st.astype(np.float32)
+    o64.obs[:] = obs
+    o32.obs[:] = obs
+
+    def dev_step(a):
+        og, rg, dg, _ = env.step(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(env.device))
+        return og.cpu().numpy().astype(np.float64), rg.cpu().numpy().astype(np.float64), dg.cpu().numpy().astype(bool)
+
+    def dev_state():
+        return statemod.to_float64(env.layout, env.state.detach().cpu().numpy())
+    return env, o64, o32, dev_step, dev_state
+
+
+@pytest.mark.parametrize("robot", ["laikago", "mini_cheetah"])
+def test_hip_drift_is_float32_drift(robot):
+    n = 1024
+    env, o64, o32, dev_step, dev_state = _three(robot, n, seed=31)
+    out, alive = drift.run_three_way(dev_step, dev_state, o64, o32, env.layout, env.models, env.robot_type, steps=25, seed=1)
+    tab = drift.quantile_table(out, alive)
+    text = drift.format_table(tab, "%s, %d robots, randomiser on, actions = reference pose + N(0, 0.125^2)" % (robot, n))
+    print("\n" + text)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(tab, open(os.path.join(ROOT, "gpurun_out", "drift_%s.json" % robot), "w"), indent=1)
+    open(os.path.join(ROOT, "gpurun_out", "drift_%s.txt" % robot), "w").write(text + "\n")
+    bad = []
+    for h in drift.HORIZONS:
+        assert tab[h]["alive"] >= 100, "too few robots survive to horizon %d" % h
+        for name in list(drift.FIELDS) + [g for g, _ in drift.OBS_GROUPS] + ["reward"]:
+            for q, fac in FACTOR.items():
+                d, f = tab[h][name]["dev"][q], tab[h][name]["f32"][q]
+                if d > fac * f + FLOOR:
+                    bad.append("%s h=%d %s: HIP %.3g > %.1f x f32 %.3g" % (name, h, q, d, fac, f))
+    assert not bad, "\n".join(bad)
+    env.close(); o64.close(); o32.close()
+
+
+def test_latency_ring_multi_step_without_resync():
+    """The ring test of round 2 (test_gpu_parity.test_latency_ring_wraps_with_random_latency) copies the device state into the oracle
+    before every env step since commit 54babc4, after one robot's base-rate entries had differed by 0.42 over three un-synced steps.
+    Here the same scenario (seed 11, 64 robots, latencies 0-40 ms, three env steps = 99 pushes into the 44-deep ring) runs WITHOUT
+    re-sync on three sides: ring cursors must agree exactly, and the ring contents / delayed observations of the HIP path must be no
+    further from the float64 oracle than the float32 oracle's worst robot is (x FACTOR) -- the outlier is contact chaos, it shows in the
+    float32 oracle too."""
+    n = 64
+    env, o64, o32, dev_step, dev_state = _three("laikago", n, seed=11)
+    rng = np.random.RandomState(3)
+    acts = [rng.uniform(-0.15, 0.15, (n, 12)).astype(np.float32) for _ in range(3)]
+    out, alive = drift.run_three_way(dev_step, dev_state, o64, o32, env.layout, env.models, env.robot_type, steps=3, actions=acts)
+    lat = env.field("LATENCY")[:, 0].cpu().numpy()
+    assert lat.max() > 0.03 and lat.min() < 0.01
+    g = dev_state()
+    lay = env.layout
+    for name in ("RING_LEN", "RING_HEAD"):
+        np.testing.assert_array_equal(g[:, lay.sl(name)], o64.state[:, lay.sl(name)])
+        np.testing.assert_array_equal(o32.state[:, lay.sl(name)].astype(np.float64), o64.state[:, lay.sl(name)])
+    m = alive[3]
+    assert m.mean() > 0.9
+    sl = lay.sl("RING")
+    shape = (-1, _abi.RING_DEPTH, _abi.RING_ENTRY)
+    rg, r64, r32 = g[m][:, sl].reshape(shape), o64.state[m][:, sl].reshape(shape), o32.state[m][:, sl].astype(np.float64).reshape(shape)
+    report = []
+    for what, cols in (("angles+quat", slice(0, 16)), ("base rates", slice(16, 19))):
+        eg = np.abs(rg[:, :, cols] - r64[:, :, cols]).max(axis=(1, 2))
+        e32 = np.abs(r32[:, :, cols] - r64[:, :, cols]).max(axis=(1, 2))
+        report.append("%s: HIP median %.2e p99 %.2e max %.2e (robot %d) | f32 oracle median %.2e p99 %.2e max %.2e (robot %d)" % (
+            what, np.median(eg), np.percentile(eg, 99), eg.max(), np.nonzero(m)[0][eg.argmax()],
+            np.median(e32), np.percentile(e32, 99), e32.max(), np.nonzero(m)[0][e32.argmax()]))
+        assert np.median(eg) <= FACTOR["median"] * np.median(e32) + FLOOR, report[-1]
+        assert eg.max() <= FACTOR["max"] * e32.max() + FLOOR, report[-1]
+    print("\nRING_DRIFT " + "\nRING_DRIFT ".join(report))
+    open(os.path.join(ROOT, "gpurun_out", "drift_ring.txt"), "w").write("\n".join(report) + "\n")
+    env.close(); o64.close(); o32.close()

@@ -28,6 +28,25 @@ def make_pair(robot="laikago", n=32, randomizer=False, auto_reset=False, seed=3,
     return env, orc
 
 
+def f32_twin(env, orc):
+    """The float32 build of the oracle (make -C oracle f32) in the state of `orc`: its distance from `orc` after the same actions is the
+    float32 NOISE FLOOR the HIP path is measured against (tests/drift.py, tests/test_gpu_drift.py) instead of hand-set tolerances."""
+    o32 = ol.OracleEnv(env.cfg, env.models, env.clips, orc.n, robot_type=env.robot_type, clip_id=env.clip_id, threads=8, f32="parity")
+    o32.reset()
+    o32.state[:] = orc.state.astype(np.float32)
+    return o32
+
+
+def compare_to_floor(env, orc, o32, names, what, mask=None):
+    from tests import drift
+    g = gpu_state64(env)
+    m = slice(None) if mask is None else mask
+    for name in names:
+        sl = env.layout.sl(name)
+        drift.assert_within_float32_floor(np.abs(g[m][:, sl] - orc.state[m][:, sl]).max(axis=1),
+                                          np.abs(o32.state[m][:, sl].astype(np.float64) - orc.state[m][:, sl]).max(axis=1), "%s %s" % (what, name))
+
+
 def gpu_state64(env):
     return statemod.to_float64(env.layout, env.state.detach().cpu().numpy())
 
@@ -97,48 +116,58 @@ def test_reset_parity(robot, randomizer):
 @pytest.mark.parametrize("robot,randomizer", [("laikago", False), ("laikago", True), ("mini_cheetah", False)])
 def test_step_parity(robot, randomizer):
     import torch
-    n = 64
+    n = 256
     env, orc = make_pair(robot, n=n, randomizer=randomizer, mode="train" if randomizer else "test")
     env.reset(); orc.reset()
     # identical starting point on both sides (float32-representable)
     st = gpu_state64(env)
     orc.state[:] = st
+    o32 = f32_twin(env, orc)
     rng = np.random.RandomState(5)
     act = torch.tensor(rng.uniform(-0.3, 0.3, (n, 12)), dtype=torch.float32, device=env.device)
     og, rg, dg, _ = env.step(act)
     oo, ro, do = orc.step(act.cpu().numpy().astype(np.float64))
+    o3, r3, d3 = o32.step(act.cpu().numpy())
     og, rg, dg = og.cpu().numpy(), rg.cpu().numpy(), dg.cpu().numpy().astype(bool)
-    compare_fields(env, orc, ["POS", "QUAT", "Q"], atol=2e-4, what="step")
-    compare_fields(env, orc, ["LINVEL", "ANGVEL", "QD"], atol=2e-2, rtol=2e-3, what="step")
+    # 33 sub-steps of contact dynamics amplify float32 rounding (the float32 ORACLE is up to 1e-2 rad/s off on the base rates and
+    # 0.1-1 rad/s on the joint rates in the worst robot after ONE env step, tests/test_gpu_drift.py): the bound is that floor, measured
+    # on the same robots, not a hand-set tolerance (round 2: atol 2e-4 / 2e-2)
+    compare_to_floor(env, orc, o32, RIGID, "step")
     compare_fields(env, orc, ["ACTION", "FILTER_ACTION", "LAST_ACTION", "XHIST", "YHIST", "TIME_OFFSET", "ORIGIN_ROT",
                               "PREV_PHASE", "REF_POSE"], atol=5e-6, what="step")
     compare_fields(env, orc, ["STATE_ACTION_COUNTER", "STEP_COUNTER", "FILTER_VALID", "RING_LEN", "RING_HEAD", "EP_STEP",
                               "WARMUP", "MAX_EP_STEPS", "EPISODE_IDX"], atol=0, what="step")
-    np.testing.assert_allclose(rg, ro, atol=3e-3)
-    np.testing.assert_allclose(og[:, :12], oo[:, :12], atol=2e-2, rtol=1e-2)       # IMU (rates are noisy)
-    np.testing.assert_allclose(og[:, 12:84], oo[:, 12:84], atol=5e-4)              # last action + motor angles
-    np.testing.assert_allclose(og[:, 84:], oo[:, 84:], atol=5e-4)                  # target frames
+    from tests import drift
+    drift.assert_within_float32_floor(np.abs(rg - ro), np.abs(r3.astype(np.float64) - ro), "step reward")
+    for what, sl in drift.OBS_GROUPS:                                              # IMU | last action + motor angles | target frames
+        drift.assert_within_float32_floor(np.abs(og[:, sl] - oo[:, sl]).max(axis=1), np.abs(o3[:, sl].astype(np.float64) - oo[:, sl]).max(axis=1),
+                                          "step " + what)
     assert (dg == do).mean() > 0.97
-    env.close(); orc.close()
+    env.close(); orc.close(); o32.close()
 
 
 def test_short_rollout_tracks_oracle():
     """10 env steps from an identical start: trajectories stay close (loose: contact dynamics amplify rounding)."""
     import torch
-    n = 32
+    n = 256       # quantiles of a heavy-tailed error distribution: 32 robots are too few for a stable median
     env, orc = make_pair("laikago", n=n)
     env.reset(); orc.reset()
     orc.state[:] = gpu_state64(env)
+    o32 = f32_twin(env, orc)
     rng = np.random.RandomState(9)
+    alive = np.ones(n, dtype=bool)
     for k in range(10):
         a = rng.uniform(-0.2, 0.2, (n, 12)).astype(np.float32)
         og, rg, dg, _ = env.step(torch.from_numpy(a).to(env.device))
         oo, ro, do = orc.step(a.astype(np.float64))
-    np.testing.assert_allclose(rg.cpu().numpy(), ro, atol=0.05)
-    g = gpu_state64(env)
-    sl = env.layout.sl("POS")
-    assert np.median(np.abs(g[:, sl] - orc.state[:, sl])) < 2e-3
-    env.close(); orc.close()
+        o3, r3, d3 = o32.step(a)
+        if k < 9:
+            alive &= ~(dg.cpu().numpy().astype(bool) | do | d3)
+    assert alive.mean() > 0.8
+    from tests import drift
+    drift.assert_within_float32_floor(np.abs(rg.cpu().numpy() - ro)[alive], np.abs(r3.astype(np.float64) - ro)[alive], "10-step reward")
+    compare_to_floor(env, orc, o32, RIGID + ["REF_POSE"], "10 steps", mask=alive)
+    env.close(); orc.close(); o32.close()
 
 
 def test_mixed_batch_parity():
@@ -242,7 +271,7 @@ def test_rollout_across_cycle_wrap_tracks_oracle():
     """25 env steps (> one pace cycle of 19.2 steps) so every robot passes the cycle-sync re-anchoring of
     ImitationTask._sync_ref_origin (imitation_task.py:751-754,1047-1053) at least once."""
     import torch
-    n = 32
+    n = 128
     env, orc = make_pair("laikago", n=n, seed=13)
     env.reset(); orc.reset()
     orc.state[:] = gpu_state64(env)
@@ -254,22 +283,22 @@ def test_rollout_across_cycle_wrap_tracks_oracle():
         return np.clip(h @ W["model__pi__w_0"] + W["model__pi__b_0"], -2 * np.pi, 2 * np.pi)
     og = env.obs.cpu().numpy().astype(np.float64)
     origin0 = orc.field("ORIGIN_POS").copy()
+    o32 = f32_twin(env, orc)
     for k in range(25):
-        a = policy(og).astype(np.float32)         # same actions on both sides (driven by the GPU observation)
+        a = policy(og).astype(np.float32)         # same actions on all sides (driven by the GPU observation)
         o_t, rg, dg, _ = env.step(torch.from_numpy(a).to(env.device))
         oo, ro, do = orc.step(a.astype(np.float64))
+        o3, r3, d3 = o32.step(a)
         og = o_t.cpu().numpy().astype(np.float64)
     moved = np.abs(orc.field("ORIGIN_POS") - origin0).max(axis=1) > 1e-6
     warm = orc.field("WARMUP")[:, 0] > 0
     assert moved[~warm].all()                      # the wrap happened for every non-warm-up robot
-    g = gpu_state64(env)
-    for name, tol in (("ORIGIN_POS", 2e-2), ("POS", 2e-2), ("REF_POSE", 2e-2)):
-        sl = env.layout.sl(name)
-        assert np.median(np.abs(g[:, sl] - orc.state[:, sl])) < tol / 10, name
-        assert np.abs(g[:, sl] - orc.state[:, sl]).max() < tol * 5, name
-    np.testing.assert_allclose(rg.cpu().numpy(), ro, atol=0.1)
+    # after 25 env steps of contacts the bound is the float32 oracle's own drift on the same robots (round 2: hand-set 2e-3 .. 0.1)
+    from tests import drift
+    compare_to_floor(env, orc, o32, ["ORIGIN_POS", "POS", "REF_POSE", "QUAT", "Q"], "25 steps")
+    drift.assert_within_float32_floor(np.abs(rg.cpu().numpy() - ro), np.abs(r3.astype(np.float64) - ro), "25-step reward")
     assert (dg.cpu().numpy().astype(bool) == do).all()
-    env.close(); orc.close()
+    env.close(); orc.close(); o32.close()
 
 
 def test_device_policy_rollout_and_gae():
