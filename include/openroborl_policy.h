@@ -65,6 +65,16 @@ int32_t orr_policy_forward(const orr_policy_net* net, const float* obs, int32_t 
 int32_t orr_gae(const float* rewards, const float* vpred, const uint8_t* dones, const float* bootstrap, int32_t t, int32_t n,
                 float gamma, float lam, int32_t normalize, float eps, float* adv, float* ret, void* stream);
 
+/* The same with flags.  ORR_GAE_LEGACY_INDEX reproduces the reference's recursion for num_robot > 1 bit for bit in its INDEXING:
+ * add_vtarg_and_adv reads `episode_starts[(step*num_robot+i) + (1+i)]` (agents/ppo_imitation.py:88), i.e. the episode-start flag of
+ * robot (2i+1) mod N at step t + (2i+1)/N instead of robot i's own at t+1 (identical only for N = 1).  For users who compare learning
+ * curves with the reference at its default num_robot: 2.  first_starts [N] uint8 = episode_starts of the segment's first step
+ * (NULL = all 1: a segment that begins with fresh episodes). */
+#define ORR_GAE_NORMALIZE 1
+#define ORR_GAE_LEGACY_INDEX 2
+int32_t orr_gae_flags(const float* rewards, const float* vpred, const uint8_t* dones, const uint8_t* first_starts, const float* bootstrap,
+                      int32_t t, int32_t n, float gamma, float lam, int32_t flags, float eps, float* adv, float* ret, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

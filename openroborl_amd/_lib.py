@@ -34,7 +34,7 @@ EXPORTS = [
     "orr_layout_offset", "orr_layout_size", "orr_layout_is_int", "orr_sizeof_config", "orr_sizeof_model",
     "orr_create", "orr_destroy", "orr_set_seed", "orr_set_model", "orr_set_motion", "orr_bind", "orr_reset", "orr_step",
     "orr_episode_stats", "orr_time_steps", "orr_debug_physics", "orr_debug_replay_step", "orr_debug_replay_reset",
-    "orr_policy_packed_size", "orr_policy_pack", "orr_policy_forward", "orr_gae",
+    "orr_policy_packed_size", "orr_policy_pack", "orr_policy_forward", "orr_gae", "orr_gae_flags",
 ]
 
 
@@ -198,6 +198,8 @@ def load():
     L.orr_policy_pack.argtypes = [vp, C.c_int32, C.c_int32, vp, vp]
     L.orr_gae.restype = C.c_int32
     L.orr_gae.argtypes = [vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_float, vp, vp, vp]
+    L.orr_gae_flags.restype = C.c_int32
+    L.orr_gae_flags.argtypes = [vp, vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_float, vp, vp, vp]
     L.orr_policy_forward.restype = C.c_int32
     L.orr_policy_forward.argtypes = [C.POINTER(_abi.OrrPolicyNet), vp, C.c_int32, vp, C.c_float, C.c_float, vp, vp, vp, vp, vp]
     if L.orr_abi_version() != _abi.ABI_VERSION:

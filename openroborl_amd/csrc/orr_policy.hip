@@ -182,16 +182,28 @@ __global__ __launch_bounds__(256) void forward_kernel(Params P) {
 }
 
 // One thread per robot: backward recursion over the segment, then mean / variance / standardisation of its own T values.
+// legacy (ORR_GAE_LEGACY_INDEX): the recursion's "nonterminal" is read where the reference reads it, episode_starts[(step * N + i) + (1 + i)]
+// of the flat [T * N] (+ N x False) array (agents/ppo_imitation.py:88) - robot i's own next-step flag only for N = 1, otherwise the flag of
+// robot (2 i + 1) mod N at step t + (2 i + 1) / N.  episode_starts[t'][j] = done[t' - 1][j], and first_starts[j] for t' = 0.  The
+// one-step value target still uses the robot's own flag (nextvpreds is filled per robot by the runner, imitation_runners.py:174-188).
 __global__ void gae_kernel(const float* __restrict__ rewards, const float* __restrict__ vpred, const uint8_t* __restrict__ dones,
-                           const float* __restrict__ bootstrap, int T, int N, float gamma, float lam, int normalize, float eps,
-                           float* __restrict__ adv, float* __restrict__ ret) {
+                           const uint8_t* __restrict__ first_starts, const float* __restrict__ bootstrap, int T, int N, float gamma,
+                           float lam, int flags, float eps, float* __restrict__ adv, float* __restrict__ ret) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
+  const bool normalize = flags & ORR_GAE_NORMALIZE, legacy = flags & ORR_GAE_LEGACY_INDEX;
   float last = 0.0f, next_v = bootstrap ? bootstrap[n] : 0.0f, sum = 0.0f;
   for (int k = T - 1; k >= 0; k--) {
     const size_t o = (size_t)k * N + n;
-    const float nonterminal = dones[o] ? 0.0f : 1.0f, v = vpred[o];
-    const float delta = rewards[o] + gamma * next_v * nonterminal - v;
+    const float own = dones[o] ? 0.0f : 1.0f, v = vpred[o];
+    float nonterminal = own;
+    if (legacy) {
+      const long long f = (long long)k * N + 2 * n + 1;
+      const int ts = (int)(f / N), js = (int)(f % N);
+      const bool start = ts >= T ? false : (ts == 0 ? (first_starts ? first_starts[js] != 0 : true) : dones[(size_t)(ts - 1) * N + js] != 0);
+      nonterminal = start ? 0.0f : 1.0f;
+    }
+    const float delta = rewards[o] + gamma * next_v * own - v;
     last = delta + gamma * lam * nonterminal * last;
     adv[o] = last;
     ret[o] = last + v;
@@ -240,15 +252,21 @@ int32_t orr_policy_forward(const orr_policy_net* net, const float* obs, int32_t 
   return 0;
 }
 
-int32_t orr_gae(const float* rewards, const float* vpred, const uint8_t* dones, const float* bootstrap, int32_t t, int32_t n,
-                float gamma, float lam, int32_t normalize, float eps, float* adv, float* ret, void* stream) {
+int32_t orr_gae_flags(const float* rewards, const float* vpred, const uint8_t* dones, const uint8_t* first_starts, const float* bootstrap,
+                      int32_t t, int32_t n, float gamma, float lam, int32_t flags, float eps, float* adv, float* ret, void* stream) {
   if (!rewards || !vpred || !dones || !adv || !ret || t <= 0 || n < 0) return orr_fail(-1, "orr_gae: bad argument", hipSuccess);
+  if (flags & ~(ORR_GAE_NORMALIZE | ORR_GAE_LEGACY_INDEX)) return orr_fail(-1, "orr_gae: unknown flag", hipSuccess);
   if (n == 0) return 0;
-  hipLaunchKernelGGL(gae_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rewards, vpred, dones, bootstrap,
-                     (int)t, (int)n, gamma, lam, (int)normalize, eps, adv, ret);
+  hipLaunchKernelGGL(gae_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rewards, vpred, dones, first_starts,
+                     bootstrap, (int)t, (int)n, gamma, lam, (int)flags, eps, adv, ret);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return orr_fail(-2, "orr_gae: launch", e);
   return 0;
+}
+
+int32_t orr_gae(const float* rewards, const float* vpred, const uint8_t* dones, const float* bootstrap, int32_t t, int32_t n,
+                float gamma, float lam, int32_t normalize, float eps, float* adv, float* ret, void* stream) {
+  return orr_gae_flags(rewards, vpred, dones, nullptr, bootstrap, t, n, gamma, lam, normalize ? ORR_GAE_NORMALIZE : 0, eps, adv, ret, stream);
 }
 
 }  // extern "C"

@@ -10,9 +10,9 @@ Semantics kept from the reference: gamma = lam = 0.95 (run.py:113,120); the valu
 0 and -- the reference's quirk -- so is the bootstrap value at the end of a segment
 (imitation_runners.py:98-100 `last_vpred = 0.0`); advantages are standardised per robot over the segment.
 Deliberate divergences: robots reset individually (auto-reset inside env.step) instead of the whole env
-resetting when any robot is done, and the GAE recursion uses each robot's own done flags (the reference
+resetting when any robot is done, and the GAE recursion uses each robot's own done flags by default (the reference
 indexes `episode_starts[(step*num_robot+i) + (1+i)]`, ppo_imitation.py:88, which reads a neighbouring
-robot's flag).
+robot's flag; `legacy_gae_index=True` reproduces exactly that, for comparisons with the reference at num_robot > 1).
 """
 
 
@@ -54,9 +54,24 @@ def collect_rollout(env, policy, horizon, obs=None, deterministic=False, generat
     return buf
 
 
-def gae(rewards, vpred, dones, gamma=0.95, lam=0.95, bootstrap=None):
+def legacy_nonterminal(dones, first_starts=None):
+    """The flags the reference's recursion actually reads for num_robot > 1: `1 - episode_starts[(step*N+i) + (1+i)]` of the flat
+    [T*N] (+ N x False) array (agents/ppo_imitation.py:75,88), with episode_starts[t] = done[t-1] (imitation_runners.py:178) and
+    `first_starts` ([N] bool, default all True) for the first step of the segment."""
+    import torch
+    T, n = dones.shape
+    starts = torch.empty((T + 1, n), dtype=torch.bool, device=dones.device)
+    starts[0] = True if first_starts is None else first_starts.to(torch.bool)
+    starts[1:T] = dones[:-1]
+    flat = torch.cat([starts[:T].reshape(-1), torch.zeros(2 * n, dtype=torch.bool, device=dones.device)])
+    idx = (torch.arange(T, device=dones.device)[:, None] * n + 2 * torch.arange(n, device=dones.device)[None, :] + 1)
+    return ~flat[idx]
+
+
+def gae(rewards, vpred, dones, gamma=0.95, lam=0.95, bootstrap=None, legacy_gae_index=False, first_starts=None):
     """Per-robot GAE(lambda) on [T, N] tensors.  next value = vpred[t+1] unless the episode ended at t (then 0);
-    at the end of the segment `bootstrap` ([N], default 0 like the reference)."""
+    at the end of the segment `bootstrap` ([N], default 0 like the reference).  legacy_gae_index=True reproduces the reference's
+    neighbouring-robot flag index in the recursion (see legacy_nonterminal; identical for N = 1)."""
     import torch
     T, n = rewards.shape
     nonterminal = (~dones).to(rewards.dtype)
@@ -65,10 +80,11 @@ def gae(rewards, vpred, dones, gamma=0.95, lam=0.95, bootstrap=None):
     nxt[-1] = 0.0 if bootstrap is None else bootstrap
     nxt = nxt * nonterminal
     delta = rewards + gamma * nxt - vpred
+    rec = legacy_nonterminal(dones, first_starts).to(rewards.dtype) if legacy_gae_index else nonterminal
     adv = torch.empty_like(rewards)
     last = torch.zeros(n, dtype=rewards.dtype, device=rewards.device)
     for k in range(T - 1, -1, -1):
-        last = delta[k] + gamma * lam * nonterminal[k] * last
+        last = delta[k] + gamma * lam * rec[k] * last
         adv[k] = last
     return adv, adv + vpred
 
@@ -78,8 +94,8 @@ def normalize_per_robot(adv, eps=0.0):
     return (adv - adv.mean(dim=0, keepdim=True)) / (adv.std(dim=0, unbiased=False, keepdim=True) + eps)
 
 
-def gae_fused(rewards, vpred, dones, gamma=0.95, lam=0.95, bootstrap=None, normalize=True, eps=0.0):
-    """gae() + normalize_per_robot() in one HIP launch (include/openroborl_policy.h: orr_gae).  GPU tensors only;
+def gae_fused(rewards, vpred, dones, gamma=0.95, lam=0.95, bootstrap=None, normalize=True, eps=0.0, legacy_gae_index=False, first_starts=None):
+    """gae() + normalize_per_robot() in one HIP launch (include/openroborl_policy.h: orr_gae_flags).  GPU tensors only;
     returns (advantages [T,N] - standardised per robot when `normalize` -, TD(lambda) targets [T,N])."""
     import ctypes as C
     import torch
@@ -91,6 +107,9 @@ def gae_fused(rewards, vpred, dones, gamma=0.95, lam=0.95, bootstrap=None, norma
     adv, ret = torch.empty_like(rewards), torch.empty_like(rewards)
     boot = None if bootstrap is None else bootstrap.to(rewards.dtype).contiguous()
     stream = C.c_void_p(torch.cuda.current_stream(rewards.device).cuda_stream)
-    _lib.check(L.orr_gae(rewards.data_ptr(), vpred.data_ptr(), d8.data_ptr(), None if boot is None else boot.data_ptr(), int(T), int(n),
-                         float(gamma), float(lam), int(bool(normalize)), float(eps), adv.data_ptr(), ret.data_ptr(), stream), L)
+    fs = None if first_starts is None else first_starts.to(torch.uint8).contiguous()
+    flags = (1 if normalize else 0) | (2 if legacy_gae_index else 0)          # ORR_GAE_NORMALIZE | ORR_GAE_LEGACY_INDEX
+    _lib.check(L.orr_gae_flags(rewards.data_ptr(), vpred.data_ptr(), d8.data_ptr(), None if fs is None else fs.data_ptr(),
+                               None if boot is None else boot.data_ptr(), int(T), int(n), float(gamma), float(lam), flags, float(eps),
+                               adv.data_ptr(), ret.data_ptr(), stream), L)
     return adv, ret

@@ -36,7 +36,9 @@ def lib():
     if _lib is None:
         so = os.path.join(ORACLE_DIR, "liborr_oracle.so")
         src = os.path.join(ORACLE_DIR, "orr_oracle.c")
-        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        if os.environ.get("ORR_ORACLE_SO"):      # e.g. the sanitizer build (tests/test_oracle_sanitizer.py)
+            so = os.environ["ORR_ORACLE_SO"]
+        elif not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
             subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
         L = C.CDLL(so)
         L.orc_create.restype = C.c_void_p

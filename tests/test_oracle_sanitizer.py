@@ -1,0 +1,57 @@
+"""The CPU sanitizer build of the oracle actually gets exercised: `make -C oracle asan`
+(-fsanitize=address,undefined), then - in a subprocess with the sanitizer runtime preloaded - the golden replay of the reference's
+own env run (task_laikago.npz: resets, 33-sub-step steps, randomiser, ring, reward, termination), a batch of physics sub-steps on
+the seeded parity inputs, and plain reset / step calls with auto-reset.  Any out-of-bounds access, use-after-free or undefined
+behaviour (signed overflow, bad shifts, misaligned or null access) aborts the child.  GPU AddressSanitizer is not available on this
+pool; the HIP side has the in-kernel non-finite guard (ORR_DONE_NAN) instead."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+from tests import oracle_lib as ol
+from tests import test_oracle_golden_task as tg
+from tests.parity_inputs import substep_parity_inputs
+assert "asan" in ol.lib()._name
+seen = tg._replay("task_laikago.npz")
+assert seen["wrap"] >= 3 and seen["done_fall"] >= 2, seen
+from tests.test_oracle_env import make
+for robot in ("laikago", "mini_cheetah"):
+    env, model, clip = make(robot, n=8, randomizer=True, auto_reset=True, mode="train", seed=3)
+    env.reset()
+    _, _, _, st, tau = substep_parity_inputs(robot, 8)
+    keep = env.state.copy()
+    env.state[:] = st
+    for i in range(8):
+        for _ in range(8):
+            env.L.orc_physics_substep(env.h, ol.P(env.state[i]), ol.P(np.ascontiguousarray(tau[i])))
+    assert np.isfinite(env.state[:, :37]).all()
+    env.state[:] = keep
+    rng = np.random.RandomState(0)
+    for k in range(25):                       # crosses the 20-step time limit: auto-reset inside orc_step
+        obs, rew, done = env.step(rng.uniform(-0.3, 0.3, (8, 12)))
+    assert np.isfinite(obs).all() and np.isfinite(rew).all()
+    env.close()
+print("SANITIZED_OK")
+"""
+
+
+def test_oracle_under_address_and_undefined_behaviour_sanitizers():
+    asan_rt = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(asan_rt) or not os.path.exists(asan_rt):
+        pytest.skip("no libasan for this gcc")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "asan"])
+    so = os.path.join(ROOT, "oracle", "liborr_oracle_asan.so")
+    env = dict(os.environ, LD_PRELOAD=asan_rt, ORR_ORACLE_SO=so, PYTHONDONTWRITEBYTECODE="1", OMP_NUM_THREADS="1",
+               ASAN_OPTIONS="detect_leaks=0:halt_on_error=1:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    out = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], capture_output=True, text=True, env=env, timeout=900)
+    tail = (out.stdout + out.stderr)[-4000:]
+    assert out.returncode == 0 and "SANITIZED_OK" in out.stdout, tail
+    assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr, tail

@@ -60,6 +60,44 @@ def test_reference_quirk_for_three_robots_is_understood():
     np.testing.assert_allclose(nrm.numpy(), c["adv_normalized"], atol=2e-5)
 
 
+def test_legacy_gae_index_reproduces_the_reference_for_three_robots():
+    """legacy_gae_index=True: the reference's own output for num_robot = 3 (fixture n3_T40, produced by executing the source text of
+    add_vtarg_and_adv), not the per-robot recursion."""
+    import torch
+    from openroborl_amd import rollout
+    c = _case("n3_T40")
+    adv, ret = rollout.gae(torch.tensor(c["rewards"]), torch.tensor(c["vpred"]), torch.tensor(c["dones"]), 0.95, 0.95, legacy_gae_index=True)
+    np.testing.assert_allclose(adv.numpy(), c["adv"], atol=3e-6)
+    np.testing.assert_allclose(ret.numpy(), c["tdlamret"], atol=3e-6)
+    for name in N1:         # for one robot the switch changes nothing
+        c1 = _case(name)
+        a1, _ = rollout.gae(torch.tensor(c1["rewards"]), torch.tensor(c1["vpred"]), torch.tensor(c1["dones"]), 0.95, 0.95, legacy_gae_index=True)
+        np.testing.assert_allclose(a1.numpy(), c1["adv"], atol=3e-6)
+
+
+@pytest.mark.gpu
+def test_hip_legacy_gae_index_matches_reference_for_three_robots():
+    import torch
+    from openroborl_amd import rollout
+    c = _case("n3_T40")
+    dev = torch.device("cuda:0")
+    r, v, d = (torch.tensor(c[k], device=dev) for k in ("rewards", "vpred", "dones"))
+    adv, ret = rollout.gae_fused(r, v, d, 0.95, 0.95, normalize=False, legacy_gae_index=True)
+    np.testing.assert_allclose(adv.cpu().numpy(), c["adv"], atol=3e-6)
+    np.testing.assert_allclose(ret.cpu().numpy(), c["tdlamret"], atol=3e-6)
+    nrm, _ = rollout.gae_fused(r, v, d, 0.95, 0.95, normalize=True, legacy_gae_index=True)
+    np.testing.assert_allclose(nrm.cpu().numpy(), c["adv_normalized"], atol=5e-5)
+    # first_starts is honoured: with "no episode starts at the segment's first step" only robots whose index lands in step 0 change
+    fs = torch.zeros(3, dtype=torch.bool, device=dev)
+    a2, _ = rollout.gae_fused(r, v, d, 0.95, 0.95, normalize=False, legacy_gae_index=True, first_starts=fs)
+    a2t, _ = rollout.gae(r.cpu(), v.cpu(), d.cpu(), 0.95, 0.95, legacy_gae_index=True, first_starts=fs.cpu())
+    np.testing.assert_allclose(a2.cpu().numpy(), a2t.numpy(), atol=3e-6)
+    # and the default path is untouched
+    mine, _ = rollout.gae_fused(r, v, d, 0.95, 0.95, normalize=False)
+    ref, _ = rollout.gae(r.cpu(), v.cpu(), d.cpu(), 0.95, 0.95)
+    np.testing.assert_allclose(mine.cpu().numpy(), ref.numpy(), atol=3e-6)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", N1)
 def test_hip_gae_matches_reference_for_one_robot(name):

@@ -32,6 +32,9 @@ def main():
     ap.add_argument("--torch-policy", action="store_true", help="rollout policy through plain torch instead of the fused HIP kernel")
     ap.add_argument("--eval", default="", help="evaluate a policy zip instead of training: deterministic actions, test mode "
                                                  "(no randomiser, full-length episodes), like `run.py --mode test`")
+    ap.add_argument("--legacy-gae-index", action="store_true",
+                    help="reproduce the reference's neighbouring-robot episode-start index in the GAE recursion (ppo_imitation.py:88); "
+                         "only for curve-by-curve comparisons with the reference at num_robot > 1")
     ap.add_argument("--tune-gemms", action="store_true", help="let PyTorch's TunableOp pick the learner's GEMM kernels (+7 %% samples/s after ~10 s of tuning)")
     args = ap.parse_args()
 
@@ -59,6 +62,7 @@ def main():
     t0 = time.time()
     samples = 0
     log = []
+    first_starts = None                   # episode_starts of a segment's first step = the last step's done flags of the previous segment
     for it in range(args.iters):
         buf = rollout.collect_rollout(env, model, args.horizon, obs=obs, generator=gen)
         obs = buf["last_obs"]
@@ -66,7 +70,9 @@ def main():
             boot = model.value(obs)
         # bootstrap with the critic at the segment end (the reference uses 0 there, imitation_runners.py:98-100;
         # with 32-step segments that bias would dominate)
-        adv, ret = rollout.gae_fused(buf["rewards"], buf["vpred"], buf["dones"], 0.95, 0.95, bootstrap=boot, normalize=True, eps=1e-8)
+        adv, ret = rollout.gae_fused(buf["rewards"], buf["vpred"], buf["dones"], 0.95, 0.95, bootstrap=boot, normalize=True, eps=1e-8,
+                                     legacy_gae_index=args.legacy_gae_index, first_starts=first_starts)
+        first_starts = buf["dones"][-1]
         T, n = buf["rewards"].shape
         surr, vf = learner.update(buf["obs"].reshape(T * n, -1), buf["actions"].reshape(T * n, -1), adv.reshape(-1),
                                   ret.reshape(-1), old_logp=buf["logp"].reshape(-1) if "logp" in buf else None,
