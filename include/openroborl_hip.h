@@ -78,7 +78,9 @@ extern "C" {
   X(MAX_EP_STEPS, 1, I)  /* wrapper_env.py:151-159 */                                         \
   X(ROBOT_TYPE, 1, I) X(CLIP_ID, 1, I)                                                        \
   X(ROBOT_INDEX, 1, I)   /* global robot index (RNG key, grid slot) */                        \
-  X(LAST_EP_LEN, 1, I) X(DONE_REASON, 1, I) X(RESERVED_I, 2, I)                               \
+  X(LAST_EP_LEN, 1, I)                                                                        \
+  X(DONE_REASON, 1, I)   /* of the last step; survives the (auto-)reset that follows it */    \
+  X(RESERVED_I, 2, I)                                                                         \
   /* latency ring (minitaur.py:127,313-357): ORR_RING_DEPTH entries of ORR_RING_ENTRY */      \
   X(RING, ORR_RING_DEPTH * ORR_RING_ENTRY, F)
 

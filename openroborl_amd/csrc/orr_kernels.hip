@@ -87,6 +87,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
   // read here, far ahead of its only use (the time limit of an episode that starts in this launch)
   const long long total_snapshot = P.counters[ORR_CNT_TOTAL_STEP_COUNT];
   load_robot(P, rec, S, lane);
+  {
+    // Non-finite guard, entry half: a NaN in the INCOMING rigid state (POS..QD) does not survive the step - the velocity clamp (+-100,
+    // v_med3) and the branch-free inverse trigonometric functions turn NaNs into finite numbers - so it is recorded here, in a spare
+    // word of the LDS image behind the state head (never stored), and ORed into the exit half of the guard (ORR_DONE_NAN below).
+    static_assert(kHead > ORR_STATE_WORDS - ORR_RING_DEPTH * ORR_RING_ENTRY, "spare LDS word behind the state head");
+    bool bad_in = false;
+    for (int i = lane; i < 37; i += kLanes) bad_in = bad_in || !(fabsf(S.s[O(POS) + i]) < 1e30f);
+    const bool any_bad = ((__ballot(bad_in) >> (sub * kLanes)) & ((1ull << (kLanes - 1)) * 2ull - 1ull)) != 0ull;
+    if (lane == 0) S.s[kHead - 1] = any_bad ? 1.0f : 0.0f;
+  }
   // impulse-response table: stale rows are multiplied by zero impulses, so they only have to be finite
   for (int i = lane; i < kMaxRows * kWStride; i += kLanes) (&S.ph.sub.W[0][0])[i] = 0.0f;
   WSYNC();
@@ -249,8 +259,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
     if (!(clip.flags & ORR_CLIP_WRAP) && t >= clip.dur_d) reason |= ORR_DONE_MOTION_OVER;  // is_motion_over (:224-233)
     bool bad = false;
     for (int i = lane; i < 37; i += kLanes) bad = bad || !(fabsf(S.s[O(POS) + i]) < 1e30f);
-    if (((__ballot(bad) >> (sub * kLanes)) & ((1ull << (kLanes - 1)) * 2ull - 1ull)) != 0ull) reason |= ORR_DONE_NAN;
-    if (!(fabsf(rew) < 1e30f)) { reason |= ORR_DONE_NAN; rew = 0.0f; }
+    if (((__ballot(bad) >> (sub * kLanes)) & ((1ull << (kLanes - 1)) * 2ull - 1ull)) != 0ull || S.s[kHead - 1] != 0.0f) reason |= ORR_DONE_NAN;
+    if (!(fabsf(rew) < 1e30f)) reason |= ORR_DONE_NAN;
+    if (reason & ORR_DONE_NAN) rew = 0.0f;      // whatever was computed from a non-finite state is not a reward
     const int ep_step = geti(S, O(EP_STEP)) + 1;  // quadruped_gym_env.py:237
     if (ep_step >= geti(S, O(MAX_EP_STEPS))) reason |= ORR_DONE_TIME_LIMIT;
     // episode log (imitation_runners.py:185-197): the slot comes from a returning atomic on a counter shared by the whole device (a

@@ -388,7 +388,7 @@ __device__ static void reset_robot(const KParams& P, float* rec, Shared& S, int 
   if (lane == 0) {
     seti(S, O(RING_LEN), 0); seti(S, O(RING_HEAD), ORR_RING_DEPTH - 1);
     seti(S, O(STATE_ACTION_COUNTER), 0); seti(S, O(STEP_COUNTER), 0); seti(S, O(FILTER_VALID), 0);
-    seti(S, O(EP_STEP), 0); seti(S, O(DONE_REASON), 0);
+    seti(S, O(EP_STEP), 0);   // DONE_REASON keeps the reason the PREVIOUS episode ended with until the next step overwrites it (env.stats())
     S.s[O(EP_RETURN)] = 0.0f;
   }
   WSYNC();

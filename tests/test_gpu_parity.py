@@ -569,3 +569,40 @@ def test_physics_substep_parity_other_solver_iteration_counts(iters):
     compare_fields(env, orc, ["LINVEL", "ANGVEL", "QD"], atol=1e-3, rtol=1e-3, what="iters=%d" % iters)
     compare_fields(env, orc, ["LAMBDA"], atol=5e-3, what="iters=%d" % iters)
     env.close(); orc.close()
+
+
+@pytest.mark.parametrize("auto_reset", [True, False])
+def test_non_finite_state_is_caught_by_the_state_guard(auto_reset):
+    """ORR_DONE_NAN: the ONE detection point for non-finite numbers is the |x| < 1e30 sweep over POS..QD (+ the reward check) at the end of
+    the step.  The branch-free atan2 / asin / acos (csrc/orr_device.h) drop NaNs through fmax / fmin / selects, so a NaN orientation does
+    NOT propagate through the IMU / heading paths - it cannot be detected downstream, only in the state itself.  NaN / inf injected into
+    QUAT, ANGVEL, Q: those robots finish with DONE_NAN and a finite reward; with auto-reset the returned observation is the (finite) reset
+    observation and the next step is clean; without it a masked reset recovers them.  Neighbours in the same wavefront are untouched."""
+    import torch
+    n = 8
+    env, orc = make_pair("laikago", n=n, auto_reset=auto_reset, seed=6)
+    orc.close()
+    env.reset()
+    ref = env.state.clone()
+    lay = env.layout
+    env.state[0, lay.sl("QUAT").start + 1] = float("nan")
+    env.state[1, lay.sl("ANGVEL").start] = float("nan")
+    env.state[2, lay.sl("Q").start + 5] = float("inf")
+    a = torch.zeros(n, 12, device=env.device)
+    obs, rew, done, _ = env.step(a)
+    torch.cuda.synchronize()
+    bad = torch.tensor([1, 1, 1, 0, 0, 0, 0, 0], dtype=torch.bool, device=env.device)
+    assert done.bool()[bad].all() and not done.bool()[~bad].any()
+    reason = env.field_int("DONE_REASON")[:, 0]
+    print("NAN_GUARD auto_reset=%s reasons %s" % (auto_reset, reason.cpu().numpy().tolist()))
+    assert ((reason[bad] & _abi.DONE_NAN) != 0).all() and (reason[~bad] == 0).all()
+    assert torch.isfinite(rew).all() and (rew[bad] == 0).all() and (rew[~bad] > 0).all()
+    assert torch.isfinite(obs[~bad]).all()
+    if auto_reset:
+        assert torch.isfinite(obs).all()                       # the reset observation
+        assert torch.isfinite(env.state[:, :lay.sl("RING").start]).all()
+    else:
+        env.reset(bad.to(torch.uint8))
+    obs, rew, done, _ = env.step(a)
+    assert torch.isfinite(obs).all() and torch.isfinite(rew).all() and not done.any()
+    env.close()

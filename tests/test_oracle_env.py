@@ -327,3 +327,42 @@ def test_motion_over_ends_a_non_looping_clip(tmp_path):
         assert done[over].all()
         seen |= over
     assert seen.all()
+
+
+def test_auto_reset_time_limit_lags_the_curriculum_counter_by_one_launch():
+    """Documented divergence: the reference's WrapperEnv.step adds this step's finished robots to
+    _total_step_count and reset() THEN calls _update_time_limit (wrapper_env.py:79-83,151-159).  With per-robot auto-reset inside the
+    step launch every robot of a launch reads the counter as of the START of the launch (deterministic on the device: no robot sees a
+    partial sum), so the limit of an episode that starts inside launch k ignores launch k's own finished episodes.  The effect is one
+    launch's done count against curriculum_steps = 3e7; pinned here with a curriculum short enough to show it."""
+    import ctypes as C
+    n = 8
+    cfg = config.make_config(n, mode="train", enable_randomizer=False, auto_reset=True, seed=5)
+    cfg.curriculum_steps = 64                 # every finished episode moves the limit
+    model = robots.ROBOTS["laikago"]()
+    models = [model, None]
+    env = ol.OracleEnv(cfg, models, [motion.MotionClip("laikago_pace")], n, robot_type=0)
+    env.reset()
+    lay = env.lay
+    L = ol.lib()
+    limit0 = L.orc_time_limit(C.byref(cfg), 0)
+    assert limit0 == 20 and (env.field("MAX_EP_STEPS")[:, 0] == 20).all()
+    steps = 0
+    while True:
+        before = int(env.counters[_abi.CNT_TOTAL_STEP_COUNT])
+        obs, rew, done = env.step(np.zeros((n, 12)))
+        steps += 1
+        if done.any():
+            after = int(env.counters[_abi.CNT_TOTAL_STEP_COUNT])
+            assert after == before + int(done.sum())                                  # += 1 per reset robot
+            lim_before, lim_after = L.orc_time_limit(C.byref(cfg), before), L.orc_time_limit(C.byref(cfg), after)
+            assert lim_after > lim_before                                             # the lag is visible with this curriculum
+            got = env.field("MAX_EP_STEPS")[done, 0].astype(int)
+            assert (got == lim_before).all(), (got, lim_before, lim_after)            # the launch's own dones are NOT in it
+            break
+        assert steps < 25
+    # the next launch sees them
+    obs, rew, done2 = env.step(np.zeros((n, 12)))
+    if done2.any():
+        assert (env.field("MAX_EP_STEPS")[done2, 0].astype(int) == L.orc_time_limit(C.byref(cfg), after)).all()
+    env.close()
