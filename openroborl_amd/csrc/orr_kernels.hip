@@ -20,11 +20,13 @@
 // per phase (Shared::pt_acc) and add them to g_phase_cycles at the end of the launch.
 #ifdef ORR_PHASE_TIMERS
 __device__ long long g_phase_cycles[orr::kPhaseSlots];   // 0..15: phases of the step, 16..23: stages of reset_robot, 24..: finer marks inside the reset
+__device__ long long g_wave_phases[2048 * 40];   // per wave of the last launch: its own phase totals (tools/wave_phases.py)
 __device__ long long g_wave_timeline[4 * 2048];   // per wave of the last launch: realtime start, realtime end, shader cycles, reset flag
 #define PT_INIT() do { if (threadIdx.x == 0) { S.pt_t0 = clock64(); S.pt_r0 = wall_clock64(); } if (threadIdx.x == 0) { for (int i_ = 0; i_ < orr::kPhaseSlots; i_++) S.pt_acc[i_] = 0; S.pt_last = clock64(); } } while (0)
 #define PT(k) do { if (threadIdx.x == 0) { const long long t_ = clock64(); S.pt_acc[k] += t_ - S.pt_last; S.pt_last = clock64(); } } while (0)
-#define PT_TIMELINE(flag) do { if (threadIdx.x == 0 && blockIdx.x < 2048) { g_wave_timeline[4 * blockIdx.x] = S.pt_r0; g_wave_timeline[4 * blockIdx.x + 1] = wall_clock64(); g_wave_timeline[4 * blockIdx.x + 2] = clock64() - S.pt_t0; g_wave_timeline[4 * blockIdx.x + 3] = (flag); } } while (0)
-#define PT_FLUSH() do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) for (int i_ = 0; i_ < orr::kPhaseSlots; i_++) atomicAdd((unsigned long long*)&g_phase_cycles[i_], (unsigned long long)S.pt_acc[i_]); } while (0)
+#define PT_TIMELINE(flag) do { if (threadIdx.x == 0 && blockIdx.x < 2048) { g_wave_timeline[4 * blockIdx.x] = S.pt_r0; g_wave_timeline[4 * blockIdx.x + 1] = wall_clock64(); g_wave_timeline[4 * blockIdx.x + 2] = clock64() - S.pt_t0; g_wave_timeline[4 * blockIdx.x + 3] = ((flag) & 0xFF) | ((long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 8) | ((long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xF) << 40); } } while (0)   /* bits 8..39: HW_REG_HW_ID (wave, simd, cu, sh, se), 40..43: HW_REG_XCC_ID */
+#define PT_FLUSH() do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) for (int i_ = 0; i_ < orr::kPhaseSlots; i_++) atomicAdd((unsigned long long*)&g_phase_cycles[i_], (unsigned long long)S.pt_acc[i_]); \
+                        if (threadIdx.x == 0 && blockIdx.x < 2048) for (int i_ = 0; i_ < orr::kPhaseSlots; i_++) g_wave_phases[blockIdx.x * 40 + i_] = S.pt_acc[i_]; } while (0)
 #else
 #define PT_INIT()
 #define PT(k)
@@ -674,7 +676,12 @@ int orr_debug_phase_cycles(long long* out40, int reset) {
   return 0;
 }
 // development aid: per-wave timeline of the last step launch (4 words per wave: realtime start / end in 100 MHz ticks, shader cycles,
-// mask of the robots that finished an episode)
+// bits 0..7 mask of the robots that finished an episode, bits 8..39 HW_ID register of the wave (SIMD / CU / SE), bits 40..43 XCC id)
+int orr_debug_wave_phases(long long* out, int waves) {
+  HIPCHK(hipDeviceSynchronize(), "orr_debug_wave_phases: sync");
+  HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_phases), (size_t)waves * 40 * sizeof(long long)), "orr_debug_wave_phases: read");
+  return 0;
+}
 int orr_debug_wave_timeline(long long* out, int waves) {
   HIPCHK(hipDeviceSynchronize(), "orr_debug_wave_timeline: sync");
   HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_timeline), (size_t)waves * 4 * sizeof(long long)), "orr_debug_wave_timeline: read");

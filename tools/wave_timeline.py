@@ -40,7 +40,7 @@ for _ in range(n):
     a = np.frombuffer(buf, dtype=np.int64).reshape(W, 4).copy()
     t0 = a[:, 0].min()
     start, end = (a[:, 0] - t0) / 100.0, (a[:, 1] - t0) / 100.0      # microseconds (100 MHz realtime counter)
-    reset = a[:, 3] != 0
+    reset = (a[:, 3] & 0xFF) != 0
     last = int(np.argmax(end))
     rows.append((start.max(), end.max(), (end - start).mean(), (end - start)[reset].mean() if reset.any() else np.nan,
                  (end - start)[~reset].mean(), end[~reset].max(), end[reset].max() if reset.any() else np.nan, reset.sum(), bool(reset[last]),
