@@ -199,7 +199,6 @@ struct alignas(16) Shared {
   LegSolve leg[4];
   alignas(16) float Rb[9];     // kinematic base frame -> world
   alignas(16) float IA0inv[36];  // inverse of the base's effective 6x6 inertia (world axes, about the base COM)
-  alignas(16) float ia0_dump[36];  // where the lanes that solve for a0 instead of a column of IA0inv put their result (leg_dynamics)
   alignas(16) float tau[16];   // joint torques (internal sign convention), joint order; 12..15: dump slots of the lanes that own no motor
   alignas(16) float ustar[24];
   alignas(16) float co[20];    // control (latency-delayed) observation

@@ -333,7 +333,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
       atomicExch((unsigned long long*)&P.counters[ORR_CNT_TICKET], 0ull);
     }
   }
-  PT_TIMELINE((long long)fin_mask);
+  PT_TIMELINE((long long)((fin_mask & 1ull) | ((fin_mask >> 15) & 2ull) | ((fin_mask >> 30) & 4ull) | ((fin_mask >> 45) & 8ull)));   // one bit per robot of the wave
 }
 
 // Rollout boundary (agents/ppo_imitation.py:405-423): pack this rank's episode log into the fixed-size float64 payload of the

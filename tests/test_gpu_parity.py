@@ -492,12 +492,14 @@ def test_shank_contact_parity(robot):
 
 
 def test_shipped_minicheetah_policy_probe():
-    """Behavioural anchor for config 3's robot, with its honest threshold: the reference's minicheetah_trot policy (trained in
-    PyBullet on the real URDF) does NOT finish the 600-step episode on this hand-authored mini-cheetah model -- it stays on
-    the clip for a while and then falls.  The test pins the measured level so that model changes show."""
+    """Behavioural anchor for config 3's robot: the reference's minicheetah_trot policy (trained in PyBullet on the real URDF) walks the
+    600-step episode on the mini-cheetah table of robots.py.  Round 2: 0 % of the robots finished (mean survival 158 steps) on the
+    hand-authored table; round 3 identified the uncertain distal masses / COMs / hip height against this very policy
+    (tools/mc_identify.py): 0.90 +- 0.01 of 1024 robots finish (two env seeds), ~10 % still fall.  The test pins
+    that level with the sampling noise of 1024 robots in mind; a failure is counted only for a termination other than the time limit."""
     import torch
     W = np.load(os.path.join(ol.GOLDEN, "policy_minicheetah_trot.npz"))
-    n = 256
+    n = 1024
     env, orc = make_pair("mini_cheetah", n=n, seed=1)
     orc.close()
     dev = env.device
@@ -506,6 +508,7 @@ def test_shipped_minicheetah_policy_probe():
     alive = torch.ones(n, dtype=torch.bool, device=dev)
     length = torch.zeros(n, device=dev)
     ret = torch.zeros(n, device=dev)
+    reason = env.field_int("DONE_REASON")[:, 0]
     for step in range(600):
         h = torch.relu(obs @ w["model__pi_fc0__w_0"] + w["model__pi_fc0__b_0"])
         h = torch.relu(h @ w["model__pi_fc1__w_0"] + w["model__pi_fc1__b_0"])
@@ -513,12 +516,13 @@ def test_shipped_minicheetah_policy_probe():
         obs, rew, done, _ = env.step(a.contiguous())
         ret += rew * alive
         length += alive.float()
-        alive &= ~done.bool()
+        alive &= ~(done.bool() & ((reason & ~_abi.DONE_TIME_LIMIT) != 0))
+    finished = alive.float().mean().item()
     mean_len = length.mean().item()
     rps = (ret / length).mean().item()
-    print("MINICHEETAH_PROBE mean_survival_steps=%.1f reward_per_step=%.3f finished=%.3f" % (mean_len, rps, alive.float().mean().item()))
-    assert 100.0 < mean_len < 450.0        # measured 158 (no robot finishes); far from the 600 the Laikago policy reaches
-    assert rps > 0.4                       # while it is up it tracks the clip
+    print("MINICHEETAH_PROBE finished=%.3f mean_survival_steps=%.1f reward_per_step=%.3f" % (finished, mean_len, rps))
+    assert finished >= 0.85            # measured 0.896 / 0.898 (seeds 1 / 2); the identification's bar was 0.90 on its own 256-robot sample
+    assert mean_len > 500.0 and rps > 0.6
     env.close()
 
 
