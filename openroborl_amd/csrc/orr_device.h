@@ -52,7 +52,7 @@ constexpr int kLanes = ORR_LANES_PER_ROBOT;  // lanes of a wavefront that serve 
 constexpr int kRPW = 64 / kLanes;            // robots per wavefront
 static_assert(kLanes == 16 || kLanes == 32 || kLanes == 64, "a robot needs 16 row lanes");
 constexpr int kMaxRows = 28;  // 4 knee-friction + <=12 joint-limit + 12 contact rows
-constexpr int kHead = 320;    // words of the state record staged in LDS (everything before the ring)
+constexpr int kHead = 308;    // words of the state record staged in LDS: everything before the ring (307) + one spare word (the non-finite guard's flag)
 
 // Clip header (16 words: one per lane when it is staged into LDS).  Times are DOUBLES: the motion time reaches 20 s by the end of a
 // 600-step episode, where float32 resolves 2e-6 s = 1e-4 of a frame, and the frame velocities jump by O(10) between frames
@@ -74,35 +74,45 @@ static_assert(sizeof(DevClip) == 64, "clip header = 16 words");
 // +-x, upper and lower leg (k = 1, 2) about +-y.  The sign is folded into the internal joint angle
 //   a = jdir * (q_urdf - joff),  jdir = JOINT_DIRECTION * axis_sign,
 // so that inside the kernels every joint turns about +x or +y.
+// HOT part: staged in LDS per robot (512 B) - what the 33 sub-steps and the reward's forward kinematics read again and again.
 struct ModelHot {
-  float init_pos[3];
-  float init_quat[4];
-  float init_motor_angles[12], motor_dir[12], motor_offset[12];
-  int joint_of_motor[12];
-  int motor_of_joint[12];
-  float kp[12], kd[12];
   float jdir[12], joff[12];   // per JOINT (URDF order)
-  float tau_sign[12];         // per joint: internal torque = tau_sign * motor torque
-  float link_com[12][3];
-  float joint_pos[12][3];
   float joint_lo[12], joint_hi[12];  // limits of the internal angle
+  float joint_pos[12][3];
   float toe_pos[4][3];
   float shank_pos[4][3];      // second contact sphere of the lower leg (see orr_model)
   float lower_com[4][3];
-  float default_joints[12];   // (INIT_MOTOR_ANGLES + OFFSET) * DIR, motor order (imitation_task.py:1245-1252)
-  float toe_radius, shank_radius, foot_friction;
+  float init_quat[4];
+  float toe_radius, shank_radius;
   int num_fall;
+  int pad_;
+};
+static_assert(sizeof(ModelHot) == 512, "LDS budget: 4 robots per wave, two waves per SIMD = 20 KB per wave (DESIGN.md section 3)");
+// COLD part: read straight from the device table (global memory, L2-resident) where it is needed - per-motor and per-link constants
+// that go into registers once per launch, reset-only data, and the termination-only fall proxies (fetched at the top of the last
+// sub-step of an env step).  Round 2 staged all of it in LDS (1420 B per robot), which capped a CU at 5-6 resident waves.
+struct ModelCold {
+  float init_pos[3];
+  float foot_friction;
+  float init_motor_angles[12], motor_dir[12], motor_offset[12];
+  int joint_of_motor[12];
+  float kp[12], kd[12];
+  float tau_sign[12];         // per joint: internal torque = tau_sign * motor torque
+  float tau_sign_motor[12];   // the same per MOTOR (tau_sign[joint_of_motor[m]]): no dependent second load
+  float link_com[12][3];
+  float default_joints[12];   // (INIT_MOTOR_ANGLES + OFFSET) * DIR, motor order (imitation_task.py:1245-1252)
   int fall_body[ORR_MAX_FALL_PROXIES];
   float fall_pos[ORR_MAX_FALL_PROXIES][3];
   float fall_radius[ORR_MAX_FALL_PROXIES];
-};
-struct DevModel {
-  ModelHot hot;  // staged in LDS by every wave
-  // ---- not staged in LDS: read once per launch by lanes 0..12
+  // mass properties before randomisation: body 0 = base, 1 + j = link j
   float mass[13];
   float inertia[13][6];
   float inertia_pa[13][6];
   int group[13];
+};
+struct DevModel {
+  ModelHot hot;
+  ModelCold cold;
 };
 constexpr int kModelLdsWords = (int)(sizeof(ModelHot) / 4);
 
@@ -131,6 +141,10 @@ struct KParams {
   float* ep_log;
   int ep_log_cap;
 };
+// The cold part of a robot type's model, as a GLOBAL-address-space pointer: loads through it are global_load instructions (a generic
+// pointer would make them FLAT loads, which also count on the LDS counter and serialise with every LDS access in between).
+typedef const ModelCold __attribute__((address_space(1)))* ColdPtr;
+__device__ __forceinline__ ColdPtr model_cold(const KParams& P, int robot_type) { return (ColdPtr)&P.tab->model[robot_type].cold; }
 
 // ------------------------------------------------------------------------------------------------
 // LDS image of one robot: ~6.6 KB, four per wave
@@ -150,9 +164,10 @@ struct alignas(16) LegExchange {  // per leg, hand-over between the lanes (parts
   float b[4];         // tau_k - C_k
 };
 struct alignas(16) LegSolve {   // per leg: column k of T written by the leg's part-k lane, Hi by all of them; read by the row lanes
-  float T[4][6];    // F H^-1: column k = base wrench (angular; linear, world axes, about the base COM) per unit of joint k
+  float T[3][6];    // F H^-1: column k = base wrench (angular; linear, world axes, about the base COM) per unit of joint k
   float Hi[6];      // H^-1 of the leg's 3x3 joint-space inertia (00 11 22 01 02 12)
 };
+static_assert(sizeof(LegSolve) == 96, "LDS budget");
 
 // Code alignment of the hand-written loops.  A lone wave pays for instruction fetch: an 8-byte instruction (VOP3, DPP) that starts on an
 // odd dword costs ~0.7 ticks more than an aligned one (shifting the whole kernel by one dword changes its run time by 2.5 %; DESIGN.md
@@ -177,14 +192,22 @@ union alignas(16) SubstepBuf {            // live only inside a physics sub-step
   DynamicsBuf dyn;            // shares its space: written by the next sub-step's dynamics, last read by the row setup
 };
 struct alignas(16) StepEndBuf {           // live only at reset / end of step
-  float frames[11][19];       // staged clip frames: 5 sample times x (f0, f1) + frame 0
-  float fvel[2][18];
+  union {
+    struct {
+      float frames[11][19];   // staged clip frames: 5 sample times x (f0, f1) + frame 0
+      float fvel[2][18];
+    };
+    // the observation being assembled shares the space of the staged frames: it is written (step end, end of reset_robot) only after
+    // the frames were blended into pose[] / vel[] (sample_poses_finish), and a reset that follows a step inside the same launch
+    // rewrites all 160 values at its end
+    float obs[ORR_OBS_DIM];
+  };
   float pose[5][19];          // sampled reference poses (update time + 4 target times)
   float vel[18];
   float ee[2][8][3];          // end-effector world positions, [0] sim [1] ref
-  float obs[ORR_OBS_DIM];
   float red[80];              // small cross-lane reductions of the step-end code; reset_robot: ring entries #1 / #2 and the 28 draws
 };
+static_assert(sizeof(StepEndBuf) <= sizeof(SubstepBuf), "LDS budget: the step-end buffers fit into the sub-step buffers' space");
 union PhaseBuf {
   SubstepBuf sub;
   StepEndBuf end;
@@ -194,9 +217,8 @@ struct alignas(16) Shared {
   alignas(16) float s[kHead];  // state head (float / int bit patterns)
   alignas(16) ModelHot m;      // robot model (hot part)
   alignas(16) DevClip clip;    // header of the robot's motion clip (copied once per launch: its fields are read many times at the end of a step)
-  alignas(16) float mass[13];  // after randomisation ratios
-  alignas(16) float Ic[13][6];
   LegSolve leg[4];
+  alignas(16) float tdump[8];  // where the part-3 lanes (which own no joint) put their "column of T" (leg_dynamics)
   alignas(16) float Rb[9];     // kinematic base frame -> world
   alignas(16) float IA0inv[36];  // inverse of the base's effective 6x6 inertia (world axes, about the base COM)
   alignas(16) float tau[16];   // joint torques (internal sign convention), joint order; 12..15: dump slots of the lanes that own no motor

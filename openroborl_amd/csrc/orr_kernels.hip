@@ -103,7 +103,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
   for (int i = lane; i < kMaxRows * kWStride; i += kLanes) (&S.ph.sub.W[0][0])[i] = 0.0f;
   WSYNC();
   LegConst K;
-  load_leg_const(S, lane, K);
+  load_leg_const(P, S, lane, K);
   {
     float rel[4], Rb[9];
     base_rotation(S, lane, rel, Rb);  // Shared::Rb for the first sub-step; the ring push keeps it current afterwards
@@ -111,7 +111,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
   PT(0);
 
   if (MODE == 1) {
-    if (lane < 12) { const int j = S.m.joint_of_motor[lane]; S.tau[j] = S.m.tau_sign[j] * actions[(size_t)robot * 12 + lane]; }
+    if (lane < 12) {
+      const ColdPtr mc = model_cold(P, geti(S, O(ROBOT_TYPE)));
+      const int j = mc->joint_of_motor[lane];
+      S.tau[j] = mc->tau_sign_motor[lane] * actions[(size_t)robot * 12 + lane];
+    }
     WSYNC();
     int fall = 0;
     OwnCoord X;
@@ -127,10 +131,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
     return;
   }
 
+  // per-motor constants of the PD loop (lane = motor; lanes 12..15 repeat motor 0), from the cold model table into registers: issued
+  // here, first used after the control observation's ring reads
+  const int ml = lane < 12 ? lane : 0;
+  const ColdPtr mc = model_cold(P, geti(S, O(ROBOT_TYPE)));
+  const int mj = mc->joint_of_motor[ml];
+  const float m_off = mc->motor_offset[ml], m_dir = mc->motor_dir[ml], m_kp = mc->kp[ml], m_kd = mc->kd[ml];
+  const float m_tsign = mc->tau_sign_motor[ml], m_init = mc->init_motor_angles[ml];
   // ---- set_act (minitaur.py:280-285): offset, last action, Butterworth filter ----
   ctrl_obs(P, rec, S, lane);
   if (lane < 12) {
-    const float act = actions[(size_t)robot * 12 + lane] + S.m.init_motor_angles[lane];
+    const float act = actions[(size_t)robot * 12 + lane] + m_init;
     S.s[O(LAST_ACTION) + lane] = act;
     float x1 = S.s[O(XHIST) + lane], x2 = S.s[O(XHIST) + 12 + lane], y1 = S.s[O(YHIST) + lane], y2 = S.s[O(YHIST) + 12 + lane];
     if (geti(S, O(STATE_ACTION_COUNTER)) == 0) {  // _filter (minitaur.py:1169-1178): init_history(current delayed angles)
@@ -147,11 +158,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
   int fall = 0;
   const float inv_repeat = 1.0f / (float)c.action_repeat;
   const RingLatency rlat = ring_latency(P, S);
-  // per-motor constants of the PD loop and the step's filtered target, in registers over the sub-steps (lane = motor)
-  const int ml = lane < 12 ? lane : 0;
-  const int mj = S.m.joint_of_motor[ml];
-  const float m_off = S.m.motor_offset[ml], m_dir = S.m.motor_dir[ml], m_kp = S.m.kp[ml], m_kd = S.m.kd[ml];
-  const float m_gain = S.m.tau_sign[mj] * S.s[O(STRENGTH) + ml];
+  // the step's filtered target and the motor gain, in registers over the sub-steps (lane = motor)
+  const float m_gain = m_tsign * S.s[O(STRENGTH) + ml];
   const float m_target = S.s[O(ACTION) + ml], m_prev = S.s[O(FILTER_ACTION) + ml];
   const bool m_has_prev = geti(S, O(FILTER_VALID)) != 0;
   int action_counter = geti(S, O(STATE_ACTION_COUNTER));
@@ -179,7 +187,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
       ring_prefetch(rlat, rec, ring, lane, F);
       if constexpr (MODE == 2) {
         const size_t slot = (size_t)robot * c.action_repeat + sstep;
-        if (lane < 12 && valid) RP.tau_out[slot * 12 + lane] = S.tau[mj] * S.m.tau_sign[mj] ;  // motor torque, motor order
+        if (lane < 12 && valid) RP.tau_out[slot * 12 + lane] = S.tau[mj] * m_tsign;  // motor torque, motor order
         WSYNC();
         for (int i = lane; i < 37; i += kLanes) S.s[O(POS) + i] = RP.traj[slot * 37 + i];        // POS QUAT LINVEL ANGVEL Q QD
         WSYNC();
@@ -189,7 +197,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PE
       ring_push_and_ctrl_obs(rec, S, lane, valid, F, ring, (S.s[O(Q) + mj] - m_off) * m_dir);
     } else {
       fall = physics_substep(P, S, K, lane, sub, sstep == c.action_repeat - 1, X);
-      receive_obs(rec, S, lane, valid);
+      receive_obs(P, rec, S, lane, valid);
     }
     PT(10);
   }
@@ -507,25 +515,26 @@ int32_t orr_set_model(orr_handle* h, int32_t robot_type, const orr_model* m) {
     axsgn[j] = a[ax] > 0 ? 1.0f : -1.0f;
   }
   ModelHot& H = d.hot;
-  for (int i = 0; i < 3; i++) H.init_pos[i] = m->init_pos[i];
+  ModelCold& Cd = d.cold;
+  for (int i = 0; i < 3; i++) Cd.init_pos[i] = m->init_pos[i];
   for (int i = 0; i < 4; i++) H.init_quat[i] = m->init_quat[i];
   for (int i = 0; i < 12; i++) {
     const int j = m->joint_of_motor[i];
-    H.init_motor_angles[i] = m->init_motor_angles[i];
-    H.motor_dir[i] = m->motor_dir[i];
-    H.motor_offset[i] = m->motor_offset[i];
-    H.joint_of_motor[i] = j;
-    H.motor_of_joint[j] = i;
-    H.kp[i] = m->kp[i];
-    H.kd[i] = m->kd[i];
+    Cd.init_motor_angles[i] = m->init_motor_angles[i];
+    Cd.motor_dir[i] = m->motor_dir[i];
+    Cd.motor_offset[i] = m->motor_offset[i];
+    Cd.joint_of_motor[i] = j;
+    Cd.kp[i] = m->kp[i];
+    Cd.kd[i] = m->kd[i];
     if (fabsf(fabsf(m->motor_dir[i]) - 1.0f) > 1e-6f) return fail(-1, "orr_set_model: motor_dir must be +1 or -1");
     H.jdir[j] = m->motor_dir[i] * axsgn[j];
     H.joff[j] = m->motor_offset[i];
-    H.tau_sign[j] = axsgn[j];
-    H.default_joints[i] = (m->init_motor_angles[i] + m->motor_offset[i]) * m->motor_dir[i];
+    Cd.tau_sign[j] = axsgn[j];
+    Cd.tau_sign_motor[i] = axsgn[j];
+    Cd.default_joints[i] = (m->init_motor_angles[i] + m->motor_offset[i]) * m->motor_dir[i];
   }
   for (int j = 0; j < 12; j++) {
-    for (int k = 0; k < 3; k++) { H.link_com[j][k] = m->link_com[j][k]; H.joint_pos[j][k] = m->joint_pos[j][k]; }
+    for (int k = 0; k < 3; k++) { Cd.link_com[j][k] = m->link_com[j][k]; H.joint_pos[j][k] = m->joint_pos[j][k]; }
     // limits are given for the kinematic angle; the internal angle is axis_sign times it
     H.joint_lo[j] = axsgn[j] > 0 ? m->joint_lo[j] : -m->joint_hi[j];
     H.joint_hi[j] = axsgn[j] > 0 ? m->joint_hi[j] : -m->joint_lo[j];
@@ -537,20 +546,20 @@ int32_t orr_set_model(orr_handle* h, int32_t robot_type, const orr_model* m) {
   if (!(m->shank_radius >= 0.0f)) return fail(-1, "orr_set_model: shank_radius must be >= 0");
   H.toe_radius = m->toe_radius;
   H.shank_radius = m->shank_radius;
-  H.foot_friction = m->foot_friction;
+  Cd.foot_friction = m->foot_friction;
   H.num_fall = m->num_fall_proxies;
   for (int i = 0; i < ORR_MAX_FALL_PROXIES; i++) {
-    H.fall_body[i] = m->fall_body[i];
-    H.fall_radius[i] = m->fall_radius[i];
-    for (int k = 0; k < 3; k++) H.fall_pos[i][k] = m->fall_pos[i][k];
+    Cd.fall_body[i] = m->fall_body[i];
+    Cd.fall_radius[i] = m->fall_radius[i];
+    for (int k = 0; k < 3; k++) Cd.fall_pos[i][k] = m->fall_pos[i][k];
   }
-  d.mass[0] = m->base_mass;
-  d.group[0] = 0;
-  for (int k = 0; k < 6; k++) { d.inertia[0][k] = m->base_inertia[k]; d.inertia_pa[0][k] = 0.0f; }
+  Cd.mass[0] = m->base_mass;
+  Cd.group[0] = 0;
+  for (int k = 0; k < 6; k++) { Cd.inertia[0][k] = m->base_inertia[k]; Cd.inertia_pa[0][k] = 0.0f; }
   for (int j = 0; j < 12; j++) {
-    d.mass[j + 1] = m->link_mass[j];
-    d.group[j + 1] = m->link_group[j];
-    for (int k = 0; k < 6; k++) { d.inertia[j + 1][k] = m->link_inertia[j][k]; d.inertia_pa[j + 1][k] = m->link_inertia_pa[j][k]; }
+    Cd.mass[j + 1] = m->link_mass[j];
+    Cd.group[j + 1] = m->link_group[j];
+    for (int k = 0; k < 6; k++) { Cd.inertia[j + 1][k] = m->link_inertia[j][k]; Cd.inertia_pa[j + 1][k] = m->link_inertia_pa[j][k]; }
   }
   HIPCHK(hipMemcpy(&h->tab_dev->model[robot_type], &d, sizeof(DevModel), hipMemcpyHostToDevice), "orr_set_model: hipMemcpy");
   return 0;

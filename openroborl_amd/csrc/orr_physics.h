@@ -66,8 +66,9 @@ __device__ __forceinline__ void load_own_coord(const Shared& S, int lane, OwnCoo
   X.x0 = lane < 3 ? 0.0f : (lane < 6 ? S.s[O(POS) + lane - 3] : S.s[O(Q) + lane - 6]);
   X.x1 = lane < 2 ? S.s[O(Q) + 10 + lane] : 0.0f;
 }
-__device__ static void load_leg_const(const Shared& S, int lane, LegConst& K) {
+__device__ static void load_leg_const(const KParams& P, const Shared& S, int lane, LegConst& K) {
   const int leg = lane & 3, part = (lane >> 2) & 3, own = 3 * leg + (part < 3 ? part : 2);
+  const ColdPtr mc = model_cold(P, geti(S, O(ROBOT_TYPE)));
 #pragma unroll
   for (int k = 0; k < 3; k++) {
     const int j = 3 * leg + k;
@@ -82,10 +83,18 @@ __device__ static void load_leg_const(const Shared& S, int lane, LegConst& K) {
   const bool real = part < 3, base = lane == 12;
   const int body = real ? own + 1 : 0;
 #pragma unroll
-  for (int i = 0; i < 3; i++) K.com[i] = real ? S.m.link_com[own][i] : 0.0f;
+  for (int i = 0; i < 3; i++) K.com[i] = real ? mc->link_com[own][i] : 0.0f;
+  {
+    // mass properties of the own body with this episode's randomisation ratios (controllable_env_randomizer_from_config.py:193-222,
+    // 309-335), straight from the device table into registers: nothing else reads them, so they are not staged in LDS (the ratios of a
+    // robot that resets inside this launch take effect with the next launch's load_leg_const, like its new state)
+    const int g = mc->group[body];
+    const float mr = S.s[O(MASS_RATIO) + g], ir = S.s[O(INERTIA_RATIO) + g];
+    const float mass = mc->mass[body] * mr;
 #pragma unroll
-  for (int i = 0; i < 6; i++) K.Ic[i] = (real || base) ? S.Ic[body][i] : 0.0f;
-  K.m = (real || base) ? S.mass[body] : 0.0f;
+    for (int i = 0; i < 6; i++) K.Ic[i] = (real || base) ? mc->inertia[body][i] * ir + mc->inertia_pa[body][i] * mr : 0.0f;
+    K.m = (real || base) ? mass : 0.0f;
+  }
   K.jdir_own = real ? S.m.jdir[own] : 0.0f;
   K.joff_own = S.m.joff[own];
   K.damp_l = base ? S.s[O(BASE_DAMPING)] : 0.0f;
@@ -321,10 +330,11 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
   float Tq[6];  // column `part` of T = F H^-1
 #pragma unroll
   for (int i = 0; i < 6; i++) Tq[i] = F[0][i] * hq0 + F[1][i] * hq1 + F[2][i] * hq2;
-  {  // part-3 lanes: T[3] = dump slot; H^-1 is the same in all lanes of the leg, every one of them stores it
+  {  // part-3 lanes: one shared dump slot; H^-1 is the same in all lanes of the leg, every one of them stores it
     LegSolve& Q = S.leg[leg];
+    float* const tdst = part < 3 ? &Q.T[part][0] : &S.tdump[0];
 #pragma unroll
-    for (int i = 0; i < 6; i++) Q.T[part][i] = Tq[i];
+    for (int i = 0; i < 6; i++) tdst[i] = Tq[i];
 #pragma unroll
     for (int i = 0; i < 6; i++) Q.Hi[i] = Hi[i];
   }
@@ -877,18 +887,27 @@ __device__ __forceinline__ void delassus_columns(const Shared& S, unsigned int m
 __device__ static int physics_substep(const KParams& P, Shared& S, const LegConst& K, int lane, int sub, bool want_fall, OwnCoord& X) {
   const orr_config& cfg = P.cfg;
   const float dt = cfg.sim_dt, inv_dt = 1.0f / cfg.sim_dt, erp_dt = cfg.contact_erp / cfg.sim_dt;
+  // termination-only collision proxies (imitation_task.py:536-546): read once per env step, at its last sub-step, from the device table
+  // (lane i = proxy i); the loads are issued here and consumed after the leg dynamics, which cover their round trip
+  int fp_body = 0;
+  float fp_x = 0.0f, fp_y = 0.0f, fp_z = 0.0f, fp_r = 0.0f;
+  if (want_fall) {
+    const ColdPtr mc = model_cold(P, geti(S, O(ROBOT_TYPE)));
+    static_assert(ORR_MAX_FALL_PROXIES <= kLanes, "one fall proxy per lane");
+    fp_body = mc->fall_body[lane]; fp_x = mc->fall_pos[lane][0]; fp_y = mc->fall_pos[lane][1]; fp_z = mc->fall_pos[lane][2]; fp_r = mc->fall_radius[lane];
+  }
   leg_dynamics(P, S, K, lane);  // -> link poses, leg solves, unconstrained velocities u*
   WSYNC();
   PT(3);
   int fall = 0;
-  if (want_fall) {  // termination-only collision proxies (imitation_task.py:536-546)
+  if (want_fall) {
     bool hit = false;
     if (lane < S.m.num_fall) {
-      const int b = S.m.fall_body[lane];
+      const int b = fp_body;
       const float* Rw = b == 0 ? S.Rb : S.ph.sub.dyn.lc[b - 1].Rw;
       const float oz = b == 0 ? S.s[O(POS) + 2] : S.ph.sub.dyn.lc[b - 1].ow[2];
-      const float wz = Rw[6] * S.m.fall_pos[lane][0] + Rw[7] * S.m.fall_pos[lane][1] + Rw[8] * S.m.fall_pos[lane][2];
-      hit = (oz + wz - S.m.fall_radius[lane]) < cfg.contact_margin;
+      const float wz = Rw[6] * fp_x + Rw[7] * fp_y + Rw[8] * fp_z;
+      hit = (oz + wz - fp_r) < cfg.contact_margin;
     }
     fall = ((__ballot(hit) >> (sub * kLanes)) & ((1ull << (kLanes - 1)) * 2ull - 1ull)) != 0ull;
   }

@@ -5,37 +5,6 @@
 // ================================================================================================
 // load / store of the per-robot record
 // ================================================================================================
-__device__ static void refresh_mass(const DevModel& gm, Shared& S, int lane) {
-  // randomised mass properties (controllable_env_randomizer_from_config.py:193-222,309-335)
-  if (lane < 13) {
-    const int g = gm.group[lane];
-    const float mr = S.s[O(MASS_RATIO) + g], ir = S.s[O(INERTIA_RATIO) + g];
-    S.mass[lane] = gm.mass[lane] * mr;
-#pragma unroll
-    for (int k = 0; k < 6; k++) S.Ic[lane][k] = gm.inertia[lane][k] * ir + gm.inertia_pa[lane][k] * mr;
-  }
-}
-
-// the same in two halves (reset_robot): the loads are issued early and consumed once the new ratios have been drawn
-struct MassLoads { int g; float m, in[6], pa[6]; };
-__device__ __forceinline__ void mass_prefetch(const DevModel& gm, int lane, MassLoads& L) {
-  typedef const float __attribute__((address_space(1))) * gptr;    // the table lives in global memory: plain global loads, not FLAT
-  typedef const int __attribute__((address_space(1))) * giptr;
-  const int b = lane < 13 ? lane : 12;
-  L.g = ((giptr)gm.group)[b];
-  L.m = ((gptr)gm.mass)[b];
-#pragma unroll
-  for (int k = 0; k < 6; k++) { L.in[k] = ((gptr)&gm.inertia[b][0])[k]; L.pa[k] = ((gptr)&gm.inertia_pa[b][0])[k]; }
-}
-__device__ __forceinline__ void refresh_mass_from(const MassLoads& L, Shared& S, int lane) {
-  if (lane < 13) {
-    const float mr = S.s[O(MASS_RATIO) + L.g], ir = S.s[O(INERTIA_RATIO) + L.g];
-    S.mass[lane] = L.m * mr;
-#pragma unroll
-    for (int k = 0; k < 6; k++) S.Ic[lane][k] = L.in[k] * ir + L.pa[k] * mr;
-  }
-}
-
 __device__ static void load_robot(const KParams& P, const float* rec, Shared& S, int lane) {
   for (int i = lane; i < kHead; i += kLanes) S.s[i] = rec[i];
   WSYNC();
@@ -46,18 +15,20 @@ __device__ static void load_robot(const KParams& P, const float* rec, Shared& S,
     unsigned int* cl = reinterpret_cast<unsigned int*>(&S.clip);
     if (lane < (int)(sizeof(DevClip) / 4)) cl[lane] = cg[lane];
   }
-  const float* mp = reinterpret_cast<const float*>(&gm.hot);
+  typedef const float __attribute__((address_space(1))) * gptr;    // the table lives in global memory: plain global loads, not FLAT
+  const gptr mp = (gptr)reinterpret_cast<const float*>(&gm.hot);
   float* dst = reinterpret_cast<float*>(&S.m);
   {
-    // all words of the model in flight at once (a rolled copy loop waits for every group of loads: six round trips to L2 per launch)
-    constexpr int kIter = (kModelLdsWords + kLanes - 1) / kLanes;
+    // the hot part of the model (512 B = 8 words per lane), all words in flight at once; the cold part stays in the device table
+    // (ModelCold) and the mass properties go straight into the registers of load_leg_const
+    static_assert(kModelLdsWords % kLanes == 0, "whole rows of the hot model per lane");
+    constexpr int kIter = kModelLdsWords / kLanes;
     float tmp[kIter];
 #pragma unroll
-    for (int k = 0; k < kIter; k++) { const int i = lane + k * kLanes; tmp[k] = mp[i < kModelLdsWords ? i : kModelLdsWords - 1]; }
+    for (int k = 0; k < kIter; k++) tmp[k] = mp[lane + k * kLanes];
 #pragma unroll
-    for (int k = 0; k < kIter; k++) { const int i = lane + k * kLanes; if (i < kModelLdsWords) dst[i] = tmp[k]; }
+    for (int k = 0; k < kIter; k++) dst[lane + k * kLanes] = tmp[k];
   }
-  refresh_mass(gm, S, lane);
   WSYNC();
 }
 
@@ -100,7 +71,8 @@ __device__ __forceinline__ void base_rotation(Shared& S, int lane, float rel[4],
 
 // Minitaur.receive_obs + get_true_obs (minitaur.py:304-334): push the true observation.  entry: optional copy of the pushed
 // entry (20 words, LDS) for callers that build the control observation without reading the ring back (reset_robot).
-__device__ static void receive_obs(float* rec, Shared& S, int lane, bool valid, float* entry = nullptr) {
+__device__ static void receive_obs(const KParams& P, float* rec, Shared& S, int lane, bool valid, float* entry = nullptr) {
+  const ColdPtr mc = model_cold(P, geti(S, O(ROBOT_TYPE)));
   const int head = (geti(S, O(RING_HEAD)) + 1) % ORR_RING_DEPTH, len = geti(S, O(RING_LEN));
   float rel[4], Rb[9], rate[3];
   base_rotation(S, lane, rel, Rb);
@@ -108,8 +80,8 @@ __device__ static void receive_obs(float* rec, Shared& S, int lane, bool valid, 
   for (int i = lane; i < ORR_RING_ENTRY; i += kLanes) {
     float val = 0.0f;
     if (i < 12) {
-      int j = S.m.joint_of_motor[i];
-      val = (S.s[O(Q) + j] - S.m.motor_offset[i]) * S.m.motor_dir[i];  // get_true_motor_angles (:543-553)
+      int j = mc->joint_of_motor[i];
+      val = (S.s[O(Q) + j] - mc->motor_offset[i]) * mc->motor_dir[i];  // get_true_motor_angles (:543-553)
     } else if (i < 16) {
       val = i == 12 ? rel[0] : (i == 13 ? rel[1] : (i == 14 ? rel[2] : rel[3]));
     } else if (i < 19) {

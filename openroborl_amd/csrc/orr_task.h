@@ -112,17 +112,19 @@ __device__ static void sample_poses_finish(const KParams& P, Shared& S, int lane
     const bool warm_pose = warm_ep && t_lane >= -(double)P.cfg.warmup_time && t_lane < 0.0;
     float out[19];
     if (warm_pose) {
-      // default pose rotated to the heading of frame(0) (imitation_task.py:985-1009, 1245-1252)
+      // default pose rotated to the heading of frame(0) (imitation_task.py:985-1009, 1245-1252); warm-up episodes only (cold table)
+      const ColdPtr mc = model_cold(P, geti(S, O(ROBOT_TYPE)));
+      const float ipos[3] = {mc->init_pos[0], mc->init_pos[1], mc->init_pos[2]};
       const float* fr0 = S.ph.end.frames[10];
       float dr[4], pp[3], qq[4], q0[4] = {fr0[3], fr0[4], fr0[5], fr0[6]};
       const float dh = qheading(q0) - qheading(S.m.init_quat);
       q_about_z(dh, dr);
-      qrot(S.m.init_pos, dr, pp);
+      qrot(ipos, dr, pp);
       qmul(dr, S.m.init_quat, qq);
       out[0] = pp[0]; out[1] = pp[1]; out[2] = pp[2];
       out[3] = qq[0]; out[4] = qq[1]; out[5] = qq[2]; out[6] = qq[3];
 #pragma unroll
-      for (int i = 0; i < 12; i++) out[7 + i] = S.m.default_joints[i];
+      for (int i = 0; i < 12; i++) out[7 + i] = mc->default_joints[i];
     } else {
       const float* a = S.ph.end.frames[2 * lane];
       const float* b = S.ph.end.frames[2 * lane + 1];
@@ -372,15 +374,20 @@ __device__ static void reset_robot(const KParams& P, float* rec, Shared& S, int 
   const uint32_t robot = (uint32_t)geti(S, O(ROBOT_INDEX)), ep = (uint32_t)geti(S, O(EPISODE_IDX)) + 1u;
   WSYNC();
   if (lane == 0) seti(S, O(EPISODE_IDX), (int)ep);
-  // 1-2. default pose at the grid slot, counters, ring, filter (minitaur.py:246-268, 465-483)
+  // 1-2. default pose at the grid slot, counters, ring, filter (minitaur.py:246-268, 465-483).  The per-motor reset constants come from
+  // the cold table: all lanes load (clamped index), no divergent `if` around the loads
+  const ColdPtr mc = model_cold(P, geti(S, O(ROBOT_TYPE)));
+  const int lm = lane < 12 ? lane : 0, l3 = lane < 3 ? lane : 0;
+  const int rj = mc->joint_of_motor[lm];
+  const float r_q0 = mc->init_motor_angles[lm] + mc->motor_offset[lm], r_p0 = mc->init_pos[l3];
   if (lane < 3) {
-    S.s[O(POS) + lane] = S.m.init_pos[lane] + (lane < 2 ? S.s[O(GRID_OFFSET) + lane] : 0.0f);
+    S.s[O(POS) + lane] = r_p0 + (lane < 2 ? S.s[O(GRID_OFFSET) + lane] : 0.0f);
     S.s[O(LINVEL) + lane] = 0.0f; S.s[O(ANGVEL) + lane] = 0.0f;
   }
   if (lane < 4) S.s[O(QUAT) + lane] = S.m.init_quat[lane];
   if (lane < 12) {
-    const int j = S.m.joint_of_motor[lane];
-    S.s[O(Q) + j] = S.m.init_motor_angles[lane] + S.m.motor_offset[lane];  // no direction factor (minitaur.py:481)
+    const int j = rj;
+    S.s[O(Q) + j] = r_q0;  // no direction factor (minitaur.py:481)
     S.s[O(QD) + j] = 0.0f;
     S.s[O(LAST_ACTION) + lane] = 0.0f; S.s[O(ACTION) + lane] = 0.0f; S.s[O(FILTER_ACTION) + lane] = 0.0f; S.s[O(LAMBDA) + lane] = 0.0f;
     S.s[O(XHIST) + lane] = 0.0f; S.s[O(XHIST) + 12 + lane] = 0.0f; S.s[O(YHIST) + lane] = 0.0f; S.s[O(YHIST) + 12 + lane] = 0.0f;
@@ -433,13 +440,11 @@ __device__ static void reset_robot(const KParams& P, float* rec, Shared& S, int 
   PT(20);
   PoseLoads PL;
   sample_poses_issue(P, S, lane, tl, PL, 26);     // uses red[0..9] until it returns
-  MassLoads ML;
-  if (c.flags & ORR_FLAG_RANDOMIZER) mass_prefetch(P.tab->model[geti(S, O(ROBOT_TYPE))], lane, ML);
   PT(19);
   // ring entries #1 and #2 of the new episode are kept (LDS) so that the control observations of the reset are blended from them
   // directly: reading the ring back would be a store -> load round trip through memory each time
   float* e1 = S.ph.end.red;            // 20 words each
-  receive_obs(rec, S, lane, valid, e1);  // ring entry #1
+  receive_obs(P, rec, S, lane, valid, e1);  // ring entry #1
   // 3. sensor histories <- 3 copies of the current readings (minitaur.py:270-271; sensor_wrappers.py:122-129)
   PT(17);
   WSYNC();
@@ -461,9 +466,7 @@ __device__ static void reset_robot(const KParams& P, float* rec, Shared& S, int 
       else if (i < 14) S.s[O(MASS_RATIO) + i - 12] = 0.8f + u * 0.4f;
       else S.s[O(STRENGTH) + i - 14] = 0.8f + u * 0.4f;
     }
-    WSYNC();
-    refresh_mass_from(ML, S, lane);
-    WSYNC();
+    WSYNC();   // the new mass / inertia ratios take effect in the next launch's load_leg_const (no staged mass table any more)
   }
   PT(25);
   // 5b. the reference poses of the start time
@@ -496,7 +499,7 @@ __device__ static void reset_robot(const KParams& P, float* rec, Shared& S, int 
   WSYNC();
   PT(22);
   float* e2 = S.ph.end.red + 56;         // ring entry #2; entry #1 was saved in registers below before red[] was reused
-  receive_obs(rec, S, lane, valid, e2);  // ring entry #2 (imitation_task.py:792)
+  receive_obs(P, rec, S, lane, valid, e2);  // ring entry #2 (imitation_task.py:792)
   {
     // control observation with two entries in the ring (Minitaur._get_delay_obs, minitaur.py:336-357): latency <= 0 -> newest;
     // int(latency / dt) + 1 >= 2 -> the OLDEST entry (#1, the default pose: SURVEY 8a quirk 3); else blend newest / #1
