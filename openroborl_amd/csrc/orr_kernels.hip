@@ -12,6 +12,7 @@
 #include <type_traits>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "orr_device.h"
@@ -73,13 +74,19 @@ __global__ __launch_bounds__(64) void orr_reset_kernel(KParams P, const uint8_t*
 // which the physics sub-step is replaced by the recorded states of ReplayArgs, the end-effector reward reads recorded link
 // positions and the fall flag is given -- the device-side counterpart of the oracle's replay mode, fed with the fixtures that the
 // reference's own Python produced (tests/test_gpu_golden_task.py).
-#ifndef ORR_WAVES_PER_EU
-#define ORR_WAVES_PER_EU 1  // 4096 robots, four per wave = one wave on each of the 1024 SIMDs: the whole batch is resident at once
-#endif
+// WPE = waves per SIMD the kernel is compiled for.  WPE 1: up to 512 VGPRs (~300 used), one wave on each of the 1024 SIMDs = 4096 robots
+// resident at once: the best a batch of <= 4096 robots can do.  WPE 2 (<= 256 VGPRs, ~55 of them spilled; LDS 19.9 KB per wave, so
+// eight waves fit a CU): for larger batches.  A lone wave issues one vector instruction per ~5 cycles, the SIMD can take one per 2:
+// two co-resident waves of this kernel take 1.12x as long as one alone (tools/wave_pairing.py), i.e. 1.8x the throughput per SIMD,
+// where the WPE-1 kernel would run the second thousand waves after the first.  orr_step picks the variant from the batch size and the
+// device's CU count (ORR_STEP_WAVES_PER_EU = 1 | 2 overrides, for measurements).
 // (min, max) waves per SIMD are pinned to the same value: with a higher maximum this LLVM's iterative-ilp scheduler tries
 // occupancy-improving reschedules once the kernel fits 256 VGPRs and then crashes in the register allocator.
-template <int MODE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORR_WAVES_PER_EU, ORR_WAVES_PER_EU))) void orr_step_kernel(KParams P, const float* actions, float* obs_out, float* reward_out,
+#ifndef ORR_WAVES_PER_EU
+#define ORR_WAVES_PER_EU 1   // development builds (-DORR_WAVES_PER_EU=2) force every instantiation to that occupancy
+#endif
+template <int MODE, int WPE = ORR_WAVES_PER_EU>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void orr_step_kernel(KParams P, const float* actions, float* obs_out, float* reward_out,
                                                       uint8_t* done_out, int nsub, ReplayArgs RP) {
   ORR_PROLOGUE();
   const bool valid = in_range;
@@ -386,6 +393,8 @@ __global__ __launch_bounds__(1024) void orr_eplog_pack_kernel(long long* counter
 // ================================================================================================
 struct orr_handle {
   orr_config cfg;
+  int simds;          // SIMDs of the device (4 per CU): a batch of more waves than that runs the two-waves-per-SIMD variant of the step kernel
+  int force_wpe;      // ORR_STEP_WAVES_PER_EU (0 = automatic)
   DevTables* tab_dev;
   DevTables tab_host;
   float fb[3], fa[3];
@@ -466,6 +475,13 @@ int32_t orr_create(const orr_config* cfg, orr_handle** out) {
     const double K = tan(M_PI * wn / 2.0), K2 = K * K, den = 1.0 + sqrt(2.0) * K + K2;
     h->fb[0] = (float)(K2 / den); h->fb[1] = (float)(2.0 * K2 / den); h->fb[2] = (float)(K2 / den);
     h->fa[0] = 1.0f; h->fa[1] = (float)(2.0 * (K2 - 1.0) / den); h->fa[2] = (float)((1.0 - sqrt(2.0) * K + K2) / den);
+  }
+  {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    h->simds = 4 * cus;
+    const char* f = getenv("ORR_STEP_WAVES_PER_EU");
+    h->force_wpe = (f && (f[0] == '1' || f[0] == '2') && f[1] == 0) ? f[0] - '0' : 0;
   }
   e = hipMalloc((void**)&h->tab_dev, sizeof(DevTables));
   if (e != hipSuccess) { delete h; return fail(-2, "orr_create: hipMalloc", e); }
@@ -612,8 +628,14 @@ int32_t orr_reset(orr_handle* h, const uint8_t* mask_dev, float* obs_dev, void* 
 int32_t orr_step(orr_handle* h, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev, void* stream) {
   if (!h || !h->state) return fail(-1, "orr_step: handle not bound");
   if (!actions_dev || !obs_dev || !reward_dev || !done_dev) return fail(-1, "orr_step: null buffer");
-  hipLaunchKernelGGL(orr_step_kernel<0>, dim3((h->cfg.num_robots + kRPW - 1) / kRPW), dim3(64), 0, (hipStream_t)stream, make_params(h), actions_dev,
-                     obs_dev, reward_dev, done_dev, 0, ReplayArgs{});
+  const int waves = (h->cfg.num_robots + kRPW - 1) / kRPW;
+  const bool two = h->force_wpe ? h->force_wpe == 2 : waves > h->simds;
+  if (two)
+    hipLaunchKernelGGL((orr_step_kernel<0, 2>), dim3(waves), dim3(64), 0, (hipStream_t)stream, make_params(h), actions_dev, obs_dev, reward_dev,
+                       done_dev, 0, ReplayArgs{});
+  else
+    hipLaunchKernelGGL((orr_step_kernel<0, 1>), dim3(waves), dim3(64), 0, (hipStream_t)stream, make_params(h), actions_dev, obs_dev, reward_dev,
+                       done_dev, 0, ReplayArgs{});
   HIPCHK(hipGetLastError(), "orr_step: launch");
   return 0;
 }
