@@ -62,6 +62,8 @@ def test_hip_drift_is_float32_drift(robot):
         assert tab[h]["alive"] >= 100, "too few robots survive to horizon %d" % h
         for name in list(drift.FIELDS) + [g for g, _ in drift.OBS_GROUPS] + ["reward"]:
             for q, fac in FACTOR.items():
+                if q == "max" and name not in drift.MAX_ASSERTED:
+                    continue
                 d, f = tab[h][name]["dev"][q], tab[h][name]["f32"][q]
                 if d > fac * f + FLOOR:
                     bad.append("%s h=%d %s: HIP %.3g > %.1f x f32 %.3g" % (name, h, q, d, fac, f))

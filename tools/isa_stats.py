@@ -49,43 +49,56 @@ def classify(m):
 def main():
     flags = [f for f in _lib.HIPCC_FLAGS if f not in ("-shared", "-fPIC")] + sys.argv[1:]
     out = os.path.join(tempfile.mkdtemp(), "step.s")
-    subprocess.check_call([_lib.HIPCC] + flags + ["-S", "--cuda-device-only", "-o", out, _lib.SRC], stderr=subprocess.DEVNULL)
+    src = os.environ.get("ORR_ISA_SRC", _lib.SRC)      # another tree's orr_kernels.hip (A/B of code generation)
+    subprocess.check_call([_lib.HIPCC] + flags + ["-S", "--cuda-device-only", "-o", out, src], stderr=subprocess.DEVNULL)
     lines = open(out).read().split("\n")
-    start = next(i for i, l in enumerate(lines) if re.match(r"^_Z15orr_step_kernelILi0E.*:", l))
-    end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
-    body = lines[start:end + 1]
-    labels = {}
-    insts = []
-    for l in body:
-        t = l.split(";")[0].strip()
-        if not t:
-            continue
-        m = re.match(r"^(\.?[A-Za-z_0-9$]+):$", t)
-        if m:
-            labels[m.group(1)] = len(insts)
-            continue
-        if t.startswith("."):
-            continue
-        insts.append(t)
-    # largest backward branch
-    best = (0, 0, 0)
-    for i, t in enumerate(insts):
-        m = re.match(r"^s_c?branch\S*\s+(\S+)$", t)
-        if m and m.group(1) in labels and labels[m.group(1)] < i and i - labels[m.group(1)] > best[0]:
-            best = (i - labels[m.group(1)], labels[m.group(1)], i)
-    for name, seg in (("whole kernel", insts), ("largest loop (sub-steps)", insts[best[1]:best[2] + 1])):
-        c = collections.Counter(classify(t.split()[0]) for t in seg)
-        tot = sum(c.values())
-        print("%s: %d instructions" % (name, tot))
-        for k, v in c.most_common():
-            print("   %-18s %6d  %5.1f%%" % (k, v, 100.0 * v / tot))
-    for l in lines:
-        if "orr_step_kernelILi0E" in l and ("NumVgprs" in l or "spill" in l):
-            print(l)
     meta = "\n".join(lines)
-    m = re.search(r"\.name:\s+_Z15orr_step_kernelILi0E.*?\.vgpr_spill_count:\s+\d+", meta, re.S)
-    if m:
-        print(re.sub(r"\s+", " ", " ".join(x for x in m.group(0).split("\n") if "count" in x or "lds" in x or "group_segment" in x)))
+    # one report per variant of the step kernel (WPE 1: one wave per SIMD, WPE 2: two; see orr_kernels.hip)
+    for sym, title in (("_Z15orr_step_kernelILi0ELi1E", "step kernel, one wave per SIMD"), ("_Z15orr_step_kernelILi0ELi2E", "step kernel, two waves per SIMD")):
+        try:
+            start = next(i for i, l in enumerate(lines) if re.match(r"^%s.*:" % sym, l))
+        except StopIteration:
+            continue
+        end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
+        body = lines[start:end + 1]
+        labels = {}
+        insts = []
+        for l in body:
+            t = l.split(";")[0].strip()
+            if not t:
+                continue
+            m = re.match(r"^(\.?[A-Za-z_0-9$]+):$", t)
+            if m:
+                labels[m.group(1)] = len(insts)
+                continue
+            if t.startswith("."):
+                continue
+            insts.append(t)
+        # the sub-step loop = the backward branch whose body holds the most DPP instructions (the Gauss-Seidel sweeps live there); the
+        # largest backward branch alone can be some other loop of the step-end / reset code
+        best = (0, 0, 0)
+        dpp_prefix = [0]
+        for t in insts:
+            dpp_prefix.append(dpp_prefix[-1] + ("dpp" in t.split()[0]))
+        best_key = (-1, -1)
+        for i, t in enumerate(insts):
+            m = re.match(r"^s_c?branch\S*\s+(\S+)$", t)
+            if m and m.group(1) in labels and labels[m.group(1)] < i:
+                lo = labels[m.group(1)]
+                key = (dpp_prefix[i + 1] - dpp_prefix[lo], i - lo)
+                if key > best_key:
+                    best_key, best = key, (i - lo, lo, i)
+        print("==== %s" % title)
+        for name, seg in (("whole kernel", insts), ("largest loop (sub-steps)", insts[best[1]:best[2] + 1])):
+            c = collections.Counter(classify(t.split()[0]) for t in seg)
+            tot = sum(c.values())
+            scratch = sum(1 for t in seg if t.startswith("scratch_") or t.startswith("buffer_") and "offen" in t)
+            print("%s: %d instructions (scratch accesses: %d)" % (name, tot, scratch))
+            for k, v in c.most_common():
+                print("   %-18s %6d  %5.1f%%" % (k, v, 100.0 * v / tot))
+        m = re.search(r"\.group_segment_fixed_size:\s+(\d+)(?:(?!\.group_segment_fixed_size).)*?\.name:\s+%s.*?\.private_segment_fixed_size:\s+(\d+).*?\.sgpr_count:\s+(\d+).*?\.sgpr_spill_count:\s+(\d+).*?\.vgpr_count:\s+(\d+).*?\.vgpr_spill_count:\s+(\d+)" % sym, meta, re.S)
+        if m:
+            print(" LDS %s B, scratch %s B per lane, sgpr %s (spilled %s), vgpr %s (spilled %s)" % m.groups())
 
 
 if __name__ == "__main__":
