@@ -12,8 +12,9 @@ from . import _abi
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(PKG_DIR, "csrc", "orr_kernels.hip")
+SRC_W2 = os.path.join(PKG_DIR, "csrc", "orr_kernels_w2.hip")      # the two-waves-per-SIMD step kernel: its own translation unit + flags
 SRC_POLICY = os.path.join(PKG_DIR, "csrc", "orr_policy.hip")
-DEPS = [SRC, SRC_POLICY] + [os.path.join(PKG_DIR, "csrc", h) for h in ("orr_device.h", "orr_robot_io.h", "orr_physics.h", "orr_task.h")] + [
+DEPS = [SRC, SRC_W2, SRC_POLICY] + [os.path.join(PKG_DIR, "csrc", h) for h in ("orr_device.h", "orr_robot_io.h", "orr_physics.h", "orr_task.h")] + [
         os.path.join(os.path.dirname(PKG_DIR), "include", "openroborl_hip.h"),
         os.path.join(os.path.dirname(PKG_DIR), "include", "openroborl_policy.h")]
 LIB_PATH = os.path.join(PKG_DIR, "libopenroborl_hip.so")
@@ -28,6 +29,11 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # the reset and consumed after it instead, and the per-launch counters are combined per wave by hand (orr_step_kernel).
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O2", "-fPIC", "-shared", "-std=c++17", "-Wno-unused-value", "-fno-slp-vectorize",
                "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
+
+# The second translation unit (orr_kernels_w2.hip = the step kernel compiled for two waves per SIMD, used for batches of more than
+# 4 x #SIMDs robots) keeps the compiler's DEFAULT scheduler: at 256 registers that variant spills, and the ILP schedule's long live
+# ranges cost it 8 % (8192 robots: 0.382 -> 0.352 ms), while the default scheduler costs the one-wave variant 9 % (tools/ab_variants.sh).
+HIPCC_FLAGS_W2 = [f for i, f in enumerate(HIPCC_FLAGS) if "amdgpu-sched-strategy" not in f and not (f == "-mllvm" and i + 1 < len(HIPCC_FLAGS) and "amdgpu-sched-strategy" in HIPCC_FLAGS[i + 1])]
 
 EXPORTS = [
     "orr_last_error", "orr_abi_version", "orr_source_hash", "orr_state_stride", "orr_layout_count", "orr_layout_name",
@@ -62,6 +68,7 @@ def source_hash(extra_flags=()):
         with open(d, "rb") as f:
             h.update(f.read())
     h.update(" ".join(HIPCC_FLAGS).encode())
+    h.update(" ".join(HIPCC_FLAGS_W2).encode())
     extra = tuning_defines() + list(extra_flags)
     if extra:
         h.update(("|" + " ".join(extra)).encode())
@@ -110,22 +117,32 @@ def build(force=False, verbose=False, out_path=None, extra_flags=()):
                 return LIB_PATH              # another rank built it while this one waited for the lock
             flags = [f for f in HIPCC_FLAGS if f != "-shared"] + ["-c", '-DORR_SOURCE_HASH="%s"' % source_hash(extra_flags)]
             flags += tuning_defines() + list(extra_flags)
+            flags_w2 = [f for f in HIPCC_FLAGS_W2 if f != "-shared"] + ["-c"] + tuning_defines() + list(extra_flags)
             tag = ".%d" % os.getpid()
             obj_env = os.path.join(PKG_DIR, "csrc", "orr_kernels%s.o" % tag)
+            obj_w2 = os.path.join(PKG_DIR, "csrc", "orr_kernels_w2%s.o" % tag)
             obj_pol = os.path.join(PKG_DIR, "csrc", "orr_policy%s.o" % tag)
             tmp_so = out_path + tag + ".tmp"
             cmds = [[HIPCC] + flags + ["-o", obj_env, SRC],
+                    [HIPCC] + flags_w2 + ["-o", obj_w2, SRC_W2],
                     # the policy forward pass (matrix cores) is its own translation unit with the compiler's default scheduling
                     [HIPCC, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-c", "-o", obj_pol, SRC_POLICY],
-                    [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp_so, obj_env, obj_pol]]
+                    [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp_so, obj_env, obj_w2, obj_pol]]
             try:
-                for cmd in cmds:
+                procs = []
+                for cmd in cmds[:3]:            # the three compiles are independent: run them side by side
                     if verbose:
                         print(" ".join(cmd))
-                    subprocess.check_call(cmd)
+                    procs.append(subprocess.Popen(cmd))
+                rcs = [p.wait() for p in procs]
+                if any(rcs):
+                    raise subprocess.CalledProcessError(next(r for r in rcs if r), cmds[rcs.index(next(r for r in rcs if r))])
+                if verbose:
+                    print(" ".join(cmds[3]))
+                subprocess.check_call(cmds[3])
                 os.replace(tmp_so, out_path)
             finally:
-                for o in (obj_env, obj_pol, tmp_so):
+                for o in (obj_env, obj_w2, obj_pol, tmp_so):
                     if os.path.exists(o):
                         os.remove(o)
         finally:

@@ -8,6 +8,14 @@
 // Device code by phase: orr_device.h (LDS image, math, DPP helpers), orr_robot_io.h (record load / store, latency
 // ring), orr_physics.h (one physics sub-step), orr_task.h (motion clips, reward, observation, reset); this file holds
 // the two kernels and the C-ABI.
+// Two translation units are built from this file.  The main one (everything) is compiled with the instruction-level-parallelism
+// scheduler: one wave per SIMD, ~300 registers, nothing to hide latency but the wave's own independent instructions.  The second
+// one (orr_kernels_w2.hip: #define ORR_TU_STEP_W2 + #include of this file) holds ONLY the two-waves-per-SIMD instantiation of the step
+// kernel and is compiled with the compiler's default (occupancy-minded) scheduler: at 256 registers that variant spills, and the ILP
+// schedule's longer live ranges cost it 8 % (0.382 vs 0.352 ms at 8192 robots; the default scheduler costs the one-wave variant 9 %).
+#ifdef ORR_TU_STEP_W2
+#undef ORR_PHASE_TIMERS      // the development timers live in the main translation unit only
+#endif
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include <math.h>
@@ -57,6 +65,7 @@ using namespace orr;
   const int robot = in_range ? robot_raw : 0; /* a padding lane group shadows robot 0 and never stores */ \
   float* rec = P.state + (size_t)robot * ORR_STATE_STRIDE
 
+#ifndef ORR_TU_STEP_W2
 __global__ __launch_bounds__(64) void orr_reset_kernel(KParams P, const uint8_t* mask, float* obs_out, const float* uniforms) {
   ORR_PROLOGUE();
   const bool valid = in_range && !(mask && !mask[robot]);
@@ -68,6 +77,7 @@ __global__ __launch_bounds__(64) void orr_reset_kernel(KParams P, const uint8_t*
   if (obs_out && valid)
     for (int i = lane; i < ORR_OBS_DIM; i += kLanes) obs_out[(size_t)robot * ORR_OBS_DIM + i] = obs[i];
 }
+#endif  // !ORR_TU_STEP_W2
 
 // mode 0: full env step.  mode 1 (debug / parity of row C): nsub physics sub-steps with the given
 // motor torques (actions = torques), no robot or task logic.  mode 2 (parity of everything BUT row C): a full env step in
@@ -351,6 +361,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
   PT_TIMELINE((long long)((fin_mask & 1ull) | ((fin_mask >> 15) & 2ull) | ((fin_mask >> 30) & 4ull) | ((fin_mask >> 45) & 8ull)));   // one bit per robot of the wave
 }
 
+namespace orr {
+// launcher of the two-waves-per-SIMD instantiation, defined in the second translation unit (see the top of this file)
+hipError_t launch_step_w2(const KParams& P, int waves, hipStream_t stream, const float* actions, float* obs, float* reward, uint8_t* done);
+}
+#ifdef ORR_TU_STEP_W2
+namespace orr {
+hipError_t launch_step_w2(const KParams& P, int waves, hipStream_t stream, const float* actions, float* obs, float* reward, uint8_t* done) {
+  hipLaunchKernelGGL((orr_step_kernel<0, 2>), dim3(waves), dim3(64), 0, stream, P, actions, obs, reward, done, 0, ReplayArgs{});
+  return hipGetLastError();
+}
+}  // namespace orr
+#else   // ---- everything below: main translation unit only ----
+
+
 // Rollout boundary (agents/ppo_imitation.py:405-423): pack this rank's episode log into the fixed-size float64 payload of the
 // all-gather -- [n_listed, total_timesteps, n_dropped, n_episodes, sum_ret, sum_len, ret[K], len[K]] -- and clear the log, in
 // ONE launch of one workgroup (the log holds at most a few ten thousand (return, length) pairs).
@@ -630,13 +654,13 @@ int32_t orr_step(orr_handle* h, const float* actions_dev, float* obs_dev, float*
   if (!actions_dev || !obs_dev || !reward_dev || !done_dev) return fail(-1, "orr_step: null buffer");
   const int waves = (h->cfg.num_robots + kRPW - 1) / kRPW;
   const bool two = h->force_wpe ? h->force_wpe == 2 : waves > h->simds;
-  if (two)
-    hipLaunchKernelGGL((orr_step_kernel<0, 2>), dim3(waves), dim3(64), 0, (hipStream_t)stream, make_params(h), actions_dev, obs_dev, reward_dev,
-                       done_dev, 0, ReplayArgs{});
-  else
+  if (two) {
+    HIPCHK(launch_step_w2(make_params(h), waves, (hipStream_t)stream, actions_dev, obs_dev, reward_dev, done_dev), "orr_step: launch (two waves per SIMD)");
+  } else {
     hipLaunchKernelGGL((orr_step_kernel<0, 1>), dim3(waves), dim3(64), 0, (hipStream_t)stream, make_params(h), actions_dev, obs_dev, reward_dev,
                        done_dev, 0, ReplayArgs{});
-  HIPCHK(hipGetLastError(), "orr_step: launch");
+    HIPCHK(hipGetLastError(), "orr_step: launch");
+  }
   return 0;
 }
 
@@ -721,3 +745,4 @@ int orr_debug_wave_timeline(long long* out, int waves) {
 #endif
 
 }  // extern "C"
+#endif  // !ORR_TU_STEP_W2

@@ -52,6 +52,11 @@ def main():
     src = os.environ.get("ORR_ISA_SRC", _lib.SRC)      # another tree's orr_kernels.hip (A/B of code generation)
     subprocess.check_call([_lib.HIPCC] + flags + ["-S", "--cuda-device-only", "-o", out, src], stderr=subprocess.DEVNULL)
     lines = open(out).read().split("\n")
+    src_w2 = os.path.join(os.path.dirname(src), "orr_kernels_w2.hip")
+    if os.path.exists(src_w2):       # the two-waves-per-SIMD variant is its own translation unit with its own flags
+        flags_w2 = [f for f in _lib.HIPCC_FLAGS_W2 if f not in ("-shared", "-fPIC")] + sys.argv[1:]
+        subprocess.check_call([_lib.HIPCC] + flags_w2 + ["-S", "--cuda-device-only", "-o", out + "2", src_w2], stderr=subprocess.DEVNULL)
+        lines += open(out + "2").read().split("\n")
     meta = "\n".join(lines)
     # one report per variant of the step kernel (WPE 1: one wave per SIMD, WPE 2: two; see orr_kernels.hip)
     for sym, title in (("_Z15orr_step_kernelILi0ELi1E", "step kernel, one wave per SIMD"), ("_Z15orr_step_kernelILi0ELi2E", "step kernel, two waves per SIMD")):
