@@ -317,6 +317,8 @@ def main():
         traffic, valu, issue = None, {}, None
         clock_hz = 1e3 * float(getattr(torch.cuda.get_device_properties(dev), "clock_rate", 2.4e6))   # kHz -> Hz (2.4 GHz)
         tag = args.config + ("_norand" if args.no_randomizer else "")
+        if os.environ.get("ORR_STEP_WAVES_PER_EU") == "1" and n > 4 * 4 * torch.cuda.get_device_properties(dev).multi_processor_count:
+            tag += "_wpe1"          # a batch that would run the two-waves-per-SIMD variant, forced onto the one-wave kernel (comparison runs)
         for rnd in ("r03", "r02"):
             name = "%s_%s_pmc_summary.json" % (rnd, tag)
             pmc = os.path.join(ROOT, "profiles", name)
@@ -332,15 +334,21 @@ def main():
                         "wait_any_frac_of_wave_cycles": d["SQ_WAIT_ANY"]["mean_per_launch"] / d["SQ_WAVE_CYCLES"]["mean_per_launch"],
                         "waves_per_simd": waves / 1024.0}
                 # THE BOUND THAT BINDS: VALU issue of the waves resident on a SIMD.  A lone wave issues at most one VALU instruction
-                # per 4 cycles (MI355X_MICROARCH.md: dependent-issue cadence of a single wave), a SIMD with >= 2 waves one per 2.
-                # `rounds` = how many waves a SIMD runs one after the other (4096 robots: 1; 8192: 2).
+                # per 4 cycles (MI355X_MICROARCH.md: issue cadence of a single wave), a SIMD with >= 2 resident waves one per 2.
+                # Batches of up to 4 x #SIMDs robots run the one-wave-per-SIMD variant of the kernel (every wave alone on its SIMD:
+                # the lone-wave ceiling applies), larger ones the two-waves-per-SIMD variant (orr_step; ORR_STEP_WAVES_PER_EU overrides).
                 ipw = d["SQ_INSTS_VALU"]["mean_per_launch"] / waves
-                rounds = max(1.0, waves / 1024.0)
+                simds = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
+                forced = os.environ.get("ORR_STEP_WAVES_PER_EU", "")
+                resident = int(forced) if forced in ("1", "2") else (2 if waves > simds else 1)
+                per_simd = max(1.0, waves / float(simds))            # waves a SIMD runs per launch (together or one after the other)
                 kcyc = kern_ms * 1e-3 * clock_hz
                 issue = {"source": "profiles/" + name + " (instruction counts) x this run's kernel_ms",
-                         "insts_per_wave": ipw, "waves_per_simd_in_series": rounds, "cycles_per_inst_lone_wave": 4,
+                         "insts_per_wave": ipw, "waves_per_simd_per_launch": per_simd, "waves_resident_per_simd": resident,
+                         "cycles_per_inst_lone_wave": 4, "cycles_per_inst_simd": 2,
                          "shader_clock_ghz": clock_hz / 1e9, "kernel_cycles": kcyc,
-                         "frac_of_lone_wave_ceiling": ipw * rounds * 4.0 / kcyc, "frac_of_simd_peak": ipw * rounds * 2.0 / kcyc,
+                         "frac_of_lone_wave_ceiling": (ipw * per_simd * 4.0 / kcyc) if resident == 1 else None,
+                         "frac_of_simd_peak": ipw * per_simd * 2.0 / kcyc,
                          "tail_frac": None}
                 for rnd2 in ("r03", "r02"):
                     tl = os.path.join(ROOT, "profiles", "%s_wave_timeline.txt" % rnd2)

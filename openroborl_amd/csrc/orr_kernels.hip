@@ -657,7 +657,9 @@ int32_t orr_step(orr_handle* h, const float* actions_dev, float* obs_dev, float*
   if (two) {
     HIPCHK(launch_step_w2(make_params(h), waves, (hipStream_t)stream, actions_dev, obs_dev, reward_dev, done_dev), "orr_step: launch (two waves per SIMD)");
   } else {
-    hipLaunchKernelGGL((orr_step_kernel<0, 1>), dim3(waves), dim3(64), 0, (hipStream_t)stream, make_params(h), actions_dev, obs_dev, reward_dev,
+    // <0> = <0, ORR_WAVES_PER_EU>: one wave per SIMD in the shipped build; development builds (-DORR_WAVES_PER_EU=2 with the timers of
+    // this translation unit, tools/wave_pairing.py) get their instrumented two-wave kernel through this path with ORR_STEP_WAVES_PER_EU=1
+    hipLaunchKernelGGL((orr_step_kernel<0>), dim3(waves), dim3(64), 0, (hipStream_t)stream, make_params(h), actions_dev, obs_dev, reward_dev,
                        done_dev, 0, ReplayArgs{});
     HIPCHK(hipGetLastError(), "orr_step: launch");
   }

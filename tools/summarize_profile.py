@@ -39,7 +39,7 @@ for f in newest(os.path.join(src, "pmc_*", "**", "*counter_collection.csv")):
             continue
         c = r["Counter_Name"]
         acc.setdefault(c, []).append(float(r["Counter_Value"]))
-        if "ILi0E" in r.get("Kernel_Name", "") or "<0>" in r.get("Kernel_Name", ""):
+        if "ILi0E" in r.get("Kernel_Name", "") or "<0" in r.get("Kernel_Name", ""):
             for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Grid_Size", "Workgroup_Size"):
                 if k in r:
                     summary.setdefault("dispatch", {})[k] = r[k]

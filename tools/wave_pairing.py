@@ -22,6 +22,7 @@ LIB = os.path.join(ROOT, "openroborl_amd", "libopenroborl_pairing_w%d.so" % wpe)
 from openroborl_amd import _lib as _build  # noqa: E402
 _build.build(out_path=LIB, extra_flags=["-DORR_PHASE_TIMERS", "-DORR_WAVES_PER_EU=%d" % wpe])
 os.environ["ORR_LIB_PATH"] = LIB
+os.environ["ORR_STEP_WAVES_PER_EU"] = "1"     # = the main translation unit's kernel, which this build compiled for `wpe` waves per SIMD + timers
 
 import torch  # noqa: E402
 from openroborl_amd import _lib  # noqa: E402
