@@ -5,8 +5,22 @@
 // ================================================================================================
 // load / store of the per-robot record
 // ================================================================================================
+// The state head moves in 16-byte pieces (global_load_dwordx4 / ds_write_b128 and back): 5 instead of 20 memory instructions per lane
+// at either end of a launch, where all waves of the chip load / store their records at about the same time.
+typedef float f4 __attribute__((ext_vector_type(4)));
 __device__ static void load_robot(const KParams& P, const float* rec, Shared& S, int lane) {
-  for (int i = lane; i < kHead; i += kLanes) S.s[i] = rec[i];
+  {
+    static_assert(kHead % 4 == 0 && ORR_STATE_STRIDE % 4 == 0, "16-byte pieces");
+    typedef const f4 __attribute__((address_space(1))) * g4ptr;
+    const g4ptr src = (g4ptr)reinterpret_cast<const f4*>(rec);
+    f4* dst = reinterpret_cast<f4*>(S.s);
+    constexpr int kQ = kHead / 4, kIt = (kQ + kLanes - 1) / kLanes;
+    f4 tmp[kIt];
+#pragma unroll
+    for (int k = 0; k < kIt; k++) { const int q = lane + k * kLanes; tmp[k] = src[q < kQ ? q : kQ - 1]; }
+#pragma unroll
+    for (int k = 0; k < kIt; k++) { const int q = lane + k * kLanes; if (q < kQ) dst[q] = tmp[k]; }
+  }
   WSYNC();
   const DevModel& gm = P.tab->model[geti(S, O(ROBOT_TYPE))];
   {
@@ -33,8 +47,15 @@ __device__ static void load_robot(const KParams& P, const float* rec, Shared& S,
 }
 
 __device__ static void store_robot(float* rec, const Shared& S, int lane, bool valid) {
-  if (valid)
-    for (int i = lane; i < O(RING); i += kLanes) rec[i] = S.s[i];
+  if (valid) {
+    typedef f4 __attribute__((address_space(1))) * g4ptr;
+    const g4ptr dst = (g4ptr)reinterpret_cast<f4*>(rec);
+    const f4* src = reinterpret_cast<const f4*>(S.s);
+    constexpr int kQ = O(RING) / 4;                 // whole 16-byte pieces of the head; the remaining words one by one
+#pragma unroll
+    for (int k = 0; k < (kQ + kLanes - 1) / kLanes; k++) { const int q = lane + k * kLanes; if (q < kQ) dst[q] = src[q]; }
+    if (lane < O(RING) - 4 * kQ) rec[4 * kQ + lane] = S.s[4 * kQ + lane];
+  }
 }
 
 // ================================================================================================
