@@ -110,10 +110,11 @@ struct ModelCold {
   float inertia_pa[13][6];
   int group[13];
 };
-struct DevModel {
+struct alignas(16) DevModel {   // 16-byte aligned in the device table: the hot part is copied to LDS in 16-byte pieces
   ModelHot hot;
   ModelCold cold;
 };
+static_assert(sizeof(DevModel) % 16 == 0 && offsetof(DevModel, hot) == 0, "16-byte pieces");
 constexpr int kModelLdsWords = (int)(sizeof(ModelHot) / 4);
 
 struct DevTables {

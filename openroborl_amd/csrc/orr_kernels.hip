@@ -337,8 +337,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
   WSYNC();
   PT(14);
   store_robot(rec, S, lane, valid);
-  if (valid)
-    for (int i = lane; i < ORR_OBS_DIM; i += kLanes) obs_out[(size_t)robot * ORR_OBS_DIM + i] = obs[i];
+  if (valid) {   // the observation, in 16-byte pieces like the record (40 per robot)
+    typedef f4 __attribute__((address_space(1))) * g4ptr;
+    static_assert(ORR_OBS_DIM % 4 == 0, "16-byte pieces");
+    const g4ptr od = (g4ptr)reinterpret_cast<f4*>(obs_out + (size_t)robot * ORR_OBS_DIM);
+    const f4* os = reinterpret_cast<const f4*>(obs);
+#pragma unroll
+    for (int k = 0; k < (ORR_OBS_DIM / 4 + kLanes - 1) / kLanes; k++) { const int q = lane + k * kLanes; if (q < ORR_OBS_DIM / 4) od[q] = os[q]; }
+  }
   PT(15);
   PT_FLUSH();
   // One counter update per WAVE (the compiler's own atomic combining is switched off, see _lib.HIPCC_FLAGS: it makes the issuing

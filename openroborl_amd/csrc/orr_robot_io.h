@@ -29,15 +29,16 @@ __device__ static void load_robot(const KParams& P, const float* rec, Shared& S,
     unsigned int* cl = reinterpret_cast<unsigned int*>(&S.clip);
     if (lane < (int)(sizeof(DevClip) / 4)) cl[lane] = cg[lane];
   }
-  typedef const float __attribute__((address_space(1))) * gptr;    // the table lives in global memory: plain global loads, not FLAT
-  const gptr mp = (gptr)reinterpret_cast<const float*>(&gm.hot);
-  float* dst = reinterpret_cast<float*>(&S.m);
   {
-    // the hot part of the model (512 B = 8 words per lane), all words in flight at once; the cold part stays in the device table
-    // (ModelCold) and the mass properties go straight into the registers of load_leg_const
-    static_assert(kModelLdsWords % kLanes == 0, "whole rows of the hot model per lane");
-    constexpr int kIter = kModelLdsWords / kLanes;
-    float tmp[kIter];
+    // the hot part of the model (512 B = two 16-byte pieces per lane), in flight together; the cold part stays in the device table
+    // (ModelCold) and the mass properties go straight into the registers of load_leg_const.  The table lives in global memory:
+    // global loads (address space 1), not FLAT
+    typedef const f4 __attribute__((address_space(1))) * g4ptr;
+    static_assert(sizeof(ModelHot) % (16 * kLanes) == 0 && alignof(DevModel) >= 16, "whole 16-byte rows of the hot model per lane");
+    const g4ptr mp = (g4ptr)reinterpret_cast<const f4*>(&gm.hot);
+    f4* dst = reinterpret_cast<f4*>(&S.m);
+    constexpr int kIter = (int)(sizeof(ModelHot) / 16) / kLanes;
+    f4 tmp[kIter];
 #pragma unroll
     for (int k = 0; k < kIter; k++) tmp[k] = mp[lane + k * kLanes];
 #pragma unroll
