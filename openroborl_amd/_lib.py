@@ -33,7 +33,10 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O2", "-fPIC", "-shared", "-std=c++17",
 # The second translation unit (orr_kernels_w2.hip = the step kernel compiled for two waves per SIMD, used for batches of more than
 # 4 x #SIMDs robots) keeps the compiler's DEFAULT scheduler: at 256 registers that variant spills, and the ILP schedule's long live
 # ranges cost it 8 % (8192 robots: 0.382 -> 0.352 ms), while the default scheduler costs the one-wave variant 9 % (tools/ab_variants.sh).
-HIPCC_FLAGS_W2 = [f for i, f in enumerate(HIPCC_FLAGS) if "amdgpu-sched-strategy" not in f and not (f == "-mllvm" and i + 1 < len(HIPCC_FLAGS) and "amdgpu-sched-strategy" in HIPCC_FLAGS[i + 1])]
+# -O3 instead of -O2: another 1.5 % for this unit (0.3554 -> 0.3500 ms; the schedule-metric bias, the AMDGPU pressure trackers and the
+# high-pressure reschedule stage make no difference, the SLP vectoriser costs 70 %).
+HIPCC_FLAGS_W2 = ["-O3" if f == "-O2" else f for i, f in enumerate(HIPCC_FLAGS)
+                  if "amdgpu-sched-strategy" not in f and not (f == "-mllvm" and i + 1 < len(HIPCC_FLAGS) and "amdgpu-sched-strategy" in HIPCC_FLAGS[i + 1])]
 
 EXPORTS = [
     "orr_last_error", "orr_abi_version", "orr_source_hash", "orr_state_stride", "orr_layout_count", "orr_layout_name",
