@@ -610,3 +610,41 @@ def test_non_finite_state_is_caught_by_the_state_guard(auto_reset):
     obs, rew, done, _ = env.step(a)
     assert torch.isfinite(obs).all() and torch.isfinite(rew).all() and not done.any()
     env.close()
+
+
+@pytest.mark.parametrize("robot,randomizer", [("laikago", True), ("mini_cheetah", False)])
+def test_two_waves_per_simd_variant_parity(robot, randomizer, monkeypatch):
+    """orr_step runs a second build of the step kernel (two waves per SIMD: <= 256 registers, its own translation unit and compiler
+    flags, csrc/orr_kernels_w2.hip) for batches of more than 4 x #SIMDs robots.  ORR_STEP_WAVES_PER_EU=2 forces it onto small batches:
+    the one-step parity test, the auto-reset test and a reset + 3-step run with a padding lane group, against the oracle.  (The whole
+    -m gpu suite also passes with the variable set; tests/test_gpu_scale.py runs the 8192-robot config through it by default.)"""
+    monkeypatch.setenv("ORR_STEP_WAVES_PER_EU", "2")
+    test_step_parity(robot, randomizer)
+    if robot == "laikago":
+        test_auto_reset_inside_step_matches_oracle()
+        test_robot_counts_that_do_not_fill_a_wavefront(5)
+        test_non_finite_state_is_caught_by_the_state_guard(True)
+
+
+def test_variant_selection_by_batch_size():
+    """4096 robots = 1024 waves = one per SIMD of an MI355X: the one-wave kernel; one robot more: the two-wave kernel.  Both give the same
+    physics: the first 4096 robots of a 4100-robot env (two-wave kernel) track a 4096-robot env (one-wave kernel) from the same seed to
+    float32 rounding over three steps (compiler flags differ between the two builds, so not bitwise)."""
+    import torch
+    from openroborl_amd.env import VecQuadrupedEnv
+    kw = dict(seed=4, robot="laikago", motion_file=CLIP["laikago"], mode="test", enable_randomizer=False, auto_reset=False)
+    a = VecQuadrupedEnv(num_robot=4096, **kw)
+    b = VecQuadrupedEnv(num_robot=4100, **kw)
+    oa, ob = a.reset(), b.reset()
+    assert torch.equal(oa, ob[:4096])                       # the reset kernel is the same build for both
+    act = (torch.randn(4100, 12, generator=torch.Generator().manual_seed(0)) * 0.1).to(a.device)
+    for _ in range(3):
+        oa, ra, da, _ = a.step(act[:4096].contiguous())
+        ob, rb, db, _ = b.step(act)
+    # two different builds of the same source ran (different scheduler, -O2 / -O3): with this compiler they come out BITWISE equal
+    # (floating-point contraction is decided before scheduling); the contract is only float32 closeness
+    print("VARIANTS bitwise_equal=%s" % bool(torch.equal(oa, ob[:4096]) and torch.equal(ra, rb[:4096])))
+    assert (ra - rb[:4096]).abs().median().item() < 1e-5
+    assert (oa[:, 84:] - ob[:4096, 84:]).abs().median().item() < 1e-5
+    assert (da == db[:4096]).float().mean().item() > 0.999
+    a.close(); b.close()
