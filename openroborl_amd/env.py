@@ -160,9 +160,13 @@ class VecQuadrupedEnv(object):
         self.ep_log = torch.zeros((max(int(ep_log_capacity), 1), 2), dtype=torch.float32, device=self.device)
         _lib.check(self.L.orr_bind(self.h, self.state.data_ptr(), self.counters.data_ptr(), self.ep_log.data_ptr(),
                                    int(ep_log_capacity)), self.L)
-        self.obs = torch.zeros((num_robot, _abi.OBS_DIM), dtype=torch.float32, device=self.device)
-        self.reward = torch.zeros(num_robot, dtype=torch.float32, device=self.device)
-        self.done = torch.zeros(num_robot, dtype=torch.uint8, device=self.device)
+        # the three outputs of a step are views into ONE device buffer [obs N x 160 f32 | reward N f32 | done N u8], so that a host-side
+        # consumer (LegacyListEnv) fetches them with a single copy
+        nb_obs, nb_rew = num_robot * _abi.OBS_DIM * 4, num_robot * 4
+        self._out = torch.zeros(nb_obs + nb_rew + num_robot, dtype=torch.uint8, device=self.device)
+        self.obs = self._out[:nb_obs].view(torch.float32).view(num_robot, _abi.OBS_DIM)
+        self.reward = self._out[nb_obs:nb_obs + nb_rew].view(torch.float32)
+        self.done = self._out[nb_obs + nb_rew:]
         self.observation_space = observation_space(self.clips)
         self.action_space = action_space()
         self._env_step_counter = 0
@@ -327,13 +331,32 @@ class LegacyListEnv(object):
         self.observation_space = env.observation_space
         self.action_space = env.action_space
         self._init_angles = [np.asarray(env.models[t]["init_motor_angles"], dtype=np.float64) for t in env.robot_type]
+        # host <-> device staging in pinned memory: one asynchronous upload (actions), one asynchronous download (obs | reward | done)
+        # and ONE synchronisation per step, instead of four blocking pageable copies
+        t = env.torch
+        n = env.num_robot
+        self._act_host = t.empty((n, _abi.NUM_MOTORS), dtype=t.float32).pin_memory()
+        self._act_dev = t.empty((n, _abi.NUM_MOTORS), dtype=t.float32, device=env.device)
+        self._out_host = t.empty(env._out.shape, dtype=t.uint8).pin_memory()
+        nb_obs, nb_rew = n * _abi.OBS_DIM * 4, n * 4
+        out_np = self._out_host.numpy()
+        self._obs_np = out_np[:nb_obs].view(np.float32).reshape(n, _abi.OBS_DIM)
+        self._rew_np = out_np[nb_obs:nb_obs + nb_rew].view(np.float32)
+        self._done_np = out_np[nb_obs + nb_rew:]
+
+    def _fetch(self):
+        """obs | reward | done of the last reset / step -> pinned host buffer (one copy, one sync)."""
+        t = self._env.torch
+        self._out_host.copy_(self._env._out, non_blocking=True)
+        t.cuda.current_stream(self._env.device).synchronize()
 
     def __getattr__(self, attr):           # wrapper_env.py:55-56
         return getattr(self._env, attr)
 
     def reset(self):
-        obs = self._env.reset().detach().cpu().numpy().astype(np.float64)
-        return [obs[i] for i in range(self.num_robot)]
+        self._env.reset()
+        self._fetch()
+        return list(self._obs_np.astype(np.float64))
 
     def step(self, action):
         t = self._env.torch
@@ -343,16 +366,19 @@ class LegacyListEnv(object):
             a = np.stack([np.asarray(action[i], dtype=np.float32) for i in range(self.num_robot)])
         if a.shape != (self.num_robot, _abi.NUM_MOTORS):
             a = np.stack([np.asarray(action[i], dtype=np.float32).reshape(_abi.NUM_MOTORS) for i in range(self.num_robot)])
-        obs, rew, done, _ = self._env.step(t.from_numpy(np.ascontiguousarray(a)).to(self._env.device))
-        if self._mutate:
+        self._act_host.numpy()[...] = a
+        self._act_dev.copy_(self._act_host, non_blocking=True)
+        self._env.step(self._act_dev)
+        if self._mutate:                   # minitaur.py:281 adds INIT_MOTOR_ANGLES to the caller's arrays in place (done while the GPU works)
             init = self._init_angles
             for i in range(self.num_robot):
                 ai = action[i]
                 if isinstance(ai, np.ndarray):
                     ai += init[i]
-        obs = obs.detach().cpu().numpy().astype(np.float64)
-        rew_list = rew.detach().cpu().numpy().astype(np.float64).tolist()
-        done_np = done.detach().cpu().numpy().astype(bool)
+        self._fetch()
+        obs = self._obs_np.astype(np.float64)
+        rew_list = self._rew_np.astype(np.float64).tolist()
+        done_np = self._done_np.astype(bool)
         ndone = int(done_np.sum())
         if ndone > 0:
             # wrapper_env.py:82-83: the curriculum counter advances by num_robot per step in which ANY robot finished
