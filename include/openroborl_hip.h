@@ -234,7 +234,10 @@ int32_t orr_reset(orr_handle* h, const uint8_t* mask_dev, float* obs_dev, void* 
 
 /* replaces WrapperEnv.step (wrapper_env.py:58-85): actions [N,12] policy outputs (already clipped to
  * +-2pi by the caller, imitation_runners.py:140-143; NOT modified, unlike minitaur.py:281);
- * obs [N,160], reward [N], done [N] (uint8). */
+ * obs [N,160], reward [N], done [N] (uint8).
+ * One launch.  The library holds two builds of the same kernel source and picks by batch size: up to 4 robots x #SIMDs of the device
+ * (4096 on an MI355X) one wave per SIMD, above that two waves per SIMD (identical results; the environment variable
+ * ORR_STEP_WAVES_PER_EU = 1 | 2, read by orr_create, forces one of them - measurements and tests only). */
 int32_t orr_step(orr_handle* h, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev,
                  void* stream);
 
