@@ -141,6 +141,7 @@ struct KParams {
   long long* counters;
   float* ep_log;
   int ep_log_cap;
+  int simds;           // SIMDs of the device: workgroup b belongs to dispatch round b / simds (two-waves-per-SIMD variant: priority alternation)
 };
 // The cold part of a robot type's model, as a GLOBAL-address-space pointer: loads through it are global_load instructions (a generic
 // pointer would make them FLAT loads, which also count on the LDS counter and serialise with every LDS access in between).

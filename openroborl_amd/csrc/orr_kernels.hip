@@ -183,7 +183,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
   RingCursor ring = {geti(S, O(RING_HEAD)), geti(S, O(RING_LEN))};
   OwnCoord X;
   load_own_coord(S, lane, X);
+#ifndef ORR_NO_PRIO_ALTERNATION
+  // Two waves per SIMD: VALU issue is arbitrated by priority, then AGE - the older wave of a SIMD runs nearly unimpeded, the younger on
+  // the leftover slots, and when the older one has finished the younger runs on alone at a lone wave's pace (half the SIMD idle).  The
+  // two waves of a SIMD come from consecutive dispatch rounds (workgroup b: round b / #SIMDs), so raising the priority of the even rounds
+  // in even sub-steps and of the odd rounds in odd sub-steps lets them take turns at being the favoured one and finish together.
+  // 8192 robots: 0.349 -> 0.331 ms (-5.3 %); turns of 2 or 4 sub-steps, or a second flip in the middle of a sub-step, are no better
+  // (0.332 / 0.332 / 0.335; tools/build_variants.py: -DORR_PRIO_SHIFT=n, -DORR_NO_PRIO_ALTERNATION).
+  const int prio_phase = WPE == 2 ? (int)((blockIdx.x / (unsigned)(P.simds > 0 ? P.simds : 1)) & 1u) : 0;
+#endif
   for (int sstep = 0; sstep < c.action_repeat; sstep++) {
+#ifndef ORR_NO_PRIO_ALTERNATION
+#ifndef ORR_PRIO_SHIFT
+#define ORR_PRIO_SHIFT 0      // favoured for 2^ORR_PRIO_SHIFT sub-steps at a time (measured: tools/ab_variants.sh)
+#endif
+    if (WPE == 2) { if (((sstep >> ORR_PRIO_SHIFT) ^ prio_phase) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+#endif
     if (kLanes != 16 && sstep > 0) ctrl_obs(P, rec, S, lane);
     {  // every lane (no divergent `if`: it would cost more than it skips); lanes 12..15 repeat motor 0 and store into dump slots
       const float lerp = (float)(sstep + 1) * inv_repeat;  // process_action (minitaur.py:438-460)
@@ -644,6 +659,7 @@ static KParams make_params(const orr_handle* h) {
   P.counters = h->counters;
   P.ep_log = h->ep_log;
   P.ep_log_cap = h->ep_log_cap;
+  P.simds = h->simds;
   return P;
 }
 
