@@ -18,6 +18,7 @@ boundary is the copy of the gathered buffer to the host in unpack_episode_stats.
 import os
 
 HEADER = 6
+_PINNED = {}      # pinned host staging buffers of unpack_episode_stats, by (shape, dtype)
 
 
 def init_from_env(backend=None):
@@ -94,7 +95,18 @@ def unpack_episode_stats(gathered, capacity):
     """Per-rank payloads -> (all_returns, all_lengths, total_timesteps, dropped); .sums = (n_episodes, sum_ret, sum_len)
     over every logged episode of every rank.  ONE device->host copy (the rollout boundary's only sync)."""
     import torch
-    host = torch.stack([g.reshape(-1) for g in gathered]).cpu()
+    dev = torch.stack([g.reshape(-1) for g in gathered]) if len(gathered) > 1 else gathered[0].reshape(1, -1)
+    if dev.is_cuda:
+        # one asynchronous copy into a cached pinned buffer + one stream synchronisation (a pageable .cpu() costs 2-3x as much, and this
+        # copy is the only host synchronisation of a rollout boundary)
+        key = (tuple(dev.shape), dev.dtype)
+        host = _PINNED.get(key)
+        if host is None:
+            host = _PINNED[key] = torch.empty(dev.shape, dtype=dev.dtype).pin_memory()
+        host.copy_(dev, non_blocking=True)
+        torch.cuda.current_stream(dev.device).synchronize()
+    else:
+        host = dev
     rets, lens, ts, dr, n, sr, sl = [], [], 0, 0, 0, 0.0, 0.0
     for buf in host:
         k = int(buf[0])
