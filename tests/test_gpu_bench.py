@@ -1,0 +1,57 @@
+"""The driver's contract with bench.py, on the GPU box: one JSON line with the fields the round records are built from (a short run:
+ORR_BENCH_WARMUP_FLOOR cuts the untimed floor, which is a measurement aid, not part of the contract)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*args, **env):
+    e = dict(os.environ, ORR_BENCH_WARMUP_FLOOR="50", **env)
+    e.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), capture_output=True, text=True, env=e, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_line_contract():
+    d = _run("--gpus", "1", "--steps", "6", "--warmup", "2", "--no-cpu-baseline")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["metric"].startswith("env steps/sec") and d["unit"] == "env steps/s" and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["robots_per_gpu"] == 4096
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "valu_issue"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert 0.15 < r["kernel_ms"] < 0.5                                   # 4096 robots: ~0.24 ms
+    assert abs(d["value"] - 4096 * 6 / (d["ms_per_step"] * 6e-3)) / d["value"] < 1e-6
+    vi = r["valu_issue"]
+    assert vi and 0.3 < vi["frac_of_lone_wave_ceiling"] < 1.0 and vi["waves_resident_per_simd"] == 1
+
+
+def test_bench_second_row_and_two_wave_config():
+    d = _run("--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-randomizer")
+    assert d["config"]["randomizer"] is False and d["config"]["control_latency_s"] == 0.002
+    assert d["roofline"]["alg_bytes_per_robot_step"] < 4000
+    d = _run("--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--config", "mixed8192")
+    assert d["config"]["robots_per_gpu"] == 8192
+    vi = d["roofline"]["valu_issue"]
+    assert vi is None or vi["waves_resident_per_simd"] == 2
+
+
+def test_bench_launches_its_own_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` with no launcher around it: the parent starts torch.distributed.run itself; on a one-GPU box the two ranks
+    share the device and talk gloo (a rehearsal of the launcher and the collective, never a measurement)."""
+    d = _run("--gpus", "2", "--steps", "4", "--warmup", "1", ORR_BENCH_SINGLE_DEVICE="1", ORR_DIST_BACKEND="gloo")
+    assert d["n_gpus"] == 2 and d["dist"]["world"] == 2 and d["dist"]["backend"] == "gloo" and "cpu_baseline" not in d
+    assert d["config"]["total_robots"] == 8192
