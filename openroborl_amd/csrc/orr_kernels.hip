@@ -137,8 +137,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     int fall = 0;
     OwnCoord X;
     load_own_coord(S, lane, X);
+    int limit_idle = 0;
     for (int s = 0; s < nsub; s++) {
-      fall = physics_substep(P, S, K, lane, sub, true, X);
+      fall = physics_substep(P, S, K, lane, sub, true, X, limit_idle);
       float rel[4], Rb[9];
       base_rotation(S, lane, rel, Rb);
       WSYNC();
@@ -183,6 +184,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
   RingCursor ring = {geti(S, O(RING_HEAD)), geti(S, O(RING_LEN))};
   OwnCoord X;
   load_own_coord(S, lane, X);
+  int limit_idle = 0;      // see physics_substep
 #ifndef ORR_NO_PRIO_ALTERNATION
   // Two waves per SIMD: VALU issue is arbitrated by priority, then AGE - the older wave of a SIMD runs nearly unimpeded, the younger on
   // the leftover slots, and when the older one has finished the younger runs on alone at a lone wave's pace (half the SIMD idle).  The
@@ -225,10 +227,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
         WSYNC();
         fall = RP.fall[robot];
       } else
-      fall = physics_substep(P, S, K, lane, sub, sstep == c.action_repeat - 1, X);
+      fall = physics_substep(P, S, K, lane, sub, sstep == c.action_repeat - 1, X, limit_idle);
       ring_push_and_ctrl_obs(rec, S, lane, valid, F, ring, (S.s[O(Q) + mj] - m_off) * m_dir);
     } else {
-      fall = physics_substep(P, S, K, lane, sub, sstep == c.action_repeat - 1, X);
+      fall = physics_substep(P, S, K, lane, sub, sstep == c.action_repeat - 1, X, limit_idle);
       receive_obs(P, rec, S, lane, valid);
     }
     PT(10);

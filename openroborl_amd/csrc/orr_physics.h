@@ -428,7 +428,7 @@ struct ContactGeom {
 // and its base Jacobian is the compile-time constant zero.
 template <int BANK>
 __device__ __forceinline__ void row_setup(const Shared& S, const orr_config& cfg, int slot, bool enable, float dt, float inv_dt,
-                                          float erp_dt, Row& R, ContactGeom& G) {
+                                          float erp_dt, Row& R, ContactGeom& G, float* limit_margin = nullptr) {
   if (BANK == 0) G = ContactGeom{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
   R.active = false; R.leg = 0; R.nrm_slot = -1; R.warm = -1;
 #pragma unroll
@@ -449,6 +449,7 @@ __device__ __forceinline__ void row_setup(const Shared& S, const orr_config& cfg
     const int kk = j - 3 * R.leg;
     const float a = S.m.jdir[j] * (S.s[O(Q) + j] - S.m.joff[j]);
     const float pen_lo = a - S.m.joint_lo[j], pen_hi = S.m.joint_hi[j] - a;
+    if (limit_margin) *limit_margin = fminf(pen_lo, pen_hi) - cfg.limit_activation;   // how far the joint is from getting a limit row
     const bool use_lo = pen_lo < cfg.limit_activation;
     const bool use_hi = (!use_lo) && pen_hi < cfg.limit_activation;
     R.active = use_lo || use_hi;
@@ -884,7 +885,12 @@ __device__ __forceinline__ void delassus_columns(const Shared& S, unsigned int m
 }
 
 // One physics sub-step.  Returns the fall-proxy flag (wave-uniform) when want_fall.
-__device__ static int physics_substep(const KParams& P, Shared& S, const LegConst& K, int lane, int sub, bool want_fall, OwnCoord& X) {
+// limit_idle (wave-uniform, kept by the caller across the sub-steps of a launch, 0 at its start): sub-steps for which NO joint of this
+// wave can get a joint-limit row.  A joint coordinate moves by at most max_coord_velocity * dt per sub-step (the velocity clamp of the
+// integration), so a joint that is m away from the activation distance of its nearer bound stays rowless for floor(m / that) sub-steps;
+// the bank-B row setup (12 lanes x ~25 instructions + ballots, every sub-step) is skipped for that long - exactly, not approximately.
+__device__ static int physics_substep(const KParams& P, Shared& S, const LegConst& K, int lane, int sub, bool want_fall, OwnCoord& X,
+                                      int& limit_idle) {
   const orr_config& cfg = P.cfg;
   const float dt = cfg.sim_dt, inv_dt = 1.0f / cfg.sim_dt, erp_dt = cfg.contact_erp / cfg.sim_dt;
   // termination-only collision proxies (imitation_task.py:536-546): read once per env step, at its last sub-step, from the device table
@@ -925,8 +931,27 @@ __device__ static int physics_substep(const KParams& P, Shared& S, const LegCons
   const bool rowlane = lane < 16;
   ContactGeom G, Gunused;
   row_setup<0>(S, cfg, rowlane ? (lane < 4 ? lane : lane + 12) : 0, rowlane, dt, inv_dt, erp_dt, A, G);
-  row_setup<1>(S, cfg, (rowlane && lane >= 4) ? lane : 4, rowlane && lane >= 4, dt, inv_dt, erp_dt, B, Gunused);
-  const unsigned long long balA = __ballot(A.active), balB = __ballot(B.active);
+  unsigned long long balB = 0ull;
+  if (limit_idle > 0) {
+    limit_idle--;
+    B = Row{};                  // never read: without an active joint-limit row in the wave the bank-B paths below are not taken
+    B.active = false;
+  } else {
+    float margin = 1e30f;
+    row_setup<1>(S, cfg, (rowlane && lane >= 4) ? lane : 4, rowlane && lane >= 4, dt, inv_dt, erp_dt, B, Gunused, &margin);
+    balB = __ballot(B.active);
+    // sub-steps that can be skipped from here: the minimum over the wave's joints of floor(margin / (vmax dt)) - 1 (one sub-step of
+    // slack against rounding), found with five ballots (powers of two up to 16 are enough: the check itself is cheap)
+    const float steps_f = (rowlane && lane >= 4) ? margin * __builtin_amdgcn_rcpf(cfg.max_coord_velocity * dt) - 1.0f : 1e30f;
+    int idle = 0;
+    if (__ballot(steps_f < 1.0f) == 0ull) idle = 1;
+    if (__ballot(steps_f < 2.0f) == 0ull) idle = 2;
+    if (__ballot(steps_f < 4.0f) == 0ull) idle = 4;
+    if (__ballot(steps_f < 8.0f) == 0ull) idle = 8;
+    if (__ballot(steps_f < 16.0f) == 0ull) idle = 16;
+    limit_idle = idle;
+  }
+  const unsigned long long balA = __ballot(A.active);
   const bool anyB = balB != 0ull;  // wave-uniform
   // union over the robots of this wave of the active slots (a slot visited for a robot where it is inactive is a no-op)
   unsigned int mask = 0;

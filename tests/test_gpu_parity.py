@@ -648,3 +648,56 @@ def test_variant_selection_by_batch_size():
     assert (oa[:, 84:] - ob[:4096, 84:]).abs().median().item() < 1e-5
     assert (da == db[:4096]).float().mean().item() > 0.999
     a.close(); b.close()
+
+
+def test_joint_limit_rows_appear_on_time_when_the_setup_is_skipped():
+    """The joint-limit bank's row setup is skipped for as many sub-steps as no joint of the wave can reach the activation distance of a bound
+    (a coordinate moves at most max_coord_velocity * dt per sub-step; csrc/orr_physics.h: limit_idle).  Airborne robots whose knees /
+    thighs / hips run towards a limit at up to 95 rad/s from 0.12 .. 1.5 rad away, 14 sub-steps in ONE launch (the skip counter lives
+    across the sub-steps of a launch) against the oracle: a row that came one sub-step late would let the joint run 0.1 rad through it."""
+    import torch
+    from tests.parity_inputs import substep_parity_inputs
+    n = 48
+    env, orc = make_pair("laikago", n=n)
+    env.reset(); orc.reset()
+    _, _, _, st, tau = substep_parity_inputs("laikago", n)
+    lay = env.layout
+    m = env.models[0]
+    rng = np.random.RandomState(12)
+    st[:, lay.sl("POS").start + 2] = 2.0                          # no ground contact
+    st[:, lay.sl("LINVEL")] = 0.0
+    st[:, lay.sl("ANGVEL")] = 0.0
+    st[:, lay.sl("KNEE_FRICTION")] = 0.0
+    q = np.tile((m["init_motor_angles"] + m["motor_offset"]) * m["motor_dir"], (n, 1))
+    qd = np.zeros((n, 12))
+    lo, hi = m["joint_lo"], m["joint_hi"]                        # limits of the kinematic angle = motor angle (joint axes +x / +y here)
+    for i in range(n):
+        j = rng.randint(12)
+        mot = list(m["joint_of_motor"]).index(j)
+        away = rng.choice([0.12, 0.2, 0.35, 0.5, 0.8, 1.2, 1.5])
+        side = rng.rand() < 0.5
+        room = hi[j] - lo[j]
+        away = min(away, 0.45 * room)
+        ang = (hi[j] - away) if side else (lo[j] + away)          # motor angle
+        speed = rng.uniform(40.0, 95.0) * (1.0 if side else -1.0)
+        q[i, j] = ang * m["motor_dir"][mot] + m["motor_offset"][mot]
+        qd[i, j] = speed * m["motor_dir"][mot]
+    st[:, lay.sl("Q")] = q
+    st[:, lay.sl("QD")] = qd
+    st = statemod.to_float64(lay, statemod.from_float64(lay, st))
+    push_state(env, st); orc.state[:] = st
+    tau0 = np.zeros((n, 12))
+    nsub = 14
+    env.debug_physics(torch.zeros(n, 12, device=env.device), nsub)
+    hit = np.zeros(n, dtype=bool)
+    for i in range(n):
+        for _ in range(nsub):
+            orc.L.orc_physics_substep(orc.h, ol.P(orc.state[i]), ol.P(np.ascontiguousarray(tau0[i])))
+    # the oracle's joints were stopped by their limits (they would have travelled 0.56 .. 1.3 rad otherwise)
+    moved = np.abs(orc.state[:, lay.sl("Q")] - q).max(axis=1)
+    assert (moved < 1.45).all() and (np.abs(orc.state[:, lay.sl("QD")]).max(axis=1) < 96.0).all()
+    g = gpu_state64(env)
+    dq = np.abs(g[:, lay.sl("Q")] - orc.state[:, lay.sl("Q")]).max(axis=1)
+    dv = np.abs(g[:, lay.sl("QD")] - orc.state[:, lay.sl("QD")]).max(axis=1)
+    assert dq.max() < 2e-3 and dv.max() < 0.2, (dq.max(), dv.max(), np.argmax(dq))      # a late row: 0.04 .. 0.1 rad
+    env.close(); orc.close()
