@@ -224,7 +224,7 @@ int32_t orr_set_model(orr_handle* h, int32_t robot_type, const orr_model* model_
 int32_t orr_set_motion(orr_handle* h, int32_t clip_id, const float* frames_dev, const float* frame_vels_dev,
                        int32_t num_frames, double frame_dt, int32_t clip_flags, const float cycle_delta[4]);
 
-/* bind caller-owned device buffers: state [N, ORR_STATE_STRIDE] words, counters int64[8],
+/* bind caller-owned device buffers: state [N, ORR_STATE_STRIDE] words (16-byte aligned), counters int64[8],
  * episode log float[ep_log_capacity][2] = (return, length) (may be NULL / 0). */
 int32_t orr_bind(orr_handle* h, void* state_dev, int64_t* counters_dev, float* ep_log_dev, int32_t ep_log_capacity);
 
@@ -234,7 +234,7 @@ int32_t orr_reset(orr_handle* h, const uint8_t* mask_dev, float* obs_dev, void* 
 
 /* replaces WrapperEnv.step (wrapper_env.py:58-85): actions [N,12] policy outputs (already clipped to
  * +-2pi by the caller, imitation_runners.py:140-143; NOT modified, unlike minitaur.py:281);
- * obs [N,160], reward [N], done [N] (uint8).
+ * obs [N,160] (16-byte aligned), reward [N], done [N] (uint8).
  * One launch.  The library holds two builds of the same kernel source and picks by batch size: up to 4 robots x #SIMDs of the device
  * (4096 on an MI355X) one wave per SIMD, above that two waves per SIMD (identical results; the environment variable
  * ORR_STEP_WAVES_PER_EU = 1 | 2, read by orr_create, forces one of them - measurements and tests only). */

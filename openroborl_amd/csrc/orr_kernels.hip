@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include <math.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -645,6 +646,7 @@ int32_t orr_set_motion(orr_handle* h, int32_t clip_id, const float* frames_dev, 
 
 int32_t orr_bind(orr_handle* h, void* state_dev, int64_t* counters_dev, float* ep_log_dev, int32_t ep_log_capacity) {
   if (!h || !state_dev || !counters_dev) return fail(-1, "orr_bind: null argument (state and counters are required)");
+  if (((uintptr_t)state_dev & 15u) != 0) return fail(-1, "orr_bind: the state buffer must be 16-byte aligned (records move in 16-byte pieces)");
   h->state = (float*)state_dev;
   h->counters = (long long*)counters_dev;
   h->ep_log = ep_log_dev;
@@ -676,6 +678,7 @@ int32_t orr_reset(orr_handle* h, const uint8_t* mask_dev, float* obs_dev, void* 
 int32_t orr_step(orr_handle* h, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev, void* stream) {
   if (!h || !h->state) return fail(-1, "orr_step: handle not bound");
   if (!actions_dev || !obs_dev || !reward_dev || !done_dev) return fail(-1, "orr_step: null buffer");
+  if (((uintptr_t)obs_dev & 15u) != 0) return fail(-1, "orr_step: the observation buffer must be 16-byte aligned (it is written in 16-byte pieces)");
   const int waves = (h->cfg.num_robots + kRPW - 1) / kRPW;
   const bool two = h->force_wpe ? h->force_wpe == 2 : waves > h->simds;
   if (two) {

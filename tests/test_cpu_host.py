@@ -195,3 +195,11 @@ def test_tuning_defines_are_part_of_the_source_hash(monkeypatch):
     assert _lib.source_hash() != base
     monkeypatch.delenv("ORR_WAVES_PER_EU")
     assert _lib.source_hash() == base and _lib.source_hash(("-DX",)) != base
+
+
+def test_null_handles_are_reported_not_dereferenced():
+    """Without a device no handle exists here: the NULL-handle paths of bind / step must report instead of crashing (the alignment
+    checks behind them need a real handle: tests/test_gpu_parity.py::test_misaligned_buffers_are_refused)."""
+    L = _lib.load()
+    assert L.orr_bind(None, C.c_void_p(16), C.c_void_p(16), None, 0) < 0 and b"orr_bind" in L.orr_last_error()
+    assert L.orr_step(None, None, None, None, None, None) < 0

@@ -701,3 +701,24 @@ def test_joint_limit_rows_appear_on_time_when_the_setup_is_skipped():
     dv = np.abs(g[:, lay.sl("QD")] - orc.state[:, lay.sl("QD")]).max(axis=1)
     assert dq.max() < 2e-3 and dv.max() < 0.2, (dq.max(), dv.max(), np.argmax(dq))      # a late row: 0.04 .. 0.1 rad
     env.close(); orc.close()
+
+
+def test_misaligned_buffers_are_refused():
+    """Records and observations move in 16-byte pieces on the device: a caller-owned state / observation buffer that is not 16-byte
+    aligned is refused by the C-ABI before anything is launched."""
+    import ctypes as C
+    import torch
+    env, orc = make_pair("laikago", n=8)
+    orc.close()
+    L = env.L
+    stream = C.c_void_p(torch.cuda.current_stream(env.device).cuda_stream)
+    act = torch.zeros(8, 12, device=env.device)
+    big = torch.zeros(8 * 160 + 4, dtype=torch.float32, device=env.device)
+    rc = L.orr_step(env.h, act.data_ptr(), big.data_ptr() + 4, env.reward.data_ptr(), env.done.data_ptr(), stream)
+    assert rc < 0 and b"16-byte aligned" in L.orr_last_error()
+    assert L.orr_step(env.h, act.data_ptr(), big.data_ptr(), env.reward.data_ptr(), env.done.data_ptr(), stream) == 0
+    st2 = torch.zeros(env.state.numel() + 4, dtype=torch.float32, device=env.device)
+    rc = L.orr_bind(env.h, st2.data_ptr() + 4, env.counters.data_ptr(), None, 0)
+    assert rc < 0 and b"16-byte aligned" in L.orr_last_error()
+    torch.cuda.synchronize()
+    env.close()
