@@ -521,7 +521,7 @@ __device__ __forceinline__ void joint_sincos(float a, float* sn, float* cs) {
 // branches each, 13-30 ticks apiece: profiles/r02_issue_costs.txt).  atan2: octant reduction to t = min / max in [0, 1], then the
 // Cephes atanf kernel on [0, tan(pi/8)] (t -> (t - 1) / (t + 1) above it); absolute error < 3e-7 (checked against float64 on 2 M
 // random arguments).  -DORR_LIBM_TRIG switches back to libm.
-// NaN arguments come out FINITE (fmax / fmin and the selects drop NaNs), and (y = 0, x = -0.0) gives 0 instead of pi: non-finite numbers
+// NaN arguments come out FINITE (fmax / fmin and the selects drop NaNs): non-finite numbers
 // are detected in ONE place, the |state| < 1e30 sweep + reward check at the end of the step (ORR_DONE_NAN, orr_kernels.hip), never through
 // these functions (tests/test_gpu_parity.py::test_non_finite_state_is_caught_by_the_state_guard).
 __device__ __forceinline__ float atan2_bf(float y, float x) {
@@ -540,8 +540,9 @@ __device__ __forceinline__ float atan2_bf(float y, float x) {
   float r = fmaf(p * z, u, u);
   r = big ? r + 0.78539816339744831f : r;
   r = ay > ax ? 1.57079632679489662f - r : r;
-  r = x < 0.0f ? 3.14159265358979324f - r : r;
-  return y < 0.0f ? -r : r;
+  // quadrant by the SIGN BITS, like libm: atan2(0, -0.0) = pi and atan2(-0.0, -1) = -pi (a comparison with 0.0f treats -0.0 as positive)
+  r = __float_as_int(x) < 0 ? 3.14159265358979324f - r : r;
+  return __float_as_int(y) < 0 ? -r : r;
 #endif
 }
 __device__ __forceinline__ float asin_bf(float x) {   // |x| <= 1
