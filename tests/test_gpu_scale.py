@@ -21,6 +21,9 @@ FULL = {
     "laikago4096": dict(robot="laikago", n=4096, mixed=None),
     "minicheetah4096": dict(robot="mini_cheetah", n=4096, mixed=None),
     "mixed8192": dict(robot=None, n=8192, mixed=["laikago", "mini_cheetah"]),
+    # four dispatch rounds of the two-waves-per-SIMD kernel (its priority alternation keys on the round), and a batch that does not
+    # fill the last wave
+    "laikago16386": dict(robot="laikago", n=16386, mixed=None),
 }
 
 
