@@ -362,6 +362,9 @@ def main():
                 break
             except Exception as e:       # noqa: BLE001
                 traffic, valu, issue = None, {"error": repr(e)}, None
+        # which build of the step kernel ran (orr_step: more waves than SIMDs -> the two-waves-per-SIMD variant; name as in the rocprofv3 trace)
+        forced_wpe = os.environ.get("ORR_STEP_WAVES_PER_EU", "")
+        kernel_wpe = int(forced_wpe) if forced_wpe in ("1", "2") else (2 if (n + 3) // 4 > 4 * torch.cuda.get_device_properties(dev).multi_processor_count else 1)
         out = {
             "metric": "env steps/sec at N parallel robots", "value": world * n * args.steps / elapsed, "unit": "env steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_internal": WARMUP_FLOOR,
@@ -383,11 +386,12 @@ def main():
             "dist": dist_info,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "orr_step_kernel<0>", "kernel_ms": kern_ms, "kernel_ms_back_to_back": kern_b2b_ms,
+                         "kernel": "orr_step_kernel<0, %d>" % kernel_wpe, "kernel_ms": kern_ms, "kernel_ms_back_to_back": kern_b2b_ms,
                          "alg_bytes_per_robot_step": b_alg, "alg_bytes_per_launch": b_alg * n,
                          "pmc": valu, "valu_issue": issue,
-                         "note": "instruction-issue-bound serial chain of a lone wave (33 x (leg dynamics + rows + 9 PGS sweeps)); HBM fraction is reported "
-                                 "because the north star asks for it, see DESIGN.md section 6"},
+                         "note": "instruction-issue-bound serial chain of %s (33 x (leg dynamics + rows + 9 PGS sweeps)); HBM fraction is reported "
+                                 "because the north star asks for it, see DESIGN.md section 6"
+                                 % ("a lone wave per SIMD" if kernel_wpe == 1 else "two co-resident waves per SIMD")},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(env)
