@@ -13,13 +13,14 @@ train semantics (domain randomiser on, 20->600 step curriculum, per-robot auto-r
 A "step" is one env.step() of all robots of a GPU = one launch of the fused HIP kernel = 33 physics sub-steps +
 observation + reward + termination (+ auto-reset) per robot.  Actions are the policy-free stress input of SURVEY.md
 section 8d: reference joint pose one control step ahead (taken from the observation), in motor space, plus
-N(0, 0.125^2) noise, generated on the device (one GEMM launch per step, inside the timed region).  N > 1: independent
+N(0, 0.125^2) noise, generated on the device (one elementwise launch per step for a robot whose motors are in joint order, else a
+(batched) GEMM; inside the timed region).  N > 1: independent
 shards, one process per GPU, and the rollout-boundary all_gather of episode returns (RCCL) every 256 steps and at the
 end of the timed region.
 
 Timing protocol.  Untimed: `warmup_internal` env steps (a floor that does not depend on --warmup: a fresh box needs
 ~2 s of work before its clocks and code objects are in steady state) + one rollout-boundary gather (its first call
-loads code objects) + the W steps of --warmup.  Timed: EXACTLY K steps incl. the action GEMMs and the gathers a real
+loads code objects) + the W steps of --warmup.  Timed: EXACTLY K steps incl. the action launches and the gathers a real
 rollout performs, bracketed by barrier + synchronize.  Every 8th timed launch of the step kernel (every launch when K <= 64) is
 additionally bracketed by HIP events on the launch stream; their mean is the roofline's kernel time.
 
@@ -231,10 +232,17 @@ def main():
     if nt > 1:
         noise_pool = noise_pool.permute(0, 2, 1, 3).contiguous()   # [64, nt, n/nt, 12]
 
+    # a robot type whose motors are in joint order (Laikago) needs no permutation: its matrix is diagonal and the action is ONE
+    # elementwise launch (addmm would first copy the noise into the output - a second launch of the same length as the GEMM itself)
+    diagonal = nt == 1 and bool((perm[0] == torch.diag(torch.diagonal(perm[0]))).all())
+    mdir_row = torch.diagonal(perm[0]).clone()
+
     def make_action(obs, k):
         # |reference pose - init + noise| stays far below the 2 pi action bound, so the runner's clip
         # (imitation_runners.py:140-143) is a no-op here and is left out
         tar = obs[:, 84 + 7:84 + 19]
+        if diagonal:
+            return torch.addcmul(noise_pool[k & 63].view(n, 12), tar, mdir_row)
         if nt == 1:
             return torch.addmm(noise_pool[k & 63].view(n, 12), tar, perm[0])
         tar_t = tar.view(n // nt, nt, 12).transpose(0, 1)                      # [nt, n/nt, 12], strided view
@@ -264,7 +272,7 @@ def main():
     gloo = world > 1 and torch.distributed.get_backend() == "gloo"
 
     def timed_region(k0):
-        """EXACTLY args.steps env steps (action GEMM + step kernel) + the rollout-boundary gathers, between barrier + synchronize
+        """EXACTLY args.steps env steps (action launch + step kernel) + the rollout-boundary gathers, between barrier + synchronize
         on both sides; returns the MAX over ranks of the elapsed time and rank-local details."""
         ev = {k: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for k in range(0, args.steps, ev_stride)}
         sync_all()
@@ -374,7 +382,7 @@ def main():
             "config": {"workload": workload % n, "name": args.config,
                        "robots_per_gpu": n, "total_robots": world * n, "substeps_per_step": 33, "solver_iters": 9,
                        "randomizer": not args.no_randomizer, "control_latency_s": "U(0, 0.04) per episode" if not args.no_randomizer else 0.002,
-                       "auto_reset": True, "actions": "reference pose + N(0,0.125^2), on device (one GEMM launch per step, timed)",
+                       "auto_reset": True, "actions": "reference pose + N(0,0.125^2), on device (%s per step, timed)" % ("one elementwise launch" if diagonal else "copy + (batched) GEMM launch"),
                        "launch": "eager", "collective": "all_gather of episode returns every %d steps and at the end" % ROLLOUT,
                        "episodes_gathered": n_eps},
             "timed_breakdown": {"kernel_ms_total": kern_total_ms, "gather_ms": 1e3 * gather_s,
@@ -382,7 +390,7 @@ def main():
                                 "kernel_launches_timed": n_ev,
                                 "note": "rank 0; kernel = mean HIP-event duration of the bracketed orr_step_kernel launches x steps; gather = host time "
                                         "from the last queued kernel's end to the end of each rollout-boundary gather; other = action "
-                                        "GEMMs, launch gaps, barriers"},
+                                        "launches, launch gaps, barriers"},
             "dist": dist_info,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
