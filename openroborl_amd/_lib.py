@@ -14,9 +14,11 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(PKG_DIR, "csrc", "orr_kernels.hip")
 SRC_W2 = os.path.join(PKG_DIR, "csrc", "orr_kernels_w2.hip")      # the two-waves-per-SIMD step kernel: its own translation unit + flags
 SRC_POLICY = os.path.join(PKG_DIR, "csrc", "orr_policy.hip")
-DEPS = [SRC, SRC_W2, SRC_POLICY] + [os.path.join(PKG_DIR, "csrc", h) for h in ("orr_device.h", "orr_robot_io.h", "orr_physics.h", "orr_task.h")] + [
+SRC_LEARNER = os.path.join(PKG_DIR, "csrc", "orr_learner.hip")    # the non-GEMM part of the PPO update (include/openroborl_learner.h)
+DEPS = [SRC, SRC_W2, SRC_POLICY, SRC_LEARNER] + [os.path.join(PKG_DIR, "csrc", h) for h in ("orr_device.h", "orr_robot_io.h", "orr_physics.h", "orr_task.h")] + [
         os.path.join(os.path.dirname(PKG_DIR), "include", "openroborl_hip.h"),
-        os.path.join(os.path.dirname(PKG_DIR), "include", "openroborl_policy.h")]
+        os.path.join(os.path.dirname(PKG_DIR), "include", "openroborl_policy.h"),
+        os.path.join(os.path.dirname(PKG_DIR), "include", "openroborl_learner.h")]
 LIB_PATH = os.path.join(PKG_DIR, "libopenroborl_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
@@ -44,6 +46,7 @@ EXPORTS = [
     "orr_create", "orr_destroy", "orr_set_seed", "orr_set_model", "orr_set_motion", "orr_bind", "orr_reset", "orr_step",
     "orr_episode_stats", "orr_time_steps", "orr_debug_physics", "orr_debug_replay_step", "orr_debug_replay_reset",
     "orr_policy_packed_size", "orr_policy_pack", "orr_policy_forward", "orr_gae", "orr_gae_flags",
+    "orr_learner_workspace_floats", "orr_ppo_head", "orr_relu_backward", "orr_head_backward", "orr_head_wgrad", "orr_adam_step",
 ]
 
 
@@ -125,15 +128,17 @@ def build(force=False, verbose=False, out_path=None, extra_flags=()):
             obj_env = os.path.join(PKG_DIR, "csrc", "orr_kernels%s.o" % tag)
             obj_w2 = os.path.join(PKG_DIR, "csrc", "orr_kernels_w2%s.o" % tag)
             obj_pol = os.path.join(PKG_DIR, "csrc", "orr_policy%s.o" % tag)
+            obj_lrn = os.path.join(PKG_DIR, "csrc", "orr_learner%s.o" % tag)
             tmp_so = out_path + tag + ".tmp"
             cmds = [[HIPCC] + flags + ["-o", obj_env, SRC],
                     [HIPCC] + flags_w2 + ["-o", obj_w2, SRC_W2],
                     # the policy forward pass (matrix cores) is its own translation unit with the compiler's default scheduling
                     [HIPCC, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-c", "-o", obj_pol, SRC_POLICY],
-                    [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp_so, obj_env, obj_w2, obj_pol]]
+                    [HIPCC, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-c", "-o", obj_lrn, SRC_LEARNER],
+                    [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp_so, obj_env, obj_w2, obj_pol, obj_lrn]]
             try:
                 procs = []
-                for cmd in cmds[:3]:            # the three compiles are independent: run them side by side
+                for cmd in cmds[:-1]:           # the compiles are independent: run them side by side
                     if verbose:
                         print(" ".join(cmd))
                     procs.append(subprocess.Popen(cmd))
@@ -141,11 +146,11 @@ def build(force=False, verbose=False, out_path=None, extra_flags=()):
                 if any(rcs):
                     raise subprocess.CalledProcessError(next(r for r in rcs if r), cmds[rcs.index(next(r for r in rcs if r))])
                 if verbose:
-                    print(" ".join(cmds[3]))
-                subprocess.check_call(cmds[3])
+                    print(" ".join(cmds[-1]))
+                subprocess.check_call(cmds[-1])
                 os.replace(tmp_so, out_path)
             finally:
-                for o in (obj_env, obj_w2, obj_pol, tmp_so):
+                for o in (obj_env, obj_w2, obj_pol, obj_lrn, tmp_so):
                     if os.path.exists(o):
                         os.remove(o)
         finally:
@@ -222,6 +227,19 @@ def load():
     L.orr_gae_flags.argtypes = [vp, vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_float, vp, vp, vp]
     L.orr_policy_forward.restype = C.c_int32
     L.orr_policy_forward.argtypes = [C.POINTER(_abi.OrrPolicyNet), vp, C.c_int32, vp, C.c_float, C.c_float, vp, vp, vp, vp, vp]
+    # include/openroborl_learner.h
+    L.orr_learner_workspace_floats.restype = C.c_int64
+    L.orr_learner_workspace_floats.argtypes = [C.c_int32, C.c_int32]
+    L.orr_ppo_head.restype = C.c_int32
+    L.orr_ppo_head.argtypes = [vp, vp, vp, C.c_int32, C.c_float, C.c_float, C.c_float, vp, vp, vp, vp, vp, vp, vp]
+    L.orr_relu_backward.restype = C.c_int32
+    L.orr_relu_backward.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, vp]
+    L.orr_head_backward.restype = C.c_int32
+    L.orr_head_backward.argtypes = [vp, C.c_int32, vp, vp, C.c_int32, C.c_int32, vp, vp, vp, vp]
+    L.orr_head_wgrad.restype = C.c_int32
+    L.orr_head_wgrad.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp]
+    L.orr_adam_step.restype = C.c_int32
+    L.orr_adam_step.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, vp, vp]
     if L.orr_abi_version() != _abi.ABI_VERSION:
         raise RuntimeError("libopenroborl_hip.so ABI version mismatch")
     if L.orr_sizeof_config() != C.sizeof(_abi.OrrConfig) or L.orr_sizeof_model() != C.sizeof(_abi.OrrModel):

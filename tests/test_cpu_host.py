@@ -69,7 +69,7 @@ def test_yaml_schema_and_config():
 
 def test_library_loads_and_exports_every_declared_symbol():
     L = _lib.load()
-    hdr = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("openroborl_hip.h", "openroborl_policy.h"))
+    hdr = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("openroborl_hip.h", "openroborl_policy.h", "openroborl_learner.h"))
     declared = set(re.findall(r"\b(orr_[a-z_]+)\s*\(", hdr))
     declared -= {"orr_handle"}
     assert declared, "no declarations found"
@@ -138,9 +138,9 @@ def test_motion_clip_validator():
 
 
 def test_headers_are_plain_c():
-    """The drop-in boundary is a C ABI: both headers must compile as C99 on their own."""
+    """The drop-in boundary is a C ABI: the headers must compile as C99 on their own."""
     import subprocess
-    for h in ("openroborl_hip.h", "openroborl_policy.h"):
+    for h in ("openroborl_hip.h", "openroborl_policy.h", "openroborl_learner.h"):
         subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", h)])
 
 
@@ -157,6 +157,27 @@ def test_policy_abi_argument_checks_without_gpu():
     assert b"orr_policy_forward" in L.orr_last_error()
     assert L.orr_gae(None, None, None, None, 4, 4, 0.95, 0.95, 1, 0.0, None, None, None) == -1
     assert b"orr_gae" in L.orr_last_error()
+
+
+def test_learner_abi_argument_checks_without_gpu():
+    """Host-side argument validation of include/openroborl_learner.h (no launch happens on these paths)."""
+    L = _lib.load()
+    assert L.orr_learner_workspace_floats(16384, 512) == 512 * 256 * 12       # 32 rows per workgroup; the head's weight gradient: [256][12] each
+    assert L.orr_learner_workspace_floats(64, 4) == 2 * 4 * 12
+    assert L.orr_learner_workspace_floats(0, 512) == -1
+    assert L.orr_ppo_head(None, None, None, 16, 0.125, 0.2, 1.0, None, None, None, None, None, None, None) == -1
+    assert b"orr_ppo_head" in L.orr_last_error()
+    assert L.orr_relu_backward(None, None, 16, 512, None, None, None) == -1
+    assert L.orr_relu_backward(16, 16, 16, 24, 16, 16, None) == -1            # 24 / 4 = 6 columns of four do not divide a workgroup
+    assert b"multiple of 4" in L.orr_last_error()
+    assert L.orr_head_backward(16, 3, 16, 16, 16, 256, 16, 16, 16, None) == -1
+    assert b"fan-out" in L.orr_last_error()
+    assert L.orr_head_wgrad(16, 16, 5, 16, 256, 16, 16, None) == -1
+    assert b"fan-out" in L.orr_last_error()
+    assert L.orr_adam_step(16, 16, 16, 16, 8, 1e-4, 0.9, 0.999, 1e-5, 1.0, 2, 16, None) == -1
+    assert b"unknown flag" in L.orr_last_error()
+    assert L.orr_adam_step(16, 16, 16, 20, 8, 1e-4, 0.9, 0.999, 1e-5, 1.0, 0, 16, None) == -1
+    assert b"aligned" in L.orr_last_error()
 
 
 def test_stale_library_is_rebuilt_and_the_new_build_is_what_gets_loaded(tmp_path):

@@ -30,6 +30,9 @@ def main():
     ap.add_argument("--log", default="")
     ap.add_argument("--save", default="", help="write the trained weights as a stable-baselines style zip")
     ap.add_argument("--torch-policy", action="store_true", help="rollout policy through plain torch instead of the fused HIP kernel")
+    ap.add_argument("--torch-learner", action="store_true",
+                    help="PPO update through autograd + torch.optim.Adam (ppo.PPO, the fp32 reference) instead of the hand-written backward "
+                         "replayed as a hipGraph (learner_hip.FusedPPO)")
     ap.add_argument("--eval", default="", help="evaluate a policy zip instead of training: deterministic actions, test mode "
                                                  "(no randomiser, full-length episodes), like `run.py --mode test`")
     ap.add_argument("--legacy-gae-index", action="store_true",
@@ -55,7 +58,11 @@ def main():
     model = ppo.ActorCritic(dev, params=params, seed=args.seed)                     # same seed -> identical replicas
     if not args.torch_policy:
         model.enable_fused()
-    learner = ppo.PPO(model, lr=args.lr, minibatch=args.minibatch)
+    if args.torch_learner:
+        learner = ppo.PPO(model, lr=args.lr, minibatch=args.minibatch)
+    else:
+        from openroborl_amd import learner_hip
+        learner = learner_hip.FusedPPO(model, lr=args.lr, minibatch=args.minibatch)
     gen = torch.Generator(device=dev)
     gen.manual_seed(args.seed * 1000 + rank)
     obs = env.reset()
