@@ -7,8 +7,9 @@
  * autograd graph spends around them - ~70 elementwise / reduction launches per minibatch, more time than the GEMMs themselves - is
  * these launches:
  *   orr_ppo_head       loss terms, d loss / d mean, d loss / d value, bias gradients of the two output layers
- *   orr_head_backward  gradient through an output layer (fan-out 12 or 1) + ReLU mask + bias gradient of the layer below
- *   orr_head_wgrad     weight gradient of an output layer
+ *   orr_head_backward  gradient through an output layer (fan-out 12 or 1) + ReLU mask + bias gradient of the layer below + the
+ *                      output layer's weight gradient
+ *   orr_colsum_finish  the column sums behind all bias gradients of a minibatch in one launch
  *   orr_relu_backward  ReLU mask in place + bias gradient
  *   orr_adam_step      Adam on the flat parameter vector, step counter on the device (the whole update replays as one hipGraph)
  * All pointers are device pointers, float32, row-major and 16-byte aligned; calls are asynchronous on the caller's stream; every
@@ -24,9 +25,12 @@
 extern "C" {
 #endif
 
-/* Floats of scratch the calls below need for a minibatch of m rows and layers of at most c columns (one buffer serves all calls
- * of a stream: they run one after the other). */
+/* Floats of scratch one call below needs for a minibatch of m rows and a layer of c columns.  Calls that finish their sums
+ * themselves (gb given) can share one buffer: they run one after the other on the stream.  Deferred calls (gb = NULL) leave their
+ * per-workgroup partial sums in the buffer for orr_colsum_finish and need one buffer each. */
 int64_t orr_learner_workspace_floats(int32_t m, int32_t c);
+/* Rows of partial sums a deferred call leaves for m samples. */
+int32_t orr_learner_partial_rows(int32_t m);
 
 #define ORR_PPO_BATCH_COLS 16
 /* Loss head for a minibatch of m samples (agents/ppo_imitation.py:196-214: ratio = exp(logp - old logp), surrogate
@@ -41,17 +45,27 @@ int32_t orr_ppo_head(const float* mean, const float* value, const float* batch, 
                      float* g_mean, float* g_value, float* gb_mean, float* gb_value, float* stats, float* workspace, void* stream);
 
 /* g [m][c] (gradient w.r.t. a ReLU layer's output h [m][c]) becomes the gradient w.r.t. its pre-activation, in place: g *= (h > 0);
- * gb [c] = its column sums (the layer's bias gradient).  c: a multiple of 4 with 1024 % c == 0. */
+ * gb [c] = its column sums (the layer's bias gradient).  c: a multiple of 4 with 1024 % c == 0.
+ * gb = NULL defers the sum: workspace then holds [orr_learner_partial_rows(m)][c] partial sums for orr_colsum_finish. */
 int32_t orr_relu_backward(float* g, const float* h, int32_t m, int32_t c, float* gb, float* workspace, void* stream);
 
-/* The same for the layer below an OUTPUT layer, whose gradient is formed on the fly instead of by a GEMM with fan-out k = 12 or 1:
- * gz [m][c] = (gy [m][k] . w [c][k]^T) * (h > 0),  gb [c] = column sums of gz.  w is the output layer's weight as stored ([c][k]). */
-int32_t orr_head_backward(const float* gy, int32_t k, const float* w, const float* h, int32_t m, int32_t c, float* gz, float* gb,
+/* The layer below an OUTPUT layer of fan-out k = 12 or 1 (w [c][k] as stored, gy [m][k] = d loss / d output): no GEMM with N = k.
+ *   gz [m][c] = (gy . w^T) * (h > 0)    gradient w.r.t. the pre-activation of the hidden layer h [m][c]
+ *   gb [c]    = column sums of gz       that layer's bias gradient
+ *   gw [c][k] = h^T . gy                the output layer's weight gradient
+ * gb = gw = NULL defers both sums: workspace holds [rows][c] partials of gb followed by [rows][c * k] partials of gw. */
+int32_t orr_head_backward(const float* gy, int32_t k, const float* w, const float* h, int32_t m, int32_t c, float* gz, float* gb, float* gw,
                           float* workspace, void* stream);
 
-/* Weight gradient of an output layer of fan-out k = 12 or 1: gw [c][k] = h [m][c]^T . gy [m][k] (a library GEMM with N = k and
- * K = m uses 1 % of the chip).  c <= 256 for the workspace size above. */
-int32_t orr_head_wgrad(const float* h, const float* gy, int32_t k, int32_t m, int32_t c, float* gw, float* workspace, void* stream);
+/* out [cols] = sum over `rows` rows of partials [rows][cols], for up to 8 jobs in one launch, in a fixed order. */
+#define ORR_COLSUM_MAX_JOBS 8
+typedef struct orr_colsum_job {
+  const float* partials;
+  float* out;
+  int32_t rows;
+  int32_t cols;
+} orr_colsum_job;
+int32_t orr_colsum_finish(const orr_colsum_job* jobs, int32_t n_jobs, void* stream);
 
 /* One Adam step on n parameters; t = state[0] + 1, the gradient is multiplied by grad_scale first (1 / world size after an
  * all-reduce sum: mpi_adam.py:51-53).

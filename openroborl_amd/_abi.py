@@ -113,3 +113,8 @@ class OrrPolicyNet(C.Structure):
     """include/openroborl_policy.h: orr_policy_net (packed weights + biases of the actor and the critic)."""
     _fields_ = [(n, C.c_void_p) for n in ("w0_pi", "b0_pi", "w1_pi", "b1_pi", "w2_pi", "b2_pi",
                                             "w0_vf", "b0_vf", "w1_vf", "b1_vf", "w2_vf", "b2_vf")]
+
+
+class OrrColsumJob(C.Structure):
+    """include/openroborl_learner.h: orr_colsum_job."""
+    _fields_ = [("partials", C.c_void_p), ("out", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32)]

@@ -46,7 +46,7 @@ EXPORTS = [
     "orr_create", "orr_destroy", "orr_set_seed", "orr_set_model", "orr_set_motion", "orr_bind", "orr_reset", "orr_step",
     "orr_episode_stats", "orr_time_steps", "orr_debug_physics", "orr_debug_replay_step", "orr_debug_replay_reset",
     "orr_policy_packed_size", "orr_policy_pack", "orr_policy_forward", "orr_gae", "orr_gae_flags",
-    "orr_learner_workspace_floats", "orr_ppo_head", "orr_relu_backward", "orr_head_backward", "orr_head_wgrad", "orr_adam_step",
+    "orr_learner_workspace_floats", "orr_ppo_head", "orr_relu_backward", "orr_head_backward", "orr_colsum_finish", "orr_learner_partial_rows", "orr_adam_step",
 ]
 
 
@@ -235,9 +235,11 @@ def load():
     L.orr_relu_backward.restype = C.c_int32
     L.orr_relu_backward.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, vp]
     L.orr_head_backward.restype = C.c_int32
-    L.orr_head_backward.argtypes = [vp, C.c_int32, vp, vp, C.c_int32, C.c_int32, vp, vp, vp, vp]
-    L.orr_head_wgrad.restype = C.c_int32
-    L.orr_head_wgrad.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp]
+    L.orr_head_backward.argtypes = [vp, C.c_int32, vp, vp, C.c_int32, C.c_int32, vp, vp, vp, vp, vp]
+    L.orr_learner_partial_rows.restype = C.c_int32
+    L.orr_learner_partial_rows.argtypes = [C.c_int32]
+    L.orr_colsum_finish.restype = C.c_int32
+    L.orr_colsum_finish.argtypes = [C.POINTER(_abi.OrrColsumJob), C.c_int32, vp]
     L.orr_adam_step.restype = C.c_int32
     L.orr_adam_step.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, vp, vp]
     if L.orr_abi_version() != _abi.ABI_VERSION:

@@ -98,20 +98,26 @@ __global__ __launch_bounds__(64) void ppo_head_finish_kernel(const float* __rest
 
 // ---- ReLU mask (+ the gradient through an output layer of fan-out K) + per-block column sums ------------------------------
 // A workgroup owns kRowsPerBlock rows and all c columns; a thread owns four adjacent columns (one 16-byte access per tensor and
-// row) of every (256 / (c/4))-th row.  K = 0: g holds the incoming gradient and is masked in place.
+// row) of every (256 / (c/4))-th row.  K = 0: g holds the incoming gradient and is masked in place.  K > 0 (the layer below an
+// output layer of fan-out K): the incoming gradient is gy . w^T formed on the fly, and since h and gy are in registers anyway the
+// output layer's weight gradient h^T gy is accumulated as well (a library GEMM with N = 12 or 1 and K = the batch runs at 1 % of
+// the chip: 100 us for 0.1 GFLOP) - wpart [block][c][K].
 template <int K>
 __global__ __launch_bounds__(kThreads) void relu_backward_kernel(float* __restrict__ g, const float* __restrict__ h, const float* __restrict__ gy,
-                                                                 const float* __restrict__ w, int M, int C, float* __restrict__ partials) {
+                                                                 const float* __restrict__ w, int M, int C, float* __restrict__ partials,
+                                                                 float* __restrict__ wpart) {
+  constexpr int KK = K > 0 ? K : 1;
   __shared__ f4 red[kThreads];
+  __shared__ float wred[K > 0 ? kThreads * 4 * KK : 1];
   const int c4n = C >> 2, side = kThreads / c4n;
   const int c4 = threadIdx.x % c4n, rsub = threadIdx.x / c4n;
   const int row0 = blockIdx.x * kRowsPerBlock;
-  float wr[4][K > 0 ? K : 1];
+  float wr[4][KK], gw[4][KK];
   if (K > 0) {
 #pragma unroll
     for (int q = 0; q < 4; q++)
 #pragma unroll
-      for (int k = 0; k < K; k++) wr[q][k] = w[(size_t)(4 * c4 + q) * K + k];
+      for (int k = 0; k < K; k++) { wr[q][k] = w[(size_t)(4 * c4 + q) * K + k]; gw[q][k] = 0.0f; }
   }
   f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll 4
@@ -122,7 +128,7 @@ __global__ __launch_bounds__(kThreads) void relu_backward_kernel(float* __restri
     const f4 hv = *reinterpret_cast<const f4*>(h + o);
     f4 gv;
     if (K > 0) {
-      float y[K > 0 ? K : 1];
+      float y[KK];
       if (K % 4 == 0) {
 #pragma unroll
         for (int k = 0; k < K / 4; k++) {
@@ -135,9 +141,12 @@ __global__ __launch_bounds__(kThreads) void relu_backward_kernel(float* __restri
       }
       float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-      for (int k = 0; k < K; k++)
+      for (int k = 0; k < K; k++) {
 #pragma unroll
         for (int q = 0; q < 4; q++) s[q] = fmaf(y[k], wr[q][k], s[q]);
+        gw[0][k] = fmaf(hv.x, y[k], gw[0][k]); gw[1][k] = fmaf(hv.y, y[k], gw[1][k]);
+        gw[2][k] = fmaf(hv.z, y[k], gw[2][k]); gw[3][k] = fmaf(hv.w, y[k], gw[3][k]);
+      }
       gv = f4{s[0], s[1], s[2], s[3]};
     } else {
       gv = *reinterpret_cast<const f4*>(g + o);
@@ -148,18 +157,42 @@ __global__ __launch_bounds__(kThreads) void relu_backward_kernel(float* __restri
     acc += gv;
   }
   red[threadIdx.x] = acc;
+  if (K > 0) {
+    // [rsub][q * K + k][c4]: consecutive lanes, consecutive words
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+      for (int k = 0; k < K; k++) wred[(rsub * 4 * KK + q * KK + k) * c4n + c4] = gw[q][k];
+  }
   __syncthreads();
   if (rsub == 0) {
     f4 t = red[c4];
     for (int s = 1; s < side; s++) t += red[s * c4n + c4];
     *reinterpret_cast<f4*>(partials + (size_t)blockIdx.x * C + 4 * c4) = t;
   }
+  if (K > 0) {
+    // every thread finishes 4 K / side of this workgroup's c x K sums; wpart[block][(4 c4 + q) * K + k]
+    float* o = wpart + (size_t)blockIdx.x * C * K;
+    for (int e = rsub; e < 4 * K; e += side) {
+      float t = wred[e * c4n + c4];
+      for (int s = 1; s < side; s++) t += wred[(s * 4 * KK + e) * c4n + c4];
+      o[(size_t)(4 * c4 + e / K) * K + (e % K)] = t;
+    }
+  }
 }
 
-// out[col] = sum over the nblk partial rows: 16 columns per workgroup x 16 interleaved row groups (a thread adds nblk / 16 values
-// through four independent accumulators), combined in a fixed order
-__global__ __launch_bounds__(kThreads) void colsum_finish_kernel(const float* __restrict__ partials, int nblk, int C, float* __restrict__ out) {
+// out[col] = sum over the nblk partial rows of a job: 16 columns per workgroup x 16 interleaved row groups (a thread adds
+// nblk / 16 values through four independent accumulators), combined in a fixed order.  Up to 8 jobs per launch (blockIdx.y).
+struct FinishJobs {
+  const float* partials[8];
+  float* out[8];
+  int nblk[8], cols[8];
+};
+__global__ __launch_bounds__(kThreads) void colsum_finish_kernel(FinishJobs J) {
   __shared__ float red[16][17];
+  const float* __restrict__ partials = J.partials[blockIdx.y];
+  const int nblk = J.nblk[blockIdx.y], C = J.cols[blockIdx.y];
+  if ((int)blockIdx.x * 16 >= C) return;
   const int lc = threadIdx.x & 15, part = threadIdx.x >> 4;
   const int col = blockIdx.x * 16 + lc;
   float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -177,51 +210,8 @@ __global__ __launch_bounds__(kThreads) void colsum_finish_kernel(const float* __
     float t = 0.0f;
 #pragma unroll
     for (int q = 0; q < 16; q++) t += red[q][lc];
-    out[col] = t;
+    J.out[blockIdx.y][col] = t;
   }
-}
-
-// ---- weight gradient of an output layer: out [c][K] = h^T gy for fan-out K = 12 or 1 ------------------------------------------
-// (a library GEMM with N = 12 or 1 and K = the batch runs at 1 % of the chip: 100 us for 0.1 GFLOP.)  One wavefront per workgroup
-// owns kRowsPerBlock rows and 256 columns; a lane owns four adjacent columns x K accumulators; per-block partials [c][K] as above.
-template <int K>
-__global__ __launch_bounds__(64) void head_wgrad_kernel(const float* __restrict__ h, const float* __restrict__ gy, int M, int C,
-                                                        float* __restrict__ partials) {
-  const int c4 = blockIdx.y * 64 + threadIdx.x;          // float4 column
-  if (4 * c4 >= C) return;
-  const int row0 = blockIdx.x * kRowsPerBlock;
-  float acc[4][K];
-#pragma unroll
-  for (int q = 0; q < 4; q++)
-#pragma unroll
-    for (int k = 0; k < K; k++) acc[q][k] = 0.0f;
-#pragma unroll 4
-  for (int r = 0; r < kRowsPerBlock; r++) {
-    const int i = row0 + r;
-    if (i >= M) break;
-    const f4 hv = *reinterpret_cast<const f4*>(h + (size_t)i * C + 4 * c4);
-    float y[K];
-    if (K % 4 == 0) {
-#pragma unroll
-      for (int k = 0; k < K / 4; k++) {
-        const f4 t = reinterpret_cast<const f4*>(gy + (size_t)i * K)[k];
-        y[4 * k] = t.x; y[4 * k + 1] = t.y; y[4 * k + 2] = t.z; y[4 * k + 3] = t.w;
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < K; k++) y[k] = gy[(size_t)i * K + k];
-    }
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-      acc[0][k] = fmaf(hv.x, y[k], acc[0][k]); acc[1][k] = fmaf(hv.y, y[k], acc[1][k]);
-      acc[2][k] = fmaf(hv.z, y[k], acc[2][k]); acc[3][k] = fmaf(hv.w, y[k], acc[3][k]);
-    }
-  }
-  float* o = partials + (size_t)blockIdx.x * C * K + (size_t)4 * c4 * K;      // [c][K] row-major: this lane's 4 K contiguous floats
-#pragma unroll
-  for (int q = 0; q < 4; q++)
-#pragma unroll
-    for (int k = 0; k < K; k++) o[q * K + k] = acc[q][k];
 }
 
 // ---- Adam on the flat parameter vector ----------------------------------------------------------------------------------------
@@ -265,8 +255,10 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 inline int nblocks_rows(int m) { return (m + kRowsPerBlock - 1) / kRowsPerBlock; }
 inline bool cols_ok(int c) { return c >= 4 && (c % 4) == 0 && (c / 4) <= kThreads && (kThreads % (c / 4)) == 0; }
 
-int finish_cols(const float* partials, int nblk, int c, float* gb, hipStream_t st, const char* who) {
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)((c + 15) / 16)), dim3(kThreads), 0, st, partials, nblk, c, gb);
+int launch_finish(const FinishJobs& J, int n_jobs, hipStream_t st, const char* who) {
+  int cmax = 0;
+  for (int j = 0; j < n_jobs; j++) cmax = J.cols[j] > cmax ? J.cols[j] : cmax;
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)((cmax + 15) / 16), (unsigned)n_jobs), dim3(kThreads), 0, st, J);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return orr_fail(-2, who, e);
   return 0;
@@ -276,12 +268,13 @@ int finish_cols(const float* partials, int nblk, int c, float* gb, hipStream_t s
 
 extern "C" {
 
+int32_t orr_learner_partial_rows(int32_t m) { return m > 0 ? nblocks_rows(m) : -1; }
+
 int64_t orr_learner_workspace_floats(int32_t m, int32_t c) {
   if (m <= 0 || c <= 0) return -1;
   const int64_t rows = nblocks_rows(m), head = (m + kThreads - 1) / kThreads;
-  const int64_t a = rows * (int64_t)c, b = head * kHeadCols, w = rows * (int64_t)(c < 256 ? c : 256) * kAct;   // orr_head_wgrad: c <= 256 there
-  const int64_t ab = a > b ? a : b;
-  return ab > w ? ab : w;
+  const int64_t a = rows * (int64_t)c * (1 + kAct), b = head * kHeadCols;     // orr_head_backward: [rows][c] + [rows][c][12]
+  return a > b ? a : b;
 }
 
 int32_t orr_ppo_head(const float* mean, const float* value, const float* batch, int32_t m, float std, float clip, float vf_coef,
@@ -302,49 +295,53 @@ int32_t orr_ppo_head(const float* mean, const float* value, const float* batch, 
 }
 
 int32_t orr_relu_backward(float* g, const float* h, int32_t m, int32_t c, float* gb, float* workspace, void* stream) {
-  if (!g || !h || !gb || !workspace || m <= 0) return orr_fail(-1, "orr_relu_backward: bad argument", hipSuccess);
+  if (!g || !h || !workspace || m <= 0) return orr_fail(-1, "orr_relu_backward: bad argument", hipSuccess);
   if (!cols_ok(c)) return orr_fail(-1, "orr_relu_backward: c must be a multiple of 4 that divides 1024", hipSuccess);
   if (!aligned16(g) || !aligned16(h) || !aligned16(workspace)) return orr_fail(-1, "orr_relu_backward: buffers must be 16-byte aligned", hipSuccess);
   const int nblk = nblocks_rows(m);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(relu_backward_kernel<0>, dim3((unsigned)nblk), dim3(kThreads), 0, st, g, h, (const float*)nullptr, (const float*)nullptr, (int)m,
-                     (int)c, workspace);
+                     (int)c, workspace, (float*)nullptr);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return orr_fail(-2, "orr_relu_backward: launch", e);
-  return finish_cols(workspace, nblk, c, gb, st, "orr_relu_backward: launch");
+  if (!gb) return 0;                                 // deferred: the caller sums workspace [rows][c] with orr_colsum_finish
+  FinishJobs J{};
+  J.partials[0] = workspace; J.out[0] = gb; J.nblk[0] = nblk; J.cols[0] = c;
+  return launch_finish(J, 1, st, "orr_relu_backward: launch");
 }
 
-int32_t orr_head_backward(const float* gy, int32_t k, const float* w, const float* h, int32_t m, int32_t c, float* gz, float* gb,
+int32_t orr_head_backward(const float* gy, int32_t k, const float* w, const float* h, int32_t m, int32_t c, float* gz, float* gb, float* gw,
                           float* workspace, void* stream) {
-  if (!gy || !w || !h || !gz || !gb || !workspace || m <= 0) return orr_fail(-1, "orr_head_backward: bad argument", hipSuccess);
+  if (!gy || !w || !h || !gz || !workspace || m <= 0) return orr_fail(-1, "orr_head_backward: bad argument", hipSuccess);
   if (k != 12 && k != 1) return orr_fail(-1, "orr_head_backward: fan-out must be 12 or 1", hipSuccess);
   if (!cols_ok(c)) return orr_fail(-1, "orr_head_backward: c must be a multiple of 4 that divides 1024", hipSuccess);
+  if ((gb == nullptr) != (gw == nullptr)) return orr_fail(-1, "orr_head_backward: gb and gw must both be given or both be deferred", hipSuccess);
   if (!aligned16(gy) || !aligned16(h) || !aligned16(gz) || !aligned16(workspace))
     return orr_fail(-1, "orr_head_backward: buffers must be 16-byte aligned", hipSuccess);
   const int nblk = nblocks_rows(m);
   hipStream_t st = (hipStream_t)stream;
+  float* wpart = workspace + (size_t)nblk * c;
   if (k == 12)
-    hipLaunchKernelGGL(relu_backward_kernel<12>, dim3((unsigned)nblk), dim3(kThreads), 0, st, gz, h, gy, w, (int)m, (int)c, workspace);
+    hipLaunchKernelGGL(relu_backward_kernel<12>, dim3((unsigned)nblk), dim3(kThreads), 0, st, gz, h, gy, w, (int)m, (int)c, workspace, wpart);
   else
-    hipLaunchKernelGGL(relu_backward_kernel<1>, dim3((unsigned)nblk), dim3(kThreads), 0, st, gz, h, gy, w, (int)m, (int)c, workspace);
+    hipLaunchKernelGGL(relu_backward_kernel<1>, dim3((unsigned)nblk), dim3(kThreads), 0, st, gz, h, gy, w, (int)m, (int)c, workspace, wpart);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return orr_fail(-2, "orr_head_backward: launch", e);
-  return finish_cols(workspace, nblk, c, gb, st, "orr_head_backward: launch");
+  if (!gb) return 0;                                 // deferred: workspace [rows][c] then [rows][c * k]
+  FinishJobs J{};
+  J.partials[0] = workspace; J.out[0] = gb; J.nblk[0] = nblk; J.cols[0] = c;
+  J.partials[1] = wpart; J.out[1] = gw; J.nblk[1] = nblk; J.cols[1] = c * k;
+  return launch_finish(J, 2, st, "orr_head_backward: launch");
 }
 
-int32_t orr_head_wgrad(const float* h, const float* gy, int32_t k, int32_t m, int32_t c, float* gw, float* workspace, void* stream) {
-  if (!h || !gy || !gw || !workspace || m <= 0) return orr_fail(-1, "orr_head_wgrad: bad argument", hipSuccess);
-  if (k != 12 && k != 1) return orr_fail(-1, "orr_head_wgrad: fan-out must be 12 or 1", hipSuccess);
-  if (c < 4 || (c % 4) != 0) return orr_fail(-1, "orr_head_wgrad: c must be a multiple of 4", hipSuccess);
-  if (!aligned16(h) || !aligned16(gy) || !aligned16(workspace)) return orr_fail(-1, "orr_head_wgrad: buffers must be 16-byte aligned", hipSuccess);
-  const int nblk = nblocks_rows(m);
-  hipStream_t st = (hipStream_t)stream;
-  const dim3 grid((unsigned)nblk, (unsigned)((c / 4 + 63) / 64));
-  if (k == 12) hipLaunchKernelGGL(head_wgrad_kernel<12>, grid, dim3(64), 0, st, h, gy, (int)m, (int)c, workspace);
-  else hipLaunchKernelGGL(head_wgrad_kernel<1>, grid, dim3(64), 0, st, h, gy, (int)m, (int)c, workspace);
-  const hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return orr_fail(-2, "orr_head_wgrad: launch", e);
-  return finish_cols(workspace, nblk, c * k, gw, st, "orr_head_wgrad: launch");
+int32_t orr_colsum_finish(const orr_colsum_job* jobs, int32_t n_jobs, void* stream) {
+  if (!jobs || n_jobs < 1 || n_jobs > ORR_COLSUM_MAX_JOBS) return orr_fail(-1, "orr_colsum_finish: 1 to 8 jobs", hipSuccess);
+  FinishJobs J{};
+  for (int j = 0; j < n_jobs; j++) {
+    if (!jobs[j].partials || !jobs[j].out || jobs[j].rows < 1 || jobs[j].cols < 1) return orr_fail(-1, "orr_colsum_finish: bad job", hipSuccess);
+    J.partials[j] = jobs[j].partials; J.out[j] = jobs[j].out; J.nblk[j] = jobs[j].rows; J.cols[j] = jobs[j].cols;
+  }
+  return launch_finish(J, n_jobs, (hipStream_t)stream, "orr_colsum_finish: launch");
 }
 
 int32_t orr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,

@@ -15,7 +15,7 @@ There is no fallback: without a GPU and the HIP library the constructor raises.
 """
 import ctypes as C
 
-from . import _lib
+from . import _abi, _lib
 
 NETS = ("pi", "vf")
 
@@ -97,10 +97,21 @@ class FusedPPO(object):
              "x": f(M, 160), "batch": f(M, 16), "gz2": f(M, 256), "gh1": f(M, 512), "g_pi": f(M, 12), "g_vf": f(M),
              "part1": f(16, 512, 256) if split else None, "part0": f(16, 160, 512) if split else None,
              "stats": t.zeros(B // M, 2, dtype=t.float32, device=self.dev),
-             "ws": f(int(self.L.orr_learner_workspace_floats(M, 512))), "graphs": None}
+             "ws": f(int(self.L.orr_learner_workspace_floats(M, 16))), "graphs": None}
         P["aux"].zero_()
-        for net, k in (("pi", 12), ("vf", 1)):
+        # the column sums behind the six bias gradients and the two output-layer weight gradients of a minibatch are deferred: each
+        # producer leaves its per-workgroup partial sums in its own buffer and ONE launch adds them all up (orr_colsum_finish)
+        rows = int(self.L.orr_learner_partial_rows(M))
+        jobs = (_abi.OrrColsumJob * 6)()
+        for i, (net, k) in enumerate((("pi", 12), ("vf", 1))):
             P["h1_" + net], P["h2_" + net], P["y_" + net] = f(M, 512), f(M, 256), f(M, k)
+            P["ws2_" + net] = f(int(self.L.orr_learner_workspace_floats(M, 256)))      # [rows][256] | [rows][256 * 12]
+            P["ws1_" + net] = f(rows * 512)
+            for j, (buf, off, out, cols) in enumerate(((P["ws2_" + net], 0, self.g["model/%s_fc1/b:0" % net], 256),
+                                                       (P["ws2_" + net], rows * 256, self.g["model/%s/w:0" % net], 256 * k),
+                                                       (P["ws1_" + net], 0, self.g["model/%s_fc0/b:0" % net], 512))):
+                jobs[3 * i + j] = _abi.OrrColsumJob(buf.data_ptr() + 4 * off, out.data_ptr(), rows, cols)
+        P["jobs"] = jobs
         self._plans[key] = P
         return P
 
@@ -121,13 +132,13 @@ class FusedPPO(object):
                                   g["model/vf/b:0"].data_ptr(), P["stats"][s].data_ptr(), ws, st), L)
         for net, k, gy in (("pi", 12, P["g_pi"]), ("vf", 1, P["g_vf"])):
             h1, h2 = P["h1_" + net], P["h2_" + net]
-            _lib.check(L.orr_head_wgrad(h2.data_ptr(), gy.data_ptr(), k, M, 256, g["model/%s/w:0" % net].data_ptr(), ws, st), L)
             _lib.check(L.orr_head_backward(gy.data_ptr(), k, w["model/%s/w:0" % net].data_ptr(), h2.data_ptr(), M, 256, P["gz2"].data_ptr(),
-                                           g["model/%s_fc1/b:0" % net].data_ptr(), ws, st), L)
+                                           None, None, P["ws2_" + net].data_ptr(), st), L)
             self._wgrad(h1, P["gz2"], P["part1"], g["model/%s_fc1/w:0" % net])
             t.mm(P["gz2"], w["model/%s_fc1/w:0" % net].t(), out=P["gh1"])
-            _lib.check(L.orr_relu_backward(P["gh1"].data_ptr(), h1.data_ptr(), M, 512, g["model/%s_fc0/b:0" % net].data_ptr(), ws, st), L)
+            _lib.check(L.orr_relu_backward(P["gh1"].data_ptr(), h1.data_ptr(), M, 512, None, P["ws1_" + net].data_ptr(), st), L)
             self._wgrad(x, P["gh1"], P["part0"], g["model/%s_fc0/w:0" % net])
+        _lib.check(L.orr_colsum_finish(P["jobs"], 6, st), L)
 
     def _allreduce(self):
         import torch.distributed as dist

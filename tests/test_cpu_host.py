@@ -162,18 +162,24 @@ def test_policy_abi_argument_checks_without_gpu():
 def test_learner_abi_argument_checks_without_gpu():
     """Host-side argument validation of include/openroborl_learner.h (no launch happens on these paths)."""
     L = _lib.load()
-    assert L.orr_learner_workspace_floats(16384, 512) == 512 * 256 * 12       # 32 rows per workgroup; the head's weight gradient: [256][12] each
-    assert L.orr_learner_workspace_floats(64, 4) == 2 * 4 * 12
+    assert L.orr_learner_workspace_floats(16384, 256) == 512 * 256 * 13       # 32 rows per workgroup: [rows][c] bias + [rows][c][12] weight partials
+    assert L.orr_learner_workspace_floats(64, 4) == 2 * 4 * 13
+    assert L.orr_learner_partial_rows(16384) == 512 and L.orr_learner_partial_rows(33) == 2 and L.orr_learner_partial_rows(0) == -1
     assert L.orr_learner_workspace_floats(0, 512) == -1
     assert L.orr_ppo_head(None, None, None, 16, 0.125, 0.2, 1.0, None, None, None, None, None, None, None) == -1
     assert b"orr_ppo_head" in L.orr_last_error()
     assert L.orr_relu_backward(None, None, 16, 512, None, None, None) == -1
     assert L.orr_relu_backward(16, 16, 16, 24, 16, 16, None) == -1            # 24 / 4 = 6 columns of four do not divide a workgroup
     assert b"multiple of 4" in L.orr_last_error()
-    assert L.orr_head_backward(16, 3, 16, 16, 16, 256, 16, 16, 16, None) == -1
+    assert L.orr_head_backward(16, 3, 16, 16, 16, 256, 16, 16, 16, 16, None) == -1
     assert b"fan-out" in L.orr_last_error()
-    assert L.orr_head_wgrad(16, 16, 5, 16, 256, 16, 16, None) == -1
-    assert b"fan-out" in L.orr_last_error()
+    assert L.orr_head_backward(16, 12, 16, 16, 16, 256, 16, 16, None, 16, None) == -1
+    assert b"both" in L.orr_last_error()
+    assert L.orr_colsum_finish(None, 1, None) == -1
+    jobs = (_abi.OrrColsumJob * 9)()
+    assert L.orr_colsum_finish(jobs, 9, None) == -1
+    assert L.orr_colsum_finish(jobs, 1, None) == -1                           # a job with null pointers
+    assert b"bad job" in L.orr_last_error()
     assert L.orr_adam_step(16, 16, 16, 16, 8, 1e-4, 0.9, 0.999, 1e-5, 1.0, 2, 16, None) == -1
     assert b"unknown flag" in L.orr_last_error()
     assert L.orr_adam_step(16, 16, 16, 20, 8, 1e-4, 0.9, 0.999, 1e-5, 1.0, 0, 16, None) == -1

@@ -186,10 +186,11 @@ def test_relu_backward_kernel_matches_torch(m, c):
     assert torch.equal(gb, gb2)
 
 
-@pytest.mark.parametrize("m,k", [(16384, 12), (16384, 1), (999, 12), (999, 1)])
+@pytest.mark.parametrize("m,k", [(16384, 12), (16384, 1), (999, 12), (31, 1)])
 def test_head_backward_kernel_matches_torch(m, k):
+    import ctypes as C
     import torch
-    from openroborl_amd import _lib
+    from openroborl_amd import _abi, _lib
     L = _lib.load()
     dev = torch.device("cuda:0")
     c = 256
@@ -198,29 +199,22 @@ def test_head_backward_kernel_matches_torch(m, k):
     w = torch.randn(c, k, device=dev, generator=g)
     h = torch.relu(torch.randn(m, c, device=dev, generator=g))
     want = (gy.double() @ w.double().t()) * (h > 0).double()
-    gz, gb = torch.empty(m, c, device=dev), torch.empty(c, device=dev)
+    want_gw = h.double().t() @ gy.double()
+    gz, gb, gw = torch.empty(m, c, device=dev), torch.empty(c, device=dev), torch.empty(c, k, device=dev)
     ws = torch.empty(int(L.orr_learner_workspace_floats(m, c)), device=dev)
-    _lib.check(L.orr_head_backward(_ptr(gy), k, _ptr(w), _ptr(h), m, c, _ptr(gz), _ptr(gb), _ptr(ws), _stream(dev)), L)
+    _lib.check(L.orr_head_backward(_ptr(gy), k, _ptr(w), _ptr(h), m, c, _ptr(gz), _ptr(gb), _ptr(gw), _ptr(ws), _stream(dev)), L)
     assert (gz.double() - want).abs().max().item() < 1e-5
     assert bool((gz[h == 0] == 0).all())
     assert (gb.double() - want.sum(dim=0)).abs().max().item() < 1e-5 * math.sqrt(m) * math.sqrt(k)
-
-
-@pytest.mark.parametrize("m,k", [(16384, 12), (16384, 1), (999, 12), (31, 1)])
-def test_head_wgrad_kernel_matches_torch(m, k):
-    import torch
-    from openroborl_amd import _lib
-    L = _lib.load()
-    dev = torch.device("cuda:0")
-    c = 256
-    g = torch.Generator(device=dev).manual_seed(m * 3 + k)
-    h = torch.relu(torch.randn(m, c, device=dev, generator=g))
-    gy = torch.randn(m, k, device=dev, generator=g)
-    gw = torch.empty(c, k, device=dev)
-    ws = torch.empty(int(L.orr_learner_workspace_floats(m, c)), device=dev)
-    _lib.check(L.orr_head_wgrad(_ptr(h), _ptr(gy), k, m, c, _ptr(gw), _ptr(ws), _stream(dev)), L)
-    want = h.double().t() @ gy.double()
-    assert (gw.double() - want).abs().max().item() < 2e-5 * math.sqrt(m)
+    assert (gw.double() - want_gw).abs().max().item() < 2e-5 * math.sqrt(m)
+    # deferred: the same sums through orr_colsum_finish, bit for bit
+    rows = int(L.orr_learner_partial_rows(m))
+    gz2, gb2, gw2 = torch.empty_like(gz), torch.empty_like(gb), torch.empty_like(gw)
+    ws2 = torch.empty_like(ws)
+    _lib.check(L.orr_head_backward(_ptr(gy), k, _ptr(w), _ptr(h), m, c, _ptr(gz2), None, None, _ptr(ws2), _stream(dev)), L)
+    jobs = (_abi.OrrColsumJob * 2)(_abi.OrrColsumJob(_ptr(ws2), _ptr(gb2), rows, c), _abi.OrrColsumJob(_ptr(ws2) + 4 * rows * c, _ptr(gw2), rows, c * k))
+    _lib.check(L.orr_colsum_finish(jobs, 2, _stream(dev)), L)
+    assert torch.equal(gz, gz2) and torch.equal(gb, gb2) and torch.equal(gw, gw2)
 
 
 @pytest.mark.parametrize("n", [434701, 8, 3])
