@@ -57,8 +57,9 @@ int32_t orr_relu_backward(float* g, const float* h, int32_t m, int32_t c, float*
 int32_t orr_head_backward(const float* gy, int32_t k, const float* w, const float* h, int32_t m, int32_t c, float* gz, float* gb, float* gw,
                           float* workspace, void* stream);
 
-/* out [cols] = sum over `rows` rows of partials [rows][cols], for up to 8 jobs in one launch, in a fixed order. */
-#define ORR_COLSUM_MAX_JOBS 8
+/* out [cols] = sum over `rows` rows of partials [rows][cols], for up to 12 jobs in one launch, in a fixed order (e.g. the six bias
+ * gradients, the two output-layer weight gradients and the four split weight gradients of a minibatch). */
+#define ORR_COLSUM_MAX_JOBS 12
 typedef struct orr_colsum_job {
   const float* partials;
   float* out;

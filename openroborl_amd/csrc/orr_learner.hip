@@ -182,19 +182,32 @@ __global__ __launch_bounds__(kThreads) void relu_backward_kernel(float* __restri
 }
 
 // out[col] = sum over the nblk partial rows of a job: 16 columns per workgroup x 16 interleaved row groups (a thread adds
-// nblk / 16 values through four independent accumulators), combined in a fixed order.  Up to 8 jobs per launch (blockIdx.y).
+// nblk / 16 values through four independent accumulators), combined in a fixed order.  Up to 12 jobs per launch; a workgroup finds
+// its job in the prefix table of workgroup counts.
+constexpr int kMaxJobs = ORR_COLSUM_MAX_JOBS;
+constexpr int kFewRows = 16;
 struct FinishJobs {
-  const float* partials[8];
-  float* out[8];
-  int nblk[8], cols[8];
+  const float* partials[kMaxJobs];
+  float* out[kMaxJobs];
+  int nblk[kMaxJobs], cols[kMaxJobs], first[kMaxJobs + 1];
 };
-__global__ __launch_bounds__(kThreads) void colsum_finish_kernel(FinishJobs J) {
+__global__ __launch_bounds__(kThreads) void colsum_finish_kernel(FinishJobs J, int n_jobs) {
   __shared__ float red[16][17];
-  const float* __restrict__ partials = J.partials[blockIdx.y];
-  const int nblk = J.nblk[blockIdx.y], C = J.cols[blockIdx.y];
-  if ((int)blockIdx.x * 16 >= C) return;
+  int job = 0;
+  while (job + 1 < n_jobs && (int)blockIdx.x >= J.first[job + 1]) job++;
+  const float* __restrict__ partials = J.partials[job];
+  const int nblk = J.nblk[job], C = J.cols[job];
+  if (nblk <= kFewRows) {      // few rows of many columns (the 16 partial products of a split weight gradient): a thread per column
+    const int col = ((int)blockIdx.x - J.first[job]) * kThreads + threadIdx.x;
+    if (col >= C) return;
+    float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 4
+    for (int b = 0; b < nblk; b++) s[b & 3] += partials[(size_t)b * C + col];
+    J.out[job][col] = (s[0] + s[1]) + (s[2] + s[3]);
+    return;
+  }
   const int lc = threadIdx.x & 15, part = threadIdx.x >> 4;
-  const int col = blockIdx.x * 16 + lc;
+  const int col = ((int)blockIdx.x - J.first[job]) * 16 + lc;
   float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   if (col < C) {
     int b = part;
@@ -210,13 +223,14 @@ __global__ __launch_bounds__(kThreads) void colsum_finish_kernel(FinishJobs J) {
     float t = 0.0f;
 #pragma unroll
     for (int q = 0; q < 16; q++) t += red[q][lc];
-    J.out[blockIdx.y][col] = t;
+    J.out[job][col] = t;
   }
 }
 
 // ---- Adam on the flat parameter vector ----------------------------------------------------------------------------------------
 // Every workgroup reads the step count when it starts; the LAST one to finish (ticket) advances it, so a captured launch replays.
-__global__ __launch_bounds__(kThreads) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+constexpr int kAdamThreads = 64;     // 434 k parameters = 1700 one-wave workgroups: enough of them in flight to cover the load latency
+__global__ __launch_bounds__(kAdamThreads) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, long long n, float lr, float b1, float b2, float eps, float gscale,
                                                         int flags, int* __restrict__ state) {
   const int t = __atomic_load_n(&state[0], __ATOMIC_RELAXED) + 1;
@@ -224,7 +238,7 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(float* __restrict__ p, c
   const float sq2 = sqrtf(bc2);
   const float step = (flags & ORR_ADAM_MPI_EPSILON) ? lr * sq2 / bc1 : lr / bc1;
   const float vs = (flags & ORR_ADAM_MPI_EPSILON) ? 1.0f : 1.0f / sq2;
-  const long long i4 = ((long long)blockIdx.x * kThreads + threadIdx.x) * 4;
+  const long long i4 = ((long long)blockIdx.x * kAdamThreads + threadIdx.x) * 4;
   if (i4 + 3 < n) {
     f4 gg = *reinterpret_cast<const f4*>(g + i4) * gscale;
     f4 mm = *reinterpret_cast<f4*>(m + i4), vv = *reinterpret_cast<f4*>(v + i4), pp = *reinterpret_cast<f4*>(p + i4);
@@ -255,10 +269,10 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 inline int nblocks_rows(int m) { return (m + kRowsPerBlock - 1) / kRowsPerBlock; }
 inline bool cols_ok(int c) { return c >= 4 && (c % 4) == 0 && (c / 4) <= kThreads && (kThreads % (c / 4)) == 0; }
 
-int launch_finish(const FinishJobs& J, int n_jobs, hipStream_t st, const char* who) {
-  int cmax = 0;
-  for (int j = 0; j < n_jobs; j++) cmax = J.cols[j] > cmax ? J.cols[j] : cmax;
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)((cmax + 15) / 16), (unsigned)n_jobs), dim3(kThreads), 0, st, J);
+int launch_finish(FinishJobs& J, int n_jobs, hipStream_t st, const char* who) {
+  J.first[0] = 0;
+  for (int j = 0; j < n_jobs; j++) J.first[j + 1] = J.first[j] + (J.nblk[j] <= kFewRows ? (J.cols[j] + kThreads - 1) / kThreads : (J.cols[j] + 15) / 16);
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)J.first[n_jobs]), dim3(kThreads), 0, st, J, n_jobs);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return orr_fail(-2, who, e);
   return 0;
@@ -335,7 +349,7 @@ int32_t orr_head_backward(const float* gy, int32_t k, const float* w, const floa
 }
 
 int32_t orr_colsum_finish(const orr_colsum_job* jobs, int32_t n_jobs, void* stream) {
-  if (!jobs || n_jobs < 1 || n_jobs > ORR_COLSUM_MAX_JOBS) return orr_fail(-1, "orr_colsum_finish: 1 to 8 jobs", hipSuccess);
+  if (!jobs || n_jobs < 1 || n_jobs > ORR_COLSUM_MAX_JOBS) return orr_fail(-1, "orr_colsum_finish: 1 to 12 jobs", hipSuccess);
   FinishJobs J{};
   for (int j = 0; j < n_jobs; j++) {
     if (!jobs[j].partials || !jobs[j].out || jobs[j].rows < 1 || jobs[j].cols < 1) return orr_fail(-1, "orr_colsum_finish: bad job", hipSuccess);
@@ -349,8 +363,8 @@ int32_t orr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, f
   if (!p || !g || !m || !v || !state || n <= 0) return orr_fail(-1, "orr_adam_step: bad argument", hipSuccess);
   if (flags & ~ORR_ADAM_MPI_EPSILON) return orr_fail(-1, "orr_adam_step: unknown flag", hipSuccess);
   if (!aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v)) return orr_fail(-1, "orr_adam_step: buffers must be 16-byte aligned", hipSuccess);
-  const long long per_block = 4LL * kThreads;
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + per_block - 1) / per_block)), dim3(kThreads), 0, (hipStream_t)stream, p, g, m, v, (long long)n, lr,
+  const long long per_block = 4LL * kAdamThreads;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + per_block - 1) / per_block)), dim3(kAdamThreads), 0, (hipStream_t)stream, p, g, m, v, (long long)n, lr,
                      beta1, beta2, eps, grad_scale, (int)flags, (int*)state);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return orr_fail(-2, "orr_adam_step: launch", e);

@@ -75,13 +75,12 @@ class FusedPPO(object):
                                         self._stream()), self.L)
 
     def _wgrad(self, x, g, part, out):
-        """out = x^T g.  Tall batches: 16 partial products in one batched GEMM + their sum (see ppo._wgrad: the library's plain
-        GEMM fills a third of the chip for these K = batch shapes)."""
+        """out = x^T g.  Tall batches: 16 partial products in one batched GEMM (see ppo._wgrad: the library's plain GEMM fills a
+        third of the chip for these K = batch shapes); their sum is one of the jobs of the minibatch's orr_colsum_finish."""
         t = self.torch
         if part is not None:
             M = x.shape[0]
             t.bmm(x.view(16, M // 16, x.shape[1]).transpose(1, 2), g.view(16, M // 16, g.shape[1]), out=part)
-            t.sum(part, dim=0, out=out)
         else:
             t.mm(x.t(), g, out=out)
 
@@ -95,23 +94,26 @@ class FusedPPO(object):
         split = M >= 4096 and M % 16 == 0
         P = {"B": B, "M": M, "nmb": B // M, "obs": f(B, 160), "aux": f(B, 16), "perm": t.empty(B, dtype=t.int64, device=self.dev),
              "x": f(M, 160), "batch": f(M, 16), "gz2": f(M, 256), "gh1": f(M, 512), "g_pi": f(M, 12), "g_vf": f(M),
-             "part1": f(16, 512, 256) if split else None, "part0": f(16, 160, 512) if split else None,
              "stats": t.zeros(B // M, 2, dtype=t.float32, device=self.dev),
              "ws": f(int(self.L.orr_learner_workspace_floats(M, 16))), "graphs": None}
         P["aux"].zero_()
         # the column sums behind the six bias gradients and the two output-layer weight gradients of a minibatch are deferred: each
         # producer leaves its per-workgroup partial sums in its own buffer and ONE launch adds them all up (orr_colsum_finish)
         rows = int(self.L.orr_learner_partial_rows(M))
-        jobs = (_abi.OrrColsumJob * 6)()
+        jobs = (_abi.OrrColsumJob * 10)()
         for i, (net, k) in enumerate((("pi", 12), ("vf", 1))):
             P["h1_" + net], P["h2_" + net], P["y_" + net] = f(M, 512), f(M, 256), f(M, k)
+            P["part1_" + net], P["part0_" + net] = (f(16, 512, 256), f(16, 160, 512)) if split else (None, None)
+            if split:
+                jobs[6 + 2 * i] = _abi.OrrColsumJob(P["part1_" + net].data_ptr(), self.g["model/%s_fc1/w:0" % net].data_ptr(), 16, 512 * 256)
+                jobs[7 + 2 * i] = _abi.OrrColsumJob(P["part0_" + net].data_ptr(), self.g["model/%s_fc0/w:0" % net].data_ptr(), 16, 160 * 512)
             P["ws2_" + net] = f(int(self.L.orr_learner_workspace_floats(M, 256)))      # [rows][256] | [rows][256 * 12]
             P["ws1_" + net] = f(rows * 512)
             for j, (buf, off, out, cols) in enumerate(((P["ws2_" + net], 0, self.g["model/%s_fc1/b:0" % net], 256),
                                                        (P["ws2_" + net], rows * 256, self.g["model/%s/w:0" % net], 256 * k),
                                                        (P["ws1_" + net], 0, self.g["model/%s_fc0/b:0" % net], 512))):
                 jobs[3 * i + j] = _abi.OrrColsumJob(buf.data_ptr() + 4 * off, out.data_ptr(), rows, cols)
-        P["jobs"] = jobs
+        P["jobs"], P["n_jobs"] = jobs, 10 if split else 6
         self._plans[key] = P
         return P
 
@@ -134,11 +136,11 @@ class FusedPPO(object):
             h1, h2 = P["h1_" + net], P["h2_" + net]
             _lib.check(L.orr_head_backward(gy.data_ptr(), k, w["model/%s/w:0" % net].data_ptr(), h2.data_ptr(), M, 256, P["gz2"].data_ptr(),
                                            None, None, P["ws2_" + net].data_ptr(), st), L)
-            self._wgrad(h1, P["gz2"], P["part1"], g["model/%s_fc1/w:0" % net])
+            self._wgrad(h1, P["gz2"], P["part1_" + net], g["model/%s_fc1/w:0" % net])
             t.mm(P["gz2"], w["model/%s_fc1/w:0" % net].t(), out=P["gh1"])
             _lib.check(L.orr_relu_backward(P["gh1"].data_ptr(), h1.data_ptr(), M, 512, None, P["ws1_" + net].data_ptr(), st), L)
-            self._wgrad(x, P["gh1"], P["part0"], g["model/%s_fc0/w:0" % net])
-        _lib.check(L.orr_colsum_finish(P["jobs"], 6, st), L)
+            self._wgrad(x, P["gh1"], P["part0_" + net], g["model/%s_fc0/w:0" % net])
+        _lib.check(L.orr_colsum_finish(P["jobs"], P["n_jobs"], st), L)
 
     def _allreduce(self):
         import torch.distributed as dist

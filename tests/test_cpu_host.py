@@ -176,8 +176,8 @@ def test_learner_abi_argument_checks_without_gpu():
     assert L.orr_head_backward(16, 12, 16, 16, 16, 256, 16, 16, None, 16, None) == -1
     assert b"both" in L.orr_last_error()
     assert L.orr_colsum_finish(None, 1, None) == -1
-    jobs = (_abi.OrrColsumJob * 9)()
-    assert L.orr_colsum_finish(jobs, 9, None) == -1
+    jobs = (_abi.OrrColsumJob * 13)()
+    assert L.orr_colsum_finish(jobs, 13, None) == -1
     assert L.orr_colsum_finish(jobs, 1, None) == -1                           # a job with null pointers
     assert b"bad job" in L.orr_last_error()
     assert L.orr_adam_step(16, 16, 16, 16, 8, 1e-4, 0.9, 0.999, 1e-5, 1.0, 2, 16, None) == -1
