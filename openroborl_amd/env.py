@@ -232,6 +232,19 @@ class VecQuadrupedEnv(object):
         self._env_step_counter += 1
         return self.obs, self.reward, self.done, {}
 
+    def step_into(self, actions, obs_out, reward_out, done_out):
+        """step() writing its three outputs into the caller's tensors (rows of a rollout buffer) instead of env.obs / env.reward /
+        env.done: contiguous float32 [N,160] (16-byte aligned), float32 [N], uint8 [N] on the env device.  Nothing here depends on
+        host state that changes from call to call, so a sequence of these calls can be captured into a hipGraph and replayed."""
+        t = self.torch
+        n = self.num_robot
+        for x, shape, dt in ((actions, (n, _abi.NUM_MOTORS), t.float32), (obs_out, (n, _abi.OBS_DIM), t.float32), (reward_out, (n,), t.float32),
+                             (done_out, (n,), t.uint8)):
+            if x.dtype != dt or x.device != self.obs.device or not x.is_contiguous() or tuple(x.shape) != shape:
+                raise ValueError("step_into: expected a contiguous %s tensor of shape %s on %s" % (dt, shape, self.device))
+        _lib.check(self.L.orr_step(self.h, actions.data_ptr(), obs_out.data_ptr(), reward_out.data_ptr(), done_out.data_ptr(), self._stream()), self.L)
+        self._env_step_counter += 1
+
     def time_steps(self, actions, num_steps):
         """Bench helper: num_steps back-to-back launches timed with hipEvents on the launch stream (ms)."""
         ms = C.c_float()

@@ -59,7 +59,9 @@ class FusedActorCritic(object):
                 _lib.check(self.L.orr_policy_pack(w.data_ptr(), int(k), int(n), self.packed[field].data_ptr(), self._stream()), self.L)
                 setattr(self.net, field, self.packed[field].data_ptr())
             else:
-                self.biases[field] = w.clone()        # own copy: stays valid while the optimiser updates the original
+                if field not in self.biases:          # own copy (stays valid while the optimiser updates the original) at a fixed address,
+                    self.biases[field] = t.empty_like(w)   # so that a captured forward pass can be replayed after a refresh
+                self.biases[field].copy_(w)
                 setattr(self.net, field, self.biases[field].data_ptr())
 
     def forward(self, obs, noise=None, want_mean=False, out_action=None, out_raw=None, out_value=None):

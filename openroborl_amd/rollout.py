@@ -16,8 +16,9 @@ robot's flag; `legacy_gae_index=True` reproduces exactly that, for comparisons w
 """
 
 
-def collect_rollout(env, policy, horizon, obs=None, deterministic=False, generator=None):
-    """Run `horizon` env steps of all robots.  Returns a dict of [T, N, ...] tensors + the final observation."""
+def collect_rollout(env, policy, horizon, obs=None, deterministic=False, generator=None, noise=None):
+    """Run `horizon` env steps of all robots.  Returns a dict of [T, N, ...] tensors + the final observation.
+    noise: optional [T, N, 12] standard-normal samples for the fused policy (default: drawn from `generator`)."""
     t = env.torch
     n = env.num_robot
     dev = env.device
@@ -29,9 +30,10 @@ def collect_rollout(env, policy, horizon, obs=None, deterministic=False, generat
         "vpred": t.empty((horizon, n), device=dev),
     }
     fused = getattr(policy, "fused", None) is not None
-    noise = None
-    if fused and not deterministic:   # one launch for the whole segment's exploration noise
+    if fused and not deterministic and noise is None:   # one launch for the whole segment's exploration noise
         noise = t.randn((horizon, n, 12), device=dev, generator=generator)
+    if not fused or deterministic:
+        noise = None
     for k in range(horizon):
         if fused:   # one fused launch writes the raw action and the value straight into the buffers
             clipped, _, _ = policy.act(obs, deterministic=deterministic, noise=None if noise is None else noise[k],
@@ -52,6 +54,64 @@ def collect_rollout(env, policy, horizon, obs=None, deterministic=False, generat
         std = float(policy.std)
         buf["logp"] = -0.5 * (noise * noise).sum(dim=-1) - 12.0 * math.log(std * math.sqrt(2.0 * math.pi))
     return buf
+
+
+class GraphRollout(object):
+    """collect_rollout() for the fused policy with static [T, N] buffers: the policy forward pass writes actions and values, and
+    env.step_into writes observations, rewards and done flags, straight into their rows, and the segment's launches (weight
+    re-pack, T x (policy, env step), log-probabilities) are captured once and replayed as ONE hipGraph.  The first segment runs
+    eagerly (first launches load code objects, which a capture must not do); the capture happens on the second call.
+
+    The returned tensors are views of the static buffers: they are overwritten by the next collect() (clone what must survive it,
+    e.g. the last row of `dones` that the next segment's GAE takes as first_starts)."""
+
+    def __init__(self, env, policy, horizon):
+        t = env.torch
+        if getattr(policy, "fused", None) is None:
+            raise RuntimeError("GraphRollout needs the fused policy (ActorCritic.enable_fused()); the plain path is collect_rollout()")
+        self.env, self.policy, self.T = env, policy, int(horizon)
+        n, dev, T = env.num_robot, env.device, self.T
+        f = lambda *shape: t.empty(shape, dtype=t.float32, device=dev)   # noqa: E731
+        self.obs, self.actions, self.clipped = f(T + 1, n, 160), f(T, n, 12), f(n, 12)
+        self.rewards, self.vpred, self.noise, self.logp = f(T, n), f(T, n), f(T, n, 12), f(T, n)
+        self.dones = t.zeros((T, n), dtype=t.uint8, device=dev)
+        self.graph, self.calls = None, 0
+
+    def _segment(self):
+        import math
+        t, env, fused = self.env.torch, self.env, self.policy.fused
+        fused.refresh()                   # inside the graph: every replay re-packs the weights the learner has just updated
+        for k in range(self.T):
+            fused.forward(self.obs[k], self.noise[k], out_action=self.clipped, out_raw=self.actions[k], out_value=self.vpred[k])
+            env.step_into(self.clipped, self.obs[k + 1], self.rewards[k], self.dones[k])
+        # log-probability of the sampled actions under the sampling policy: a - mean = std * noise
+        t.sum(self.noise * self.noise, dim=-1, out=self.logp)
+        self.logp.mul_(-0.5).sub_(12.0 * math.log(float(self.policy.std) * math.sqrt(2.0 * math.pi)))
+
+    def collect(self, obs, generator=None, noise=None):
+        t, env = self.env.torch, self.env
+        with t.no_grad():
+            if obs.data_ptr() != self.obs[0].data_ptr():
+                self.obs[0].copy_(obs)
+            if noise is not None:
+                self.noise.copy_(noise)
+            else:
+                self.noise.normal_(generator=generator)
+            self.calls += 1
+            if self.calls == 1:
+                self._segment()
+            else:
+                if self.graph is None:
+                    counter = env._env_step_counter
+                    self.graph = t.cuda.CUDAGraph()
+                    with t.cuda.graph(self.graph):
+                        self._segment()
+                    env._env_step_counter = counter          # the capture launched nothing
+                self.graph.replay()
+                env._env_step_counter += self.T
+            self.policy._fused_dirty = False
+        return {"obs": self.obs[:self.T], "actions": self.actions, "rewards": self.rewards, "dones": self.dones.view(t.bool),
+                "vpred": self.vpred, "logp": self.logp, "last_obs": self.obs[self.T]}
 
 
 def legacy_nonterminal(dones, first_starts=None):

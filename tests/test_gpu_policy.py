@@ -143,3 +143,40 @@ def test_rollout_logp_matches_learner_log_prob():
         lp = model.log_prob(buf["obs"].reshape(-1, 160), buf["actions"].reshape(-1, 12))
     np.testing.assert_allclose(buf["logp"].reshape(-1).cpu().numpy(), lp.cpu().numpy(), atol=2e-3, rtol=1e-4)
     env.close()
+
+
+def test_graph_rollout_equals_the_eager_collector():
+    """rollout.GraphRollout (static buffers, env.step_into, one hipGraph per segment) against rollout.collect_rollout on a twin env with
+    the same seed and the same exploration noise: every buffer bit for bit, over an eager first segment, the capture and two replays,
+    with the weights changed between segments (the captured re-pack must pick the new ones up)."""
+    import torch
+    from openroborl_amd import ppo, rollout
+    from openroborl_amd.env import VecQuadrupedEnv
+    dev = torch.device("cuda:0")
+    n, T = 256, 8
+    envs = [VecQuadrupedEnv(task_name="imitation_learning_laikago", num_robot=n, mode="train", auto_reset=True, seed=11, device=dev) for _ in range(2)]
+    models = [ppo.ActorCritic(dev, seed=1).enable_fused() for _ in range(2)]
+    collector = rollout.GraphRollout(envs[1], models[1], T)
+    obs = [e.reset() for e in envs]
+    gen = torch.Generator(device=dev).manual_seed(0)
+    ended = 0
+    for seg in range(4):
+        noise = torch.randn(T, n, 12, device=dev, generator=gen)
+        a = rollout.collect_rollout(envs[0], models[0], T, obs=obs[0], noise=noise)
+        b = collector.collect(obs[1], noise=noise)
+        for k in ("obs", "actions", "rewards", "dones", "vpred", "last_obs"):
+            assert torch.equal(a[k], b[k]), (seg, k)
+        np.testing.assert_allclose(b["logp"].cpu().numpy(), a["logp"].cpu().numpy(), rtol=1e-6, atol=1e-5)
+        assert envs[0].env_step_counter == envs[1].env_step_counter == (seg + 1) * T
+        ended += int(b["dones"].sum()) if seg >= 1 else 0
+        obs = [a["last_obs"], b["last_obs"]]
+        with torch.no_grad():                       # "the learner" moves the weights; both policies are told so
+            for m in models:
+                for k2 in sorted(m.p):
+                    m.p[k2].mul_(1.0 + 0.01 * (seg + 1))
+                m.mark_updated()
+    assert collector.graph is not None and ended >= n                  # episodes ended and restarted inside the replayed segments
+    stats = [e.stats() for e in envs]
+    assert stats[0] == stats[1]
+    for e in envs:
+        e.close()

@@ -93,13 +93,24 @@ def roll():
     state["buf"] = buf
 
 
-t_roll = ms(roll, 10)
+t_roll_eager = ms(roll, 10)
+collector = rollout.GraphRollout(env, model, T)
+
+
+def roll_graph():
+    buf = collector.collect(state["obs"], generator=gen)
+    state["obs"] = buf["last_obs"]
+    state["buf"] = buf
+
+
+t_roll = ms(roll_graph, 10)
 buf = state["buf"]
 t_env = ms(lambda: env.step(buf["actions"][0]), 100)
 t_act = ms(lambda: model.act(state["obs"], noise=buf["actions"][0]), 100)
 boot = model.value(state["obs"]).detach()
 t_gae = ms(lambda: rollout.gae_fused(buf["rewards"], buf["vpred"], buf["dones"], 0.95, 0.95, bootstrap=boot, normalize=True, eps=1e-8), 50)
-print("rollout of %d steps: %.2f ms (%.3f per step; env.step alone %.3f, act alone %.3f); GAE %.3f ms" % (T, t_roll, t_roll / T, t_env, t_act, t_gae))
+print("rollout of %d steps: %.2f ms as one hipGraph (%.3f per step), %.2f ms launched step by step; env.step alone %.3f, act alone %.3f; GAE %.3f ms"
+      % (T, t_roll, t_roll / T, t_roll_eager, t_env, t_act, t_gae))
 tot = t_roll + t_gae + t_update
 print("iteration: %.2f ms -> %.2f M samples/s (rollout %.0f %%, update %.0f %%)" % (tot, B / tot * 1e-3, 100 * t_roll / tot, 100 * t_update / tot))
 env.close()

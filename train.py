@@ -70,8 +70,10 @@ def main():
     samples = 0
     log = []
     first_starts = None                   # episode_starts of a segment's first step = the last step's done flags of the previous segment
+    # static rollout buffers + the segment replayed as one hipGraph (fused policy only); --torch-policy keeps the eager collector
+    collector = None if args.torch_policy else rollout.GraphRollout(env, model, args.horizon)
     for it in range(args.iters):
-        buf = rollout.collect_rollout(env, model, args.horizon, obs=obs, generator=gen)
+        buf = collector.collect(obs, generator=gen) if collector else rollout.collect_rollout(env, model, args.horizon, obs=obs, generator=gen)
         obs = buf["last_obs"]
         with torch.no_grad():
             boot = model.value(obs)
@@ -79,7 +81,7 @@ def main():
         # with 32-step segments that bias would dominate)
         adv, ret = rollout.gae_fused(buf["rewards"], buf["vpred"], buf["dones"], 0.95, 0.95, bootstrap=boot, normalize=True, eps=1e-8,
                                      legacy_gae_index=args.legacy_gae_index, first_starts=first_starts)
-        first_starts = buf["dones"][-1]
+        first_starts = buf["dones"][-1].clone()               # the collector's buffers are overwritten by the next segment
         T, n = buf["rewards"].shape
         surr, vf = learner.update(buf["obs"].reshape(T * n, -1), buf["actions"].reshape(T * n, -1), adv.reshape(-1),
                                   ret.reshape(-1), old_logp=buf["logp"].reshape(-1) if "logp" in buf else None,
