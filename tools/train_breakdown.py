@@ -83,7 +83,7 @@ print("autograd path, one minibatch of %d: forward %.3f ms (%.1f TFLOP/s), forwa
 
 env = VecQuadrupedEnv(task_name="imitation_learning_laikago", num_robot=n, mode="train", auto_reset=True, seed=0, device=dev)
 state = {"obs": env.reset()}
-for _ in range(150):     # past the start-up transient of the box
+for _ in range(6000):    # past the start-up transient of a fresh box (bench.py uses the same floor)
     env.step(torch.zeros(n, 12, device=dev))
 
 
