@@ -143,8 +143,14 @@ class FusedPPO(object):
         _lib.check(L.orr_colsum_finish(P["jobs"], P["n_jobs"], st), L)
 
     def _allreduce(self):
+        """Sum of the flat gradient over the ranks; orr_adam_step divides by the world size (mpi_adam.py:51-53)."""
         import torch.distributed as dist
-        dist.all_reduce(self.flat_g, group=self.group)       # sum; orr_adam_step divides by the world size (mpi_adam.py:51-53)
+        if dist.get_backend(self.group) == "gloo":            # rehearsal of the multi-rank path on a one-GPU box: stage through the host
+            tmp = self.flat_g.cpu()
+            dist.all_reduce(tmp, group=self.group)
+            self.flat_g.copy_(tmp)
+        else:
+            dist.all_reduce(self.flat_g, group=self.group)   # RCCL, in place on the device
 
     def _epoch_eager(self, P, world):
         for s in range(P["nmb"]):

@@ -45,3 +45,67 @@ def test_episode_gather_through_rccl_one_rank(tmp_path):
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ORR_FORCE_DIST="1")
     out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "rccl ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+LEARNER_WORKER = r"""
+import os, sys, math, torch
+sys.path.insert(0, %r)
+import torch.distributed as dist
+from openroborl_amd import learner_hip, ppo
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+if world > 1:
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+B, M = 16384, 4096
+def data(seed):
+    g = torch.Generator().manual_seed(seed)
+    obs = torch.randn(B, 160, generator=g).to(dev)
+    act = (torch.randn(B, 12, generator=g) * 0.2).to(dev)
+    old = (torch.randn(B, generator=g) * 0.1 - 10.0).to(dev)
+    return obs, act, torch.randn(B, generator=g).to(dev), torch.randn(B, generator=g).to(dev), old
+def run(seed):
+    model = ppo.ActorCritic(dev, seed=7)
+    obs, act, adv, ret, old = data(seed)
+    with torch.no_grad():
+        old = model.log_prob(obs, act) + 0.05 * adv        # ratios around 1
+    learner = learner_hip.FusedPPO(model, lr=1e-4, minibatch=M)
+    gen = torch.Generator(device=dev); gen.manual_seed(3)
+    stats = learner.update(obs, act, adv, ret, old_logp=old, epochs=2, generator=gen)
+    assert learner.steps_taken() == 2 * (B // M)
+    return learner.flat_p.clone(), stats
+# the same shard on every rank: the averaged gradient IS each rank's gradient, so the result is the one-rank result bit for bit
+p_same, _ = run(100)
+torch.save(p_same.cpu(), os.path.join(%r, "same_%%d_of_%%d.pt" %% (rank, world)))
+if world > 1:
+    # different shards: every rank ends with the same parameters
+    p_diff, _ = run(200 + rank)
+    mine = p_diff.cpu()
+    other = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(other, mine)
+    assert all(torch.equal(o, other[0]) for o in other)
+    assert not torch.equal(mine, p_same.cpu())
+    dist.barrier()
+    dist.destroy_process_group()
+print("learner ok")
+"""
+
+
+def test_fused_learner_two_ranks_gloo_on_one_gpu(tmp_path):
+    """The several-ranks path of learner_hip.FusedPPO (one hipGraph per minibatch, all-reduce of the flat gradient and Adam between
+    replays) rehearsed with two gloo ranks on this box's one GPU, against the one-rank path (one graph per epoch)."""
+    import torch
+    script = tmp_path / "worker.py"
+    script.write_text(LEARNER_WORKER % (ROOT, str(tmp_path)))
+    base = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    one = subprocess.run([sys.executable, str(script)], env=dict(base, RANK="0", WORLD_SIZE="1"), capture_output=True, text=True, timeout=300)
+    assert one.returncode == 0 and "learner ok" in one.stdout, one.stdout[-2000:] + one.stderr[-3000:]
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(base, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0 and "learner ok" in so, so[-2000:] + se[-3000:]
+    ref = torch.load(tmp_path / "same_0_of_1.pt")
+    for r in range(2):
+        assert torch.equal(torch.load(tmp_path / ("same_%d_of_2.pt" % r)), ref)
