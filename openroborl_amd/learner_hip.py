@@ -232,3 +232,28 @@ class FusedPPO(object):
 
     def steps_taken(self):
         return int(self.state[0].item())
+
+    # ---- replica consistency (MpiAdam.sync / check_synced, stable_baselines/common/mpi_adam.py:64-82) -----------------------
+    def _bcast_root(self):
+        import torch.distributed as dist
+        root = self.flat_p.clone()
+        if dist.get_backend(self.group) == "gloo":
+            host = root.cpu()
+            dist.broadcast(host, src=0, group=self.group)
+            root.copy_(host)
+        else:
+            dist.broadcast(root, src=0, group=self.group)
+        return root
+
+    def sync(self):
+        """Every rank takes rank 0's parameters (mpi_adam.py:64-70; the reference calls it once before training)."""
+        if self._world() > 1:
+            with self.torch.no_grad():
+                self.flat_p.copy_(self._bcast_root())
+            if hasattr(self.model, "mark_updated"):
+                self.model.mark_updated()
+
+    def check_synced(self):
+        """Raises unless this rank's parameters equal rank 0's bit for bit (mpi_adam.py:72-82; the reference checks every 100 steps)."""
+        if self._world() > 1 and not bool(self.torch.equal(self._bcast_root(), self.flat_p)):
+            raise RuntimeError("FusedPPO.check_synced: this rank's parameters differ from rank 0's")

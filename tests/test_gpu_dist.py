@@ -109,3 +109,23 @@ def test_fused_learner_two_ranks_gloo_on_one_gpu(tmp_path):
     ref = torch.load(tmp_path / "same_0_of_1.pt")
     for r in range(2):
         assert torch.equal(torch.load(tmp_path / ("same_%d_of_2.pt" % r)), ref)
+
+
+def test_train_loop_two_ranks_gloo_on_one_gpu(tmp_path):
+    """train.py end to end with two ranks (gloo, both on this box's one GPU): graph-replayed rollout, per-minibatch graphs with the
+    gradient all-reduce between replays, the episode all-gather, and the replica check of MpiAdam.check_synced every 100 iterations."""
+    import json
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    base = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                ORR_DIST_BACKEND="gloo", ORR_BENCH_SINGLE_DEVICE="1")
+    cmd = [sys.executable, os.path.join(ROOT, "train.py"), "--num-robot", "256", "--horizon", "8", "--minibatch", "1024", "--iters", "101",
+           "--save", str(tmp_path / "p.zip")]
+    procs = [subprocess.Popen(cmd, env=dict(base, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, so[-2000:] + se[-3000:]
+    recs = [json.loads(ln) for ln in outs[0][0].splitlines() if ln.startswith("{")]
+    assert recs and recs[-1]["iter"] == 100 and recs[-1]["samples"] == 101 * 8 * 256 * 2      # both shards counted
+    assert not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]                    # only rank 0 logs
+    assert recs[-1]["episodes"] > 0 and os.path.exists(tmp_path / "p.zip")

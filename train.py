@@ -50,7 +50,8 @@ def main():
     if args.eval:
         return evaluate(args, torch, pol, ppo, VecQuadrupedEnv)
     rank, world, local = odist.init_from_env()
-    dev = torch.device("cuda", local)
+    # ORR_BENCH_SINGLE_DEVICE=1 (+ ORR_DIST_BACKEND=gloo): several ranks rehearsed on a one-GPU box (tests), never a measurement
+    dev = torch.device("cuda", 0 if os.environ.get("ORR_BENCH_SINGLE_DEVICE") else local)
     torch.cuda.set_device(dev)
     env = VecQuadrupedEnv(task_name=args.task, num_robot=args.num_robot, mode="train", auto_reset=True, seed=args.seed,
                           device=dev, num_procs=world, robot_index_offset=rank * args.num_robot)
@@ -63,6 +64,7 @@ def main():
     else:
         from openroborl_amd import learner_hip
         learner = learner_hip.FusedPPO(model, lr=args.lr, minibatch=args.minibatch)
+        learner.sync()                                        # MpiAdam.sync before training (ppo_imitation.py:274)
     gen = torch.Generator(device=dev)
     gen.manual_seed(args.seed * 1000 + rank)
     obs = env.reset()
@@ -87,6 +89,8 @@ def main():
                                   ret.reshape(-1), old_logp=buf["logp"].reshape(-1) if "logp" in buf else None,
                                   epochs=args.epochs, generator=gen)
         samples += T * n * world
+        if world > 1 and it % 100 == 99 and hasattr(learner, "check_synced"):
+            learner.check_synced()                            # like MpiAdam every 100 updates (mpi_adam.py:47-48)
         stats = odist.gather_env_episodes(env, args.horizon)   # means come from the exact per-rank sums, not the truncated list
         if rank == 0 and (it % 10 == 0 or it == args.iters - 1):
             rec = {"iter": it, "samples": samples, "sec": round(time.time() - t0, 2),
