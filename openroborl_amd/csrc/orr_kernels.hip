@@ -56,12 +56,17 @@ using namespace orr;
 // kernels
 // ================================================================================================
 // lane group bookkeeping shared by the kernels: `sub` = which robot of this wave, `lane` = lane within the robot
-#define ORR_PROLOGUE()                                                                   \
-  __shared__ Shared Sarr[kRPW];                                                          \
-  const int sub = threadIdx.x / kLanes, lane = threadIdx.x % kLanes;                     \
-  Shared& S = Sarr[sub];                                                                 \
+// WPB = wavefronts per workgroup (each wave is an independent quad of robots; nothing is shared between the waves of a workgroup)
+#define ORR_PROLOGUE() ORR_PROLOGUE_W(1)
+#define ORR_PROLOGUE_W(WPB)                                                              \
+  __shared__ Shared Sarr[kRPW * (WPB)];                                                  \
+  const int wtid = (WPB) > 1 ? (int)(threadIdx.x & 63u) : (int)threadIdx.x;              \
+  const int wave_in_wg = (WPB) > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0; \
+  const int wave_id = (int)blockIdx.x * (WPB) + wave_in_wg;                              \
+  const int sub = wtid / kLanes, lane = wtid % kLanes;                                   \
+  Shared& S = Sarr[wave_in_wg * kRPW + sub];                                             \
   float* obs = S.ph.end.obs;                                                             \
-  const int robot_raw = blockIdx.x * kRPW + sub;                                         \
+  const int robot_raw = wave_id * kRPW + sub;                                            \
   const bool in_range = robot_raw < P.cfg.num_robots;                                    \
   const int robot = in_range ? robot_raw : 0; /* a padding lane group shadows robot 0 and never stores */ \
   float* rec = P.state + (size_t)robot * ORR_STATE_STRIDE
@@ -96,10 +101,15 @@ __global__ __launch_bounds__(64) void orr_reset_kernel(KParams P, const uint8_t*
 #ifndef ORR_WAVES_PER_EU
 #define ORR_WAVES_PER_EU 1   // development builds (-DORR_WAVES_PER_EU=2) force every instantiation to that occupancy
 #endif
+#ifndef ORR_WPB
+#define ORR_WPB 1            // wavefronts per workgroup of the one-wave-per-SIMD env step (tuning experiments: 2, 4)
+#endif
+template <int MODE, int WPE>
+constexpr int step_wpb() { return MODE == 0 && WPE == 1 ? ORR_WPB : 1; }
 template <int MODE, int WPE = ORR_WAVES_PER_EU>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void orr_step_kernel(KParams P, const float* actions, float* obs_out, float* reward_out,
+__global__ __launch_bounds__((MODE == 0 && WPE == 1 ? 64 * ORR_WPB : 64)) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void orr_step_kernel(KParams P, const float* actions, float* obs_out, float* reward_out,
                                                       uint8_t* done_out, int nsub, ReplayArgs RP) {
-  ORR_PROLOGUE();
+  ORR_PROLOGUE_W((step_wpb<MODE, WPE>()));
   const bool valid = in_range;
   const orr_config& c = P.cfg;
   PT_INIT();
@@ -193,7 +203,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
   // in even sub-steps and of the odd rounds in odd sub-steps lets them take turns at being the favoured one and finish together.
   // 8192 robots: 0.349 -> 0.331 ms (-5.3 %); turns of 2 or 4 sub-steps, or a second flip in the middle of a sub-step, are no better
   // (0.332 / 0.332 / 0.335; tools/build_variants.py: -DORR_PRIO_SHIFT=n, -DORR_NO_PRIO_ALTERNATION).
-  const int prio_phase = WPE == 2 ? (int)((blockIdx.x / (unsigned)(P.simds > 0 ? P.simds : 1)) & 1u) : 0;
+  const int prio_phase = WPE == 2 ? (int)(((unsigned)wave_id / (unsigned)(P.simds > 0 ? P.simds : 1)) & 1u) : 0;
 #endif
   for (int sstep = 0; sstep < c.action_repeat; sstep++) {
 #ifndef ORR_NO_PRIO_ALTERNATION
@@ -370,7 +380,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
   // a ticket for the wave's robots; the last wave to finish folds the launch's done count into the curriculum counter
   // (wrapper_env.py:82-83).
   const unsigned long long fin_mask = __ballot(valid && lane == 0 && reason != 0), val_mask = __ballot(valid && lane == 0);
-  if (threadIdx.x == 0) {
+  if (wtid == 0) {
     const unsigned long long nfin = (unsigned long long)__popcll(fin_mask), nval = (unsigned long long)__popcll(val_mask);
     if (nfin) atomicAdd((unsigned long long*)&P.counters[ORR_CNT_DONE_ACCUM], nfin);
     __threadfence();  // this wave's DONE_ACCUM / episode-log writes are visible before its ticket is
@@ -686,8 +696,9 @@ int32_t orr_step(orr_handle* h, const float* actions_dev, float* obs_dev, float*
   } else {
     // <0> = <0, ORR_WAVES_PER_EU>: one wave per SIMD in the shipped build; development builds (-DORR_WAVES_PER_EU=2 with the timers of
     // this translation unit, tools/wave_pairing.py) get their instrumented two-wave kernel through this path with ORR_STEP_WAVES_PER_EU=1
-    hipLaunchKernelGGL((orr_step_kernel<0>), dim3(waves), dim3(64), 0, (hipStream_t)stream, make_params(h), actions_dev, obs_dev, reward_dev,
-                       done_dev, 0, ReplayArgs{});
+    constexpr int wpb = step_wpb<0, ORR_WAVES_PER_EU>();
+    hipLaunchKernelGGL((orr_step_kernel<0>), dim3((waves + wpb - 1) / wpb), dim3(64 * wpb), 0, (hipStream_t)stream, make_params(h), actions_dev, obs_dev,
+                       reward_dev, done_dev, 0, ReplayArgs{});
     HIPCHK(hipGetLastError(), "orr_step: launch");
   }
   return 0;

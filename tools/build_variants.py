@@ -45,7 +45,8 @@ for spec in sys.argv[1:]:
     os.makedirs(tmp, exist_ok=True)
     procs = [subprocess.Popen([_lib.HIPCC] + fm + ["-c", '-DORR_SOURCE_HASH="variant-%s"' % name, "-o", tmp + "/k.o", _lib.SRC]),
              subprocess.Popen([_lib.HIPCC] + fw + ["-c", "-o", tmp + "/w.o", _lib.SRC_W2]),
-             subprocess.Popen([_lib.HIPCC, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-c", "-o", tmp + "/p.o", _lib.SRC_POLICY])]
+             subprocess.Popen([_lib.HIPCC, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-c", "-o", tmp + "/p.o", _lib.SRC_POLICY]),
+             subprocess.Popen([_lib.HIPCC, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-c", "-o", tmp + "/l.o", _lib.SRC_LEARNER])]
     assert all(p.wait() == 0 for p in procs), spec
-    subprocess.check_call([_lib.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, tmp + "/k.o", tmp + "/w.o", tmp + "/p.o"])
+    subprocess.check_call([_lib.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, tmp + "/k.o", tmp + "/w.o", tmp + "/p.o", tmp + "/l.o"])
     print("built", out, tu, " ".join(extra))
