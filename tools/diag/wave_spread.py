@@ -29,6 +29,10 @@ pool = torch.randn(64, N, 12, generator=gen, device=dev) * 0.125 - const
 obs = env.reset()
 L = _lib.load()
 L.orr_debug_wave_timeline.argtypes = [C.POINTER(C.c_longlong), C.c_int]
+L.orr_debug_wave_phases.argtypes = [C.POINTER(C.c_longlong), C.c_int]
+NAMES = ["load+leg consts", "set_act/filter", "substep control", "leg dynamics", "fall proxies", "row setup", "row response",
+         "Delassus columns", "PGS sweeps", "du+integrate", "receive_obs (ring)", "ctrl_obs+sensors", "reward+ref update",
+         "termination+obs", "episode end/reset", "store"]
 
 
 def step(k):
@@ -39,10 +43,14 @@ def step(k):
 for k in range(3000):
     step(k)
 buf = (C.c_longlong * (4 * W))()
+pbuf = (C.c_longlong * (40 * W))()
+phases = []
 dur, cyc, start, xcc, cu, se, simd, reset = [], [], [], [], [], [], [], []
 for k in range(n):
     step(3000 + k)
     L.orr_debug_wave_timeline(buf, W)
+    L.orr_debug_wave_phases(pbuf, W)
+    phases.append(np.frombuffer(pbuf, dtype=np.int64).reshape(W, 40)[:, :16].astype(np.float64).copy())
     a = np.frombuffer(buf, dtype=np.int64).reshape(W, 4).copy()
     t0 = a[:, 0].min()
     start.append((a[:, 0] - t0) / 100.0)
@@ -85,4 +93,13 @@ relc = c / np.nanmedian(c, axis=1, keepdims=True) - 1.0
 m_ = ~np.isnan(rel) & ~np.isnan(relc)
 print("excess in shader cycles vs excess in wall time: correlation %.2f; slowest 2 %% of waves: wall %+.2f %%, cycles %+.2f %%"
       % (np.corrcoef(rel[m_], relc[m_])[0, 1], 100 * np.nanmean(rel[rel >= np.nanpercentile(rel, 98)]), 100 * np.nanmean(relc[rel >= np.nanpercentile(rel, 98)])))
+print("percentiles of a no-reset wave's duration relative to its launch's median (%%): " +
+      "  ".join("p%d %+.2f" % (q, 100 * np.nanpercentile(rel, q)) for q in (1, 5, 10, 25, 50, 75, 90, 95, 99)))
+ph = np.array(phases)                                    # [launch, wave, phase]
+fast = rel <= np.nanpercentile(rel, 5)
+mid = (rel >= np.nanpercentile(rel, 45)) & (rel <= np.nanpercentile(rel, 55))
+slow = rel >= np.nanpercentile(rel, 95)
+print("%-22s %12s %16s %16s" % ("phase (shader cycles)", "median waves", "fastest 5 % - median", "slowest 5 % - median"))
+for k, nm in enumerate(NAMES):
+    print("%-22s %12.0f %16.0f %16.0f" % (nm, ph[mid][:, k].mean(), ph[fast][:, k].mean() - ph[mid][:, k].mean(), ph[slow][:, k].mean() - ph[mid][:, k].mean()))
 env.close()
