@@ -365,7 +365,9 @@ def main():
                         end, mean = rows.get("latest wave end = launch length (us)"), rows.get("mean wave duration (us)")
                         if end and mean:
                             issue["tail_frac"] = 1.0 - mean / end
-                            issue["tail_source"] = "profiles/%s_wave_timeline.txt (1 - mean wave duration / launch length)" % rnd2
+                            issue["tail_source"] = ("profiles/%s_wave_timeline.txt (1 - mean wave duration / launch length); most of it is waves that end "
+                                                    "EARLY - wave-level skips of contact work none of their robots needs - not late ones: "
+                                                    "profiles/r03_wave_spread.txt, DESIGN.md section 6") % rnd2
                             break
                 break
             except Exception as e:       # noqa: BLE001
