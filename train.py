@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--legacy-gae-index", action="store_true",
                     help="reproduce the reference's neighbouring-robot episode-start index in the GAE recursion (ppo_imitation.py:88); "
                          "only for curve-by-curve comparisons with the reference at num_robot > 1")
-    ap.add_argument("--tune-gemms", action="store_true", help="let PyTorch's TunableOp pick the learner's GEMM kernels (+7 %% samples/s after ~10 s of tuning)")
+    ap.add_argument("--tune-gemms", action="store_true", help="let PyTorch's TunableOp pick the learner's GEMM kernels (graph-replayed learner: 16.8 -> 16.3 ms per iteration after ~3 s of tuning)")
     args = ap.parse_args()
 
     import torch
