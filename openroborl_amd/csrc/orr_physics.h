@@ -196,7 +196,11 @@ __device__ __forceinline__ float part_suffix_sum(float x) {
   return x + a + b;
 }
 
-__device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst& K, int lane) {
+#ifndef ORR_ROW_SOLVE
+#define ORR_ROW_SOLVE 0     // 1: the rows solve with the Cholesky factor of A0 (kept in registers) instead of multiplying by an explicit A0^-1
+#endif
+struct BaseFactor { float L[21], idg[6]; };
+__device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst& K, int lane, BaseFactor& BF) {
   const int leg = lane & 3, part = (lane >> 2) & 3;
   float Rb[9];  // kinematic base frame -> world: kept current by base_rotation() (after every change of the quaternion)
 #pragma unroll
@@ -375,6 +379,12 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
 #pragma unroll
     for (int i = 0; i < 6; i++) nb[i] = -pacc[i];
     chol6_solve(Lc, idg, nb, a0);
+#if ORR_ROW_SOLVE
+#pragma unroll
+    for (int i = 0; i < 21; i++) BF.L[i] = Lc[i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) BF.idg[i] = idg[i];
+#else
     // explicit inverse for the impulse responses: lane c (< 6) solves for unit column c
     // (tried in round 3: ONE solve per lane with its own right-hand side - unit columns in lanes 0..11, -p in lanes 12..15 - and a0
     // broadcast from lane 12: only 10 instructions fewer per sub-step, and 144 B of LDS per robot for the dump slots of the a0 lanes)
@@ -385,6 +395,7 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
     chol6_solve(Lc, idg, e, x);
 #pragma unroll
     for (int i = 0; i < 6; i++) S.IA0inv[i * 6 + col] = x[i];   // lanes >= 6 store the same column again (col = lane % 6)
+#endif
   }
   // joint accelerations qdd = H^-1 (b - F^T a0): row `part` of H^-1 for the lane's own joint; written as the unconstrained
   // velocity u* = u + dt udot by the lane that owns the joint (it has the joint rate)
@@ -518,7 +529,7 @@ __device__ __forceinline__ void row_setup(const Shared& S, const orr_config& cfg
 // of T and of A0^-1 come out of LDS as aligned pairs, scalar factors ride as op_sel broadcasts.  A0^-1 is symmetric, so its
 // row k doubles as column k and a pair of outputs needs no horizontal add.
 typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void row_response(Shared& S, const orr_config& cfg, Row& R, int slot) {
+__device__ __forceinline__ void row_response(Shared& S, const orr_config& cfg, Row& R, int slot, const BaseFactor& BF) {
   const int leg = R.leg;
   const LegSolve& QL = S.leg[leg];
   float a0[6], mq[12];
@@ -536,12 +547,19 @@ __device__ __forceinline__ void row_response(Shared& S, const orr_config& cfg, R
       const v2f jb = {jb0, jb1};
       fb2[p] = jb - (TL[p] * jl0 + TL[3 + p] * jl1 + TL[6 + p] * jl2);
     }
+#if ORR_ROW_SOLVE
+    const float fb[6] = {fb2[0].x, fb2[0].y, fb2[1].x, fb2[1].y, fb2[2].x, fb2[2].y};
+    chol6_solve(BF.L, BF.idg, fb, a0);
+#pragma unroll
+    for (int p = 0; p < 3; p++) a02[p] = v2f{a0[2 * p], a0[2 * p + 1]};
+#else
     const v2f* IA = reinterpret_cast<const v2f*>(S.IA0inv);       // IA[3 k + p] = (A0^-1[k][2p], A0^-1[k][2p+1])
 #pragma unroll
     for (int p = 0; p < 3; p++)
       a02[p] = IA[p] * fb2[0].x + IA[3 + p] * fb2[0].y + IA[6 + p] * fb2[1].x + IA[9 + p] * fb2[1].y + IA[12 + p] * fb2[2].x + IA[15 + p] * fb2[2].y;
 #pragma unroll
     for (int p = 0; p < 3; p++) { a0[2 * p] = a02[p].x; a0[2 * p + 1] = a02[p].y; }
+#endif
   }
   const float h0 = QL.Hi[0] * jl0 + QL.Hi[3] * jl1 + QL.Hi[4] * jl2;
   const float h1 = QL.Hi[3] * jl0 + QL.Hi[1] * jl1 + QL.Hi[5] * jl2;
@@ -902,7 +920,8 @@ __device__ static int physics_substep(const KParams& P, Shared& S, const LegCons
     static_assert(ORR_MAX_FALL_PROXIES <= kLanes, "one fall proxy per lane");
     fp_body = mc->fall_body[lane]; fp_x = mc->fall_pos[lane][0]; fp_y = mc->fall_pos[lane][1]; fp_z = mc->fall_pos[lane][2]; fp_r = mc->fall_radius[lane];
   }
-  leg_dynamics(P, S, K, lane);  // -> link poses, leg solves, unconstrained velocities u*
+  BaseFactor BF;
+  leg_dynamics(P, S, K, lane, BF);  // -> link poses, leg solves, unconstrained velocities u*
   WSYNC();
   PT(3);
   int fall = 0;
@@ -962,8 +981,8 @@ __device__ static int physics_substep(const KParams& P, Shared& S, const LegCons
   }
   PT(5);
   // ---------------- impulse responses M^-1 J^T, diagonal, warm start ----------------
-  row_response(S, cfg, A, rowlane ? (lane < 4 ? lane : lane + 12) : 0);
-  if (anyB) row_response(S, cfg, B, (rowlane && lane >= 4) ? lane : kMaxRows);   // lanes without a joint-limit row: dump slot
+  row_response(S, cfg, A, rowlane ? (lane < 4 ? lane : lane + 12) : 0, BF);
+  if (anyB) row_response(S, cfg, B, (rowlane && lane >= 4) ? lane : kMaxRows, BF);   // lanes without a joint-limit row: dump slot
   WSYNC();
   PT(6);
   // Delassus columns, then the Gauss-Seidel sweeps; two instantiations: with and without the joint-limit bank
