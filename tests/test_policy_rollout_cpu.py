@@ -100,3 +100,26 @@ def test_stable_baselines_zip_round_trip(tmp_path):
     path2 = str(tmp_path / "model2.zip")
     pol.save_parameters_zip(path2, m2.state_dict())
     assert (pol.load_parameters(path2)["model/q/w:0"] == 0.25).all()
+
+
+def test_graph_replayed_paths_refuse_to_run_without_a_gpu():
+    """learner_hip.FusedPPO and rollout.GraphRollout are HIP-only: on a CPU model / without the fused policy they raise instead of
+    falling back to the plain PyTorch paths (ppo.PPO, rollout.collect_rollout), which stay available under their own names."""
+    import pytest
+    import torch
+    from openroborl_amd import learner_hip, ppo, rollout
+    model = ppo.ActorCritic(torch.device("cpu"), seed=0)
+    with pytest.raises(RuntimeError, match="needs a GPU"):
+        learner_hip.FusedPPO(model)
+
+    class FakeEnv(object):
+        torch = __import__("torch")
+        num_robot, device = 4, torch.device("cpu")
+    with pytest.raises(RuntimeError, match="fused policy"):
+        rollout.GraphRollout(FakeEnv(), model, 8)
+    # the plain learner still works on the CPU (the reference path of the GPU tests)
+    learner = ppo.PPO(model, lr=1e-4, minibatch=32)
+    g = torch.Generator().manual_seed(0)
+    obs, act = torch.randn(64, 160, generator=g), torch.randn(64, 12, generator=g) * 0.1
+    s = learner.update(obs, act, torch.randn(64, generator=g), torch.randn(64, generator=g), epochs=1, generator=g)
+    assert s.shape == (2,) and bool((s == s).all())
