@@ -401,11 +401,10 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
   // velocity u* = u + dt udot by the lane that owns the joint (it has the joint rate)
   const float dt = P.cfg.sim_dt;
   {
-    float g[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++)
-      g[k] = b[k] - (F[k][0] * a0[0] + F[k][1] * a0[1] + F[k][2] * a0[2] + F[k][3] * a0[3] + F[k][4] * a0[4] + F[k][5] * a0[5]);
-    S.ustar[part < 3 ? 6 + 3 * leg + part : 18 + leg] = ado + dt * (hq0 * g[0] + hq1 * g[1] + hq2 * g[2]);   // part 3: dump slot
+    // row `part` of H^-1 (b - F^T a0) = hq . b - (sum_k hq_k F_k) . a0 = hq . b - Tq . a0: the lane's own column of T is already there
+    const float hb = hq0 * b[0] + hq1 * b[1] + hq2 * b[2];
+    const float ta = Tq[0] * a0[0] + Tq[1] * a0[1] + Tq[2] * a0[2] + Tq[3] * a0[3] + Tq[4] * a0[4] + Tq[5] * a0[5];
+    S.ustar[part < 3 ? 6 + 3 * leg + part : 18 + leg] = ado + dt * (hb - ta);   // part 3: dump slot
   }
   {
     // classical base acceleration (Bullet: vdot = a_lin + w x v); gravity = uniform-field offset.  The same in every lane: all of
