@@ -7,7 +7,7 @@ fp32 reference the tests compare this against), different execution:
     all-reduce needs no packing and Adam is one launch over 434 k floats;
   * forward = six GEMMs with bias(+ReLU) epilogues writing into static activations; backward = ten GEMMs written out by hand
     (no autograd graph) with the ReLU masks, the gradient through the two output layers (fan-out 12 and 1: no GEMM), every bias
-    gradient and the loss head in four kinds of HIP launches - autograd spends ~70 elementwise / reduction launches per
+    gradient and the loss head in a handful of HIP launches (7 per minibatch) - autograd spends ~70 elementwise / reduction launches per
     minibatch on the same work, more GPU time than the GEMMs;
   * one rank: an epoch (gathers of all minibatches, forward, backward, Adam) is captured once and replayed - ~30 launches per
     minibatch cost no host time; several ranks: one graph per minibatch, the all-reduce (RCCL) and Adam between replays.
