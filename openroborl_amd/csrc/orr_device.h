@@ -215,6 +215,12 @@ union PhaseBuf {
   StepEndBuf end;
 };
 
+#ifndef ORR_ROW_SOLVE
+#define ORR_ROW_SOLVE 0
+#endif
+#ifndef ORR_LDS_PAD_WORDS
+#define ORR_LDS_PAD_WORDS 0     // multiple of 4
+#endif
 struct alignas(16) Shared {
   alignas(16) float s[kHead];  // state head (float / int bit patterns)
   alignas(16) ModelHot m;      // robot model (hot part)
@@ -222,11 +228,16 @@ struct alignas(16) Shared {
   LegSolve leg[4];
   alignas(16) float tdump[8];  // where the part-3 lanes (which own no joint) put their "column of T" (leg_dynamics)
   alignas(16) float Rb[9];     // kinematic base frame -> world
+#if !ORR_ROW_SOLVE
   alignas(16) float IA0inv[36];  // inverse of the base's effective 6x6 inertia (world axes, about the base COM)
+#endif
   alignas(16) float tau[16];   // joint torques (internal sign convention), joint order; 12..15: dump slots of the lanes that own no motor
   alignas(16) float ustar[24];
   alignas(16) float co[20];    // control (latency-delayed) observation
   alignas(16) PhaseBuf ph;
+#if ORR_LDS_PAD_WORDS > 0
+  alignas(16) float lds_pad_[ORR_LDS_PAD_WORDS];   // bank phase between the images of neighbouring robots (see the note at ORR_LDS_PAD_WORDS)
+#endif
 #ifdef ORR_PHASE_TIMERS
   long long pt_acc[kPhaseSlots], pt_last, pt_t0, pt_r0;  // development aid, see PT() in orr_kernels.hip
 #endif

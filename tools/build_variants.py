@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Build differently compiled copies of the library for tools/ab_variants.sh (development aid; build container).
 
-usage: python tools/build_variants.py name=[main|w2]:flag,flag,... [name=...]      ("base=main:" = the shipped flags)
+usage: python tools/build_variants.py name=[main|w2|both]:flag,flag,... [name=...]      ("base=main:" = the shipped flags)
 The flags replace / extend those of ONE translation unit (main = orr_kernels.hip: everything incl. the one-wave step kernel, ILP
 scheduler; w2 = orr_kernels_w2.hip: the two-waves-per-SIMD step kernel, default scheduler); the other unit keeps its shipped flags.
 A flag set that names an -amdgpu-sched-strategy replaces the unit's own; "nosched" removes it; -O1/-O2/-O3 replace -O2.
@@ -38,8 +38,8 @@ for spec in sys.argv[1:]:
     name, _, rest = spec.partition("=")
     tu, _, fl = rest.partition(":")
     extra = [f for f in fl.split(",") if f]
-    fm = apply(_lib.HIPCC_FLAGS, extra if tu == "main" else [])
-    fw = apply(_lib.HIPCC_FLAGS_W2, extra if tu == "w2" else [])
+    fm = apply(_lib.HIPCC_FLAGS, extra if tu in ("main", "both") else [])
+    fw = apply(_lib.HIPCC_FLAGS_W2, extra if tu in ("w2", "both") else [])
     out = os.path.join(ROOT, "openroborl_amd", "lib_var_%s.so" % name)
     tmp = "/tmp/var_%s" % name
     os.makedirs(tmp, exist_ok=True)
