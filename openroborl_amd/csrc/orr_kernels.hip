@@ -98,7 +98,7 @@ __global__ __launch_bounds__(64) void orr_reset_kernel(KParams P, const uint8_t*
 // positions and the fall flag is given -- the device-side counterpart of the oracle's replay mode, fed with the fixtures that the
 // reference's own Python produced (tests/test_gpu_golden_task.py).
 // WPE = waves per SIMD the kernel is compiled for.  WPE 1: up to 512 VGPRs (~300 used), one wave on each of the 1024 SIMDs = 4096 robots
-// resident at once: the best a batch of <= 4096 robots can do.  WPE 2 (<= 256 VGPRs, ~55 of them spilled; LDS 19.9 KB per wave, so
+// resident at once: the best a batch of <= 4096 robots can do.  WPE 2 (<= 256 VGPRs, 10 of them spilled outside the sub-step loop; LDS 19.3 KB per wave, so
 // eight waves fit a CU): for larger batches.  A lone wave issues one vector instruction per ~5 cycles, the SIMD can take one per 2:
 // two co-resident waves of this kernel take 1.12x as long as one alone (tools/wave_pairing.py), i.e. 1.8x the throughput per SIMD,
 // where the WPE-1 kernel would run the second thousand waves after the first.  orr_step picks the variant from the batch size and the
