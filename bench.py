@@ -13,16 +13,21 @@ train semantics (domain randomiser on, 20->600 step curriculum, per-robot auto-r
 A "step" is one env.step() of all robots of a GPU = one launch of the fused HIP kernel = 33 physics sub-steps +
 observation + reward + termination (+ auto-reset) per robot.  Actions are the policy-free stress input of SURVEY.md
 section 8d: reference joint pose one control step ahead (taken from the observation), in motor space, plus
-N(0, 0.125^2) noise, generated on the device (one elementwise launch per step for a robot whose motors are in joint order, else a
-(batched) GEMM; inside the timed region).  N > 1: independent
+N(0, 0.125^2) noise, generated on the device (one elementwise launch per step for any mix of robot types: the library's
+orr_stress_actions; inside the timed region).  N > 1: independent
 shards, one process per GPU, and the rollout-boundary all_gather of episode returns (RCCL) every 256 steps and at the
 end of the timed region.
 
 Timing protocol.  Untimed: `warmup_internal` env steps (a floor that does not depend on --warmup: a fresh box needs
 ~2 s of work before its clocks and code objects are in steady state) + one rollout-boundary gather (its first call
 loads code objects) + the W steps of --warmup.  Timed: EXACTLY K steps incl. the action launches and the gathers a real
-rollout performs, bracketed by barrier + synchronize.  Every 8th timed launch of the step kernel (every launch when K <= 64) is
-additionally bracketed by HIP events on the launch stream; their mean is the roofline's kernel time.
+rollout performs, bracketed by barrier + synchronize.  Every 8th timed launch of the step kernel (every 4th when K <= 64, every one
+when K <= 8; never launch 0, whose bracket would hold the host's launch latency on an empty queue) is additionally bracketed by HIP
+events on the launch stream; their MEDIAN is the roofline's kernel time (`kernel_ms`; the mean, min and max ride along).
+
+PMC-derived fields (`roofline.traffic`, `.pmc`, `.valu_issue`) come from a committed summary of separate rocprofv3 --pmc passes
+(profiles/rNN_<config>_pmc_summary.json, tools/profile_gpu.sh); every summary records the source hash of the library it was taken on,
+and a summary taken on other kernel sources than the loaded library's is NOT used: the fields are null and `"pmc_stale": true`.
 
 Prints ONE JSON line (rank 0).  The roofline object prices the step kernel against HBM bandwidth as the
 north star asks; DESIGN.md section 6 explains why the kernel is VALU-issue bound and nowhere near it.
@@ -92,6 +97,21 @@ def _oracle_rate(ol, env, n, threads, seconds, f32, build_dir):
     return n * steps / dt, steps
 
 
+def _cgroup_cpu_quota():
+    """CPUs this process may use per the cgroup CPU controller (v2 cpu.max, v1 cfs quota), or None when unlimited / unknown."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / p
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(env):
     """Time the CPU oracle (kind "port": PyBullet is not installed) on the host cores on bounded
     samples of the same workload.  Rows: float64 -O2 (the parity oracle) and float32 -O3 -march=native builds of the same
@@ -101,20 +121,27 @@ def cpu_baseline(env):
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
+    quota = _cgroup_cpu_quota()
     build_dir = None if os.access(os.path.join(ROOT, "oracle"), os.W_OK) else tempfile.mkdtemp()   # None = in oracle/
     rows = []
-    # a one-GPU box is a 16-core share of a bigger host: rows at 16 threads and at every core the process may run on
+    # a one-GPU box is a 16-core share of a bigger host whose affinity mask still lists every CPU (256 in round 3, where the
+    # "all cores" rows came out SLOWER than the 16-thread rows: they measured oversubscription).  The wide row is sized from the
+    # cgroup CPU quota when the box has one; without a quota it runs on the affinity mask and is labelled for what it is
     share = min(16, avail)
+    wide = min(avail, int(quota)) if quota and quota >= 1.0 else avail
     f64, f32 = "f64 -O2 -ffp-contract=off", "f32 -O3 -march=native"
     plan = [(f64, False, 1, 1, 3.0), (f64, False, 512, 1, 3.0), (f64, False, 32 * share, share, 4.0),
             (f32, True, 1, 1, 3.0), (f32, True, 512, 1, 3.0), (f32, True, 32 * share, share, 4.0)]
-    if avail > share:
-        plan += [(f64, False, 16 * avail, avail, 4.0), (f32, True, 16 * avail, avail, 4.0)]
+    if wide > share:
+        plan += [(f64, False, 16 * wide, wide, 4.0), (f32, True, 16 * wide, wide, 4.0)]
     for build, f32, n, threads, secs in plan:
         try:
             rate, steps = _oracle_rate(ol, env, min(n, env.num_robot), threads, secs, f32, build_dir)
             rows.append({"value": rate, "unit": "env steps/s", "cores": threads, "robots": min(n, env.num_robot), "build": build,
                          "sample": "%d robots x %d env steps" % (min(n, env.num_robot), steps)})
+            if threads > share and not quota:
+                rows[-1]["label"] = ("threads = CPUs in the affinity mask; this box reports no cgroup CPU quota, so if its real share is "
+                                     "smaller this row measures oversubscription, not more cores")
         except Exception as e:      # noqa: BLE001  (e.g. no compiler on the box for the f32 build): report, keep the other rows
             rows.append({"build": build, "cores": threads, "robots": n, "error": repr(e)})
     # the real reference physics, if this box happens to have it (it does not on this pool: SURVEY.md section 8c)
@@ -132,7 +159,7 @@ def cpu_baseline(env):
     return {"value": best["value"], "unit": "env steps/s", "cores": best["cores"], "kind": "port",
             "sample": "%s of the same workload, oracle/orr_oracle.c (%s), %d OpenMP threads; the fastest of the rows below"
                       % (best["sample"], best["build"], best["cores"]),
-            "host_cpu_count": os.cpu_count(), "host_cores_available": avail, "pybullet": pyb,
+            "host_cpu_count": os.cpu_count(), "host_cores_available": avail, "cgroup_cpu_quota_cores": quota, "pybullet": pyb,
             "note": "a restatement of the same algorithm (un-tuned articulated-body + PGS code), not PyBullet; never the target",
             "rows": rows}
 
@@ -213,43 +240,21 @@ def main():
     n = args.robots_per_gpu or n
     env = VecQuadrupedEnv(num_robot=n, mode="train", enable_randomizer=not args.no_randomizer, auto_reset=True, seed=int(os.environ.get("ORR_BENCH_SEED", "0")), device=dev,
                           num_procs=world, robot_index_offset=rank * n, **env_kw)
-    # action = (target joint pose -> motor space) - init + noise; the joint -> motor permutation and direction signs are one
-    # 12x12 matrix per robot type, noise and constant terms are pre-combined: one (batched) GEMM launch per step
-    types = sorted(set(int(t) for t in env.robot_type))
-    perm = torch.zeros(len(types), 12, 12, dtype=torch.float32, device=dev)
-    const = torch.zeros(len(types), 12, dtype=torch.float32, device=dev)
-    for k, t in enumerate(types):
-        m = env.models[t]
-        jom = torch.tensor(m["joint_of_motor"], dtype=torch.long, device=dev)
-        mdir = torch.tensor(m["motor_dir"], dtype=torch.float32, device=dev)
-        perm[k, jom, torch.arange(12, device=dev)] = mdir
-        const[k] = torch.tensor(m["motor_offset"], dtype=torch.float32, device=dev) * mdir + torch.tensor(m["init_motor_angles"], dtype=torch.float32, device=dev)
+    # action = clip((target joint pose -> motor space) - init + noise, +-2 pi) with every robot's own joint -> motor table: ONE launch
+    # of the library's stress-input kernel per step whatever the mix of robot types (as tensor operations a heterogeneous batch
+    # needs a copy + a batched GEMM: three launches, 4.9 % of the 8192-robot step in round 3)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
-    nt = len(types)
-    # robots are interleaved by type (robot i has type i % nt): viewing [n, 12] as [n/nt, nt, 12] groups them for a bmm
-    noise_pool = torch.randn(64, n // nt, nt, 12, generator=gen, device=dev) * 0.125 - const
-    if nt > 1:
-        noise_pool = noise_pool.permute(0, 2, 1, 3).contiguous()   # [64, nt, n/nt, 12]
-
-    # a robot type whose motors are in joint order (Laikago) needs no permutation: its matrix is diagonal and the action is ONE
-    # elementwise launch (addmm would first copy the noise into the output - a second launch of the same length as the GEMM itself)
-    diagonal = nt == 1 and bool((perm[0] == torch.diag(torch.diagonal(perm[0]))).all())
-    mdir_row = torch.diagonal(perm[0]).clone()
+    noise_pool = (torch.randn(64, n, 12, generator=gen, device=dev) * 0.125).contiguous()
+    act_buf = torch.zeros(n, 12, dtype=torch.float32, device=dev)
 
     def make_action(obs, k):
-        # |reference pose - init + noise| stays far below the 2 pi action bound, so the runner's clip
-        # (imitation_runners.py:140-143) is a no-op here and is left out
-        tar = obs[:, 84 + 7:84 + 19]
-        if diagonal:
-            return torch.addcmul(noise_pool[k & 63].view(n, 12), tar, mdir_row)
-        if nt == 1:
-            return torch.addmm(noise_pool[k & 63].view(n, 12), tar, perm[0])
-        tar_t = tar.view(n // nt, nt, 12).transpose(0, 1)                      # [nt, n/nt, 12], strided view
-        return torch.baddbmm(noise_pool[k & 63], tar_t, perm).transpose(0, 1).reshape(n, 12)
+        return env.stress_actions(obs, noise_pool[k & 63], act_buf)
+
+    in_group = torch.distributed.is_available() and torch.distributed.is_initialized()   # world > 1, or ORR_FORCE_DIST=1
 
     def sync_all():
-        if world > 1:
+        if in_group:
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
 
@@ -266,15 +271,18 @@ def main():
     dist_info = odist.describe()
     # HIP events around the step kernel of every EV_STRIDE-th timed launch (every launch for K <= 8, every 4th for K <= 64): each
     # record is a packet on the launch stream (~6 us of stream time per bracketed launch), so bracketing all launches would itself
-    # cost 2-4 % of the measured rate
+    # cost 2-4 % of the measured rate.  Launch 0 is never bracketed (unless K = 1): its opening record lands on an EMPTY queue right
+    # after the synchronize, so that bracket holds the host's launch latency, not only the kernel (one such outlier of
+    # five biased the 20-step line).  The roofline's kernel time is the MEDIAN of the bracketed launches; the mean rides along.
     ev_stride = int(os.environ.get("ORR_BENCH_EVENT_STRIDE", "0")) or (1 if args.steps <= 8 else (4 if args.steps <= 64 else 8))
+    ev_first = 1 if args.steps > 1 else 0
     stream = torch.cuda.current_stream(dev)
-    gloo = world > 1 and torch.distributed.get_backend() == "gloo"
+    gloo = in_group and torch.distributed.get_backend() == "gloo"
 
     def timed_region(k0):
         """EXACTLY args.steps env steps (action launch + step kernel) + the rollout-boundary gathers, between barrier + synchronize
         on both sides; returns the MAX over ranks of the elapsed time and rank-local details."""
-        ev = {k: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for k in range(0, args.steps, ev_stride)}
+        ev = {k: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for k in range(ev_first, args.steps, ev_stride)}
         sync_all()
         t0 = time.perf_counter()
         gather_s, since, n_eps = 0.0, 0, 0
@@ -299,17 +307,18 @@ def main():
         sync_all()
         elapsed = time.perf_counter() - t0
         el = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if gloo else dev)
-        if world > 1:
+        if in_group:
             torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
-        return {"elapsed": float(el.item()), "gather_s": gather_s, "episodes": n_eps,
-                "kern_ms": sum(a.elapsed_time(b) for a, b in ev.values()) / len(ev), "launches_timed": len(ev)}
+        durs = sorted(a.elapsed_time(b) for a, b in ev.values())
+        return {"elapsed": float(el.item()), "gather_s": gather_s, "episodes": n_eps, "kern_ms": durs[len(durs) // 2],
+                "kern_ms_mean": sum(durs) / len(durs), "kern_ms_min": durs[0], "kern_ms_max": durs[-1], "launches_timed": len(ev)}
 
     # ---- timed: --repeats regions of exactly --steps env steps each; the reported one is the median by elapsed time ----
     regions = [timed_region(r * args.steps) for r in range(max(1, args.repeats))]
     mid = sorted(regions, key=lambda r: r["elapsed"])[len(regions) // 2]
     elapsed, gather_s, n_eps, n_ev = mid["elapsed"], mid["gather_s"], mid["episodes"], mid["launches_timed"]
 
-    # dominant kernel: HIP events on the launch stream around every timed launch
+    # dominant kernel: HIP events on the launch stream around the bracketed timed launches, median
     kern_ms = mid["kern_ms"]
     kern_total_ms = kern_ms * args.steps
     # cross-check: back-to-back launches without the action kernels in between (C-ABI helper, same stream)
@@ -327,11 +336,23 @@ def main():
         tag = args.config + ("_norand" if args.no_randomizer else "")
         if os.environ.get("ORR_STEP_WAVES_PER_EU") == "1" and n > 4 * 4 * torch.cuda.get_device_properties(dev).multi_processor_count:
             tag += "_wpe1"          # a batch that would run the two-waves-per-SIMD variant, forced onto the one-wave kernel (comparison runs)
-        for rnd in ("r03", "r02"):
+        lib_hash = env.L.orr_source_hash().decode()
+        pmc_stale, pmc_seen = None, []
+        for rnd in ("r04", "r03", "r02"):
             name = "%s_%s_pmc_summary.json" % (rnd, tag)
             pmc = os.path.join(ROOT, "profiles", name)
             if not os.path.exists(pmc) or n != CONFIGS[args.config][1]:
                 continue
+            try:
+                have = json.load(open(pmc)).get("source_hash")
+            except Exception:            # noqa: BLE001
+                have = None
+            pmc_seen.append({"file": "profiles/" + name, "source_hash": have})
+            if have != lib_hash:
+                # counters of OTHER kernel sources (or of a summary that does not say which): not this run's kernel, never reported as such
+                pmc_stale = True
+                continue
+            pmc_stale = False
             try:
                 d = json.load(open(pmc))
                 traffic = d.get("hbm_bytes_per_launch_fetch_x2")
@@ -358,7 +379,7 @@ def main():
                          "frac_of_lone_wave_ceiling": (ipw * per_simd * 4.0 / kcyc) if resident == 1 else None,
                          "frac_of_simd_peak": ipw * per_simd * 2.0 / kcyc,
                          "tail_frac": None}
-                for rnd2 in ("r03", "r02"):
+                for rnd2 in ("r04", "r03", "r02"):
                     tl = os.path.join(ROOT, "profiles", "%s_wave_timeline.txt" % rnd2)
                     if args.config == "laikago4096" and not args.no_randomizer and os.path.exists(tl):
                         rows = {m.group(1).strip(): float(m.group(2)) for m in (re.match(r"^(.*\S)\s+([0-9.]+)$", ln.rstrip()) for ln in open(tl)) if m}
@@ -384,19 +405,21 @@ def main():
             "config": {"workload": workload % n, "name": args.config,
                        "robots_per_gpu": n, "total_robots": world * n, "substeps_per_step": 33, "solver_iters": 9,
                        "randomizer": not args.no_randomizer, "control_latency_s": "U(0, 0.04) per episode" if not args.no_randomizer else 0.002,
-                       "auto_reset": True, "actions": "reference pose + N(0,0.125^2), on device (%s per step, timed)" % ("one elementwise launch" if diagonal else "copy + (batched) GEMM launch"),
+                       "auto_reset": True, "actions": "reference pose + N(0,0.125^2), on device (one elementwise launch per step: orr_stress_actions; timed)",
                        "launch": "eager", "collective": "all_gather of episode returns every %d steps and at the end" % ROLLOUT,
                        "episodes_gathered": n_eps},
             "timed_breakdown": {"kernel_ms_total": kern_total_ms, "gather_ms": 1e3 * gather_s,
                                 "other_ms": 1e3 * elapsed - kern_total_ms - 1e3 * gather_s,
                                 "kernel_launches_timed": n_ev,
-                                "note": "rank 0; kernel = mean HIP-event duration of the bracketed orr_step_kernel launches x steps; gather = host time "
+                                "note": "rank 0; kernel = median HIP-event duration of the bracketed orr_step_kernel launches x steps; gather = host time "
                                         "from the last queued kernel's end to the end of each rollout-boundary gather; other = action "
                                         "launches, launch gaps, barriers"},
             "dist": dist_info,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "orr_step_kernel<0, %d>" % kernel_wpe, "kernel_ms": kern_ms, "kernel_ms_back_to_back": kern_b2b_ms,
+                         "pmc_stale": pmc_stale, "pmc_source_hash": lib_hash, "pmc_summaries_seen": pmc_seen,
+                        "kernel": "orr_step_kernel<0, %d>" % kernel_wpe, "kernel_ms": kern_ms, "kernel_ms_mean": mid["kern_ms_mean"],
+                         "kernel_ms_min": mid["kern_ms_min"], "kernel_ms_max": mid["kern_ms_max"], "kernel_ms_back_to_back": kern_b2b_ms,
                          "alg_bytes_per_robot_step": b_alg, "alg_bytes_per_launch": b_alg * n,
                          "pmc": valu, "valu_issue": issue,
                          "note": "instruction-issue-bound serial chain of %s (33 x (leg dynamics + rows + 9 PGS sweeps)); HBM fraction is reported "
@@ -407,7 +430,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(env)
         print(json.dumps(out))
     env.close()
-    if world > 1:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():     # world > 1, or ORR_FORCE_DIST=1 (one-rank RCCL rehearsal)
         torch.distributed.destroy_process_group()
 
 

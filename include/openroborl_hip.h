@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ORR_ABI_VERSION 3
+#define ORR_ABI_VERSION 4
 
 #define ORR_NUM_MOTORS 12 /* laikago.py:29, mini_cheetah.py:29 */
 #define ORR_NUM_LEGS 4
@@ -175,6 +175,10 @@ typedef struct orr_model {
   float shank_radius;                   /* in the lower-leg link frame; radius 0 = none.  A leg touches the ground with whichever of its
                                            two spheres (toe, shank) is lower: one contact point per leg and sub-step */
   float foot_friction;                  /* default lateral friction of toe / lower leg */
+  float contact_stiffness;              /* URDF <contact><stiffness/><damping/> of the TOE link (Bullet's BT_CONTACT_FLAG_CONTACT_STIFFNESS_DAMPING): */
+  float contact_damping;                /* the toe's normal row gets cfm = 1 / (dt k + d), erp = dt k / (dt k + d) instead of the global
+                                           contact_erp and cfm 0 (btMultiBodyConstraintSolver::setupMultiBodyContactConstraint).
+                                           stiffness <= 0 = rigid contact (the global pair); ABI v4 */
   int32_t num_fall_proxies;             /* termination-only collision spheres on non-foot links */
   int32_t fall_body[ORR_MAX_FALL_PROXIES];
   float fall_pos[ORR_MAX_FALL_PROXIES][3];
@@ -264,6 +268,11 @@ int32_t orr_debug_replay_reset(orr_handle* h, const float* uniforms_dev, float* 
 /* last launch durations in ms measured with hipEvents on the launch stream (bench only; syncs) */
 int32_t orr_time_steps(orr_handle* h, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev,
                        void* stream, int32_t num_steps, float* total_ms_out);
+
+/* measurement input (bench only; no reference counterpart): the policy-free stress actions of SURVEY.md section 8d (i) in ONE launch for
+ * any mix of robot types: actions[i][m] = clip((obs[i][84 + 7 + joint_of_motor[m]] - motor_offset[m]) * motor_dir[m]
+ * - init_motor_angles[m] + noise[i][m], +-2 pi) with the table of robot i's type (obs [N,160], noise and actions [N,12], device). */
+int32_t orr_stress_actions(orr_handle* h, const float* obs_dev, const float* noise_dev, float* actions_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,7 +1,7 @@
 """ctypes mirror of include/openroborl_hip.h (struct layouts and constants only)."""
 import ctypes as C
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 NUM_MOTORS = 12
 POSE_DIM = 19
 VEL_DIM = 18
@@ -91,6 +91,8 @@ class OrrModel(C.Structure):
         ("shank_pos", (C.c_float * 3) * 4),
         ("shank_radius", C.c_float),
         ("foot_friction", C.c_float),
+        ("contact_stiffness", C.c_float),
+        ("contact_damping", C.c_float),
         ("num_fall_proxies", C.c_int32),
         ("fall_body", C.c_int32 * MAX_FALL_PROXIES),
         ("fall_pos", (C.c_float * 3) * MAX_FALL_PROXIES),

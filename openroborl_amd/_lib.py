@@ -44,7 +44,7 @@ EXPORTS = [
     "orr_last_error", "orr_abi_version", "orr_source_hash", "orr_state_stride", "orr_layout_count", "orr_layout_name",
     "orr_layout_offset", "orr_layout_size", "orr_layout_is_int", "orr_sizeof_config", "orr_sizeof_model",
     "orr_create", "orr_destroy", "orr_set_seed", "orr_set_model", "orr_set_motion", "orr_bind", "orr_reset", "orr_step",
-    "orr_episode_stats", "orr_time_steps", "orr_debug_physics", "orr_debug_replay_step", "orr_debug_replay_reset",
+    "orr_episode_stats", "orr_time_steps", "orr_stress_actions", "orr_debug_physics", "orr_debug_replay_step", "orr_debug_replay_reset",
     "orr_policy_packed_size", "orr_policy_pack", "orr_policy_forward", "orr_gae", "orr_gae_flags",
     "orr_learner_workspace_floats", "orr_ppo_head", "orr_relu_backward", "orr_head_backward", "orr_colsum_finish", "orr_learner_partial_rows", "orr_adam_step",
 ]
@@ -214,6 +214,8 @@ def load():
     L.orr_episode_stats.argtypes = [vp, C.c_double, C.c_int32, vp, vp]
     L.orr_time_steps.restype = C.c_int32
     L.orr_time_steps.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int32, C.POINTER(C.c_float)]
+    L.orr_stress_actions.restype = C.c_int32
+    L.orr_stress_actions.argtypes = [vp, vp, vp, vp, vp]
     L.orr_sizeof_config.restype = C.c_int32
     L.orr_sizeof_model.restype = C.c_int32
     # include/openroborl_policy.h

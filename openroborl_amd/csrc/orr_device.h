@@ -84,8 +84,9 @@ struct ModelHot {
   float lower_com[4][3];
   float init_quat[4];
   float toe_radius, shank_radius;
-  int num_fall;
-  int pad_;
+  // toe contact normal row (orr_model::contact_stiffness / contact_damping, folded on the host): constraint-force mixing added to the
+  // row's diagonal (0 = rigid) and erp / dt of a penetrating toe contact (rigid: cfg.contact_erp / dt)
+  float contact_cfm, contact_erp_dt;
 };
 static_assert(sizeof(ModelHot) == 512, "LDS budget: 4 robots per wave, two waves per SIMD = 20 KB per wave (DESIGN.md section 3)");
 // COLD part: read straight from the device table (global memory, L2-resident) where it is needed - per-motor and per-link constants
@@ -101,6 +102,7 @@ struct ModelCold {
   float tau_sign_motor[12];   // the same per MOTOR (tau_sign[joint_of_motor[m]]): no dependent second load
   float link_com[12][3];
   float default_joints[12];   // (INIT_MOTOR_ANGLES + OFFSET) * DIR, motor order (imitation_task.py:1245-1252)
+  int num_fall;
   int fall_body[ORR_MAX_FALL_PROXIES];
   float fall_pos[ORR_MAX_FALL_PROXIES][3];
   float fall_radius[ORR_MAX_FALL_PROXIES];

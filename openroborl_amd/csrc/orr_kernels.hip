@@ -176,8 +176,18 @@ __global__ __launch_bounds__((MODE == 0 && WPE == 1 ? 64 * ORR_WPB : 64)) __attr
   const float m_tsign = mc->tau_sign_motor[ml], m_init = mc->init_motor_angles[ml];
   // ---- set_act (minitaur.py:280-285): offset, last action, Butterworth filter ----
   ctrl_obs(P, rec, S, lane);
+  // Non-finite guard, action half: the +-0.2 rad clip of the motor command (fmin / fmax) would silently DROP a NaN action while the
+  // last-action sensor and the filter history keep it.  A non-finite action is recorded like a non-finite incoming state (ORR_DONE_NAN
+  // at the end of the step) and replaced by 0, so that nothing non-finite enters the record.
+  float act_in = actions[(size_t)robot * 12 + ml];
+  {
+    const bool bad_act = !(fabsf(act_in) < 1e30f);
+    if (bad_act) act_in = 0.0f;
+    const bool any_bad = ((__ballot(bad_act) >> (sub * kLanes)) & ((1ull << (kLanes - 1)) * 2ull - 1ull)) != 0ull;
+    if (lane == 0 && any_bad) S.s[kHead - 1] = 1.0f;
+  }
   if (lane < 12) {
-    const float act = actions[(size_t)robot * 12 + lane] + m_init;
+    const float act = act_in + m_init;
     S.s[O(LAST_ACTION) + lane] = act;
     float x1 = S.s[O(XHIST) + lane], x2 = S.s[O(XHIST) + 12 + lane], y1 = S.s[O(YHIST) + lane], y2 = S.s[O(YHIST) + 12 + lane];
     if (geti(S, O(STATE_ACTION_COUNTER)) == 0) {  // _filter (minitaur.py:1169-1178): init_history(current delayed angles)
@@ -306,7 +316,10 @@ __global__ __launch_bounds__((MODE == 0 && WPE == 1 ? 64 * ORR_WPB : 64)) __attr
   PT(12);
   // _terminal_condition (imitation_task.py:518-572) + time limit (wrapper_env.py:79) + non-finite guard
   int reason = 0;
-  unsigned long long log_slot;   // deliberately not initialised: a merged value would make the compiler wait for the atomic right away
+  // the slot is only defined where the atomic was issued (lane 0 of a robot whose episode ended) and only read there.  A frozen
+  // nondeterministic value instead of an uninitialised variable: reading it is defined behaviour in every lane, and unlike a constant
+  // it gives the compiler nothing to merge with the atomic's result (a merged value made it wait for the atomic right away)
+  unsigned long long log_slot = __builtin_nondeterministic_value(log_slot);
   {
     const float* rp = &S.s[O(REF_POSE)];
     float pe = 0.0f, qc[4], dq[4];
@@ -451,6 +464,23 @@ __global__ __launch_bounds__(1024) void orr_eplog_pack_kernel(long long* counter
     out[4] = red_r[0]; out[5] = red_l[0];
     counters[ORR_CNT_EPISODES] = 0; counters[ORR_CNT_EPLOG_DROPPED] = 0;   // every thread read them before the first barrier
   }
+}
+
+// Policy-free stress input of SURVEY.md section 8d (i): action = (reference joint pose one control step ahead, taken from the first
+// target frame of the observation, mapped joint -> motor space with the robot's own table) - INIT_MOTOR_ANGLES + noise, clipped to
+// the action space (imitation_runners.py:140-143).  One thread per (robot, motor), ONE launch whatever the mix of robot types: a
+// heterogeneous batch needs a per-robot permutation, which as tensor operations is a copy + a batched GEMM (three launches).
+__global__ __launch_bounds__(256) void orr_stress_actions_kernel(const DevTables* __restrict__ tab, const float* __restrict__ state,
+                                                                 const float* __restrict__ obs, const float* __restrict__ noise,
+                                                                 float* __restrict__ actions, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * 12) return;
+  const int r = i / 12, m = i - 12 * r;
+  const int type = __float_as_int(state[(size_t)r * ORR_STATE_STRIDE + ORR_OFF_ROBOT_TYPE]);
+  const ModelCold& C = tab->model[type].cold;
+  const float tar = obs[(size_t)r * ORR_OBS_DIM + 84 + 7 + C.joint_of_motor[m]];
+  const float a = (tar - C.motor_offset[m]) * C.motor_dir[m] - C.init_motor_angles[m] + noise[i];
+  actions[i] = fminf(fmaxf(a, -6.2831853f), 6.2831853f);
 }
 
 // ================================================================================================
@@ -628,7 +658,17 @@ int32_t orr_set_model(orr_handle* h, int32_t robot_type, const orr_model* m) {
   H.toe_radius = m->toe_radius;
   H.shank_radius = m->shank_radius;
   Cd.foot_friction = m->foot_friction;
-  H.num_fall = m->num_fall_proxies;
+  Cd.num_fall = m->num_fall_proxies;
+  if (m->contact_stiffness > 0.0f) {
+    if (!(m->contact_damping >= 0.0f)) return fail(-1, "orr_set_model: contact_damping must be >= 0");
+    // btMultiBodyConstraintSolver::setupMultiBodyContactConstraint: cfm = 1 / (dt k + d), erp = dt k / (dt k + d); cfm *= 1 / dt
+    const double dtk = (double)h->cfg.sim_dt * m->contact_stiffness, denom = dtk + m->contact_damping;
+    H.contact_cfm = (float)(1.0 / denom / h->cfg.sim_dt);
+    H.contact_erp_dt = (float)(dtk / denom / h->cfg.sim_dt);
+  } else {
+    H.contact_cfm = 0.0f;
+    H.contact_erp_dt = h->cfg.contact_erp / h->cfg.sim_dt;
+  }
   for (int i = 0; i < ORR_MAX_FALL_PROXIES; i++) {
     Cd.fall_body[i] = m->fall_body[i];
     Cd.fall_radius[i] = m->fall_radius[i];
@@ -726,6 +766,17 @@ int32_t orr_episode_stats(orr_handle* h, double total_timesteps, int32_t capacit
   hipLaunchKernelGGL(orr_eplog_pack_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, h->counters, h->ep_log, h->ep_log_cap, total_timesteps,
                      (int)capacity, out_dev);
   HIPCHK(hipGetLastError(), "orr_episode_stats: launch");
+  return 0;
+}
+
+// measurement input (not part of the drop-in surface): the policy-free stress actions of SURVEY.md section 8d (i), see the kernel
+int32_t orr_stress_actions(orr_handle* h, const float* obs_dev, const float* noise_dev, float* actions_dev, void* stream) {
+  if (!h || !h->state) return fail(-1, "orr_stress_actions: handle not bound");
+  if (!obs_dev || !noise_dev || !actions_dev) return fail(-1, "orr_stress_actions: null buffer");
+  const int n = h->cfg.num_robots;
+  hipLaunchKernelGGL(orr_stress_actions_kernel, dim3((n * 12 + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->tab_dev, h->state, obs_dev,
+                     noise_dev, actions_dev, n);
+  HIPCHK(hipGetLastError(), "orr_stress_actions: launch");
   return 0;
 }
 

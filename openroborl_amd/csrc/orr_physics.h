@@ -424,6 +424,7 @@ struct Row {
   int leg, nrm_slot, warm;
   float Jb[6], jl[3];          // Jacobian: base part (world angular, linear) and the 3 joints of `leg`
   float rhs, jdi, lam, w, lam_n;
+  float cfm;                   // constraint-force mixing of a soft toe normal row (0 = rigid)
   float lo_c, hi_c, mu_e;      // bounds = constant part -/+ mu_e * lambda_normal
   float wa[6], wq[12];         // own impulse response M^-1 J^T (base part, joint part): kept in registers for the Delassus columns
 };
@@ -444,7 +445,7 @@ __device__ __forceinline__ void row_setup(const Shared& S, const orr_config& cfg
 #pragma unroll
   for (int i = 0; i < 6; i++) R.Jb[i] = 0.0f;
   R.jl[0] = R.jl[1] = R.jl[2] = 0.0f;
-  R.rhs = 0.0f; R.jdi = 0.0f; R.lam = 0.0f; R.w = 0.0f; R.lam_n = 0.0f;
+  R.rhs = 0.0f; R.jdi = 0.0f; R.lam = 0.0f; R.w = 0.0f; R.lam_n = 0.0f; R.cfm = 0.0f;
   float lo = 0.0f, hi = 0.0f, mu = 0.0f;
   if (BANK == 0 && slot < 4) {
     R.leg = slot;
@@ -506,7 +507,9 @@ __device__ __forceinline__ void row_setup(const Shared& S, const orr_config& cfg
     R.warm = 3 * leg + d;
     if (d == 0) {
       lo = 0.0f; hi = 1e30f;
-      R.rhs = dist > 0.0f ? -rel - dist * inv_dt : -rel - dist * erp_dt;
+      // a TOE contact may be soft (URDF <contact><stiffness/><damping/>, see ModelHot): its own erp, and cfm on the row's diagonal
+      R.rhs = dist > 0.0f ? -rel - dist * inv_dt : -rel - dist * (shank ? erp_dt : S.m.contact_erp_dt);
+      R.cfm = shank ? 0.0f : S.m.contact_cfm;
     } else {
       R.nrm_slot = 16 + leg;
       mu = S.s[O(FOOT_MU)] * cfg.plane_friction;  // combined friction = product of the two coefficients
@@ -586,12 +589,16 @@ __device__ __forceinline__ void row_response(Shared& S, const orr_config& cfg, R
   for (int i = 0; i < 6; i++) R.wa[i] = a0[i];
 #pragma unroll
   for (int i = 0; i < 12; i++) R.wq[i] = mq[i];
-  R.jdi = R.active ? __builtin_amdgcn_rcpf(diag) : 0.0f;
+  // soft row: lambda' = lambda + (rhs - (A lambda)_row - cfm lambda) / (A_rr + cfm) (m_rhs - appliedImpulse m_cfm - deltaVel jacDiagABInv,
+  // btMultiBodyConstraintSolver::resolveSingleConstraintRowGeneric).  In the Delassus form of the sweeps (diagonal entry of Ac zero) that
+  // is the rigid update with 1 / (A_rr + cfm) for 1 / A_rr; only the warm start's (A lambda) needs the extra cfm lambda
+  R.jdi = R.active ? __builtin_amdgcn_rcpf(diag + R.cfm) : 0.0f;
   R.rhs *= R.jdi;
   {
     float prev = S.s[O(LAMBDA) + (R.warm >= 0 ? R.warm : 0)];   // every lane loads (opaque, so that the load is not put behind a branch)
     asm volatile("" : "+v"(prev));
     R.lam = (R.active && R.warm >= 0) ? cfg.warmstart_factor * prev : 0.0f;
+    R.w = R.cfm * R.lam;
   }
 }
 
@@ -912,12 +919,13 @@ __device__ static int physics_substep(const KParams& P, Shared& S, const LegCons
   const float dt = cfg.sim_dt, inv_dt = 1.0f / cfg.sim_dt, erp_dt = cfg.contact_erp / cfg.sim_dt;
   // termination-only collision proxies (imitation_task.py:536-546): read once per env step, at its last sub-step, from the device table
   // (lane i = proxy i); the loads are issued here and consumed after the leg dynamics, which cover their round trip
-  int fp_body = 0;
+  int fp_body = 0, fp_n = 0;
   float fp_x = 0.0f, fp_y = 0.0f, fp_z = 0.0f, fp_r = 0.0f;
   if (want_fall) {
     const ColdPtr mc = model_cold(P, geti(S, O(ROBOT_TYPE)));
     static_assert(ORR_MAX_FALL_PROXIES <= kLanes, "one fall proxy per lane");
     fp_body = mc->fall_body[lane]; fp_x = mc->fall_pos[lane][0]; fp_y = mc->fall_pos[lane][1]; fp_z = mc->fall_pos[lane][2]; fp_r = mc->fall_radius[lane];
+    fp_n = mc->num_fall;
   }
   BaseFactor BF;
   leg_dynamics(P, S, K, lane, BF);  // -> link poses, leg solves, unconstrained velocities u*
@@ -926,7 +934,7 @@ __device__ static int physics_substep(const KParams& P, Shared& S, const LegCons
   int fall = 0;
   if (want_fall) {
     bool hit = false;
-    if (lane < S.m.num_fall) {
+    if (lane < fp_n) {
       const int b = fp_body;
       const float* Rw = b == 0 ? S.Rb : S.ph.sub.dyn.lc[b - 1].Rw;
       const float oz = b == 0 ? S.s[O(POS) + 2] : S.ph.sub.dyn.lc[b - 1].ow[2];

@@ -78,7 +78,8 @@ class VecQuadrupedEnv(object):
 
     def __init__(self, task_name=None, training_yaml=None, sim_yaml=None, device="cuda", num_robot=None, seed=None,
                  robot=None, motion_file=None, mode=None, enable_randomizer=None, auto_reset=True, num_procs=1,
-                 robot_index_offset=0, legacy_grid=False, mixed_robots=None, ep_log_capacity=65536, config_overrides=None):
+                 robot_index_offset=0, legacy_grid=False, mixed_robots=None, ep_log_capacity=65536, config_overrides=None,
+                 model_overrides=None):
         import torch
         self.torch = torch
         if not torch.cuda.is_available():
@@ -122,8 +123,19 @@ class VecQuadrupedEnv(object):
             self.robot_names = [robot]
             robot_type = np.full(num_robot, robots.ROBOT_TYPE_ID[robot], dtype=np.int32)
         self.models = [None] * _abi.MAX_ROBOT_TYPES
+        # model_overrides = {robot name: {table entry: value}}: experiments on the hand-authored (parity-unpinned) entries of robots.py;
+        # the entry "_build" = {keyword: value} replaces arguments of the table builder (link masses, COMs, hip position, ...)
+        model_overrides = {k: dict(v) for k, v in (model_overrides or {}).items()}
         for name in set(self.robot_names):
-            self.models[robots.ROBOT_TYPE_ID[name]] = robots.ROBOTS[name]()
+            self.models[robots.ROBOT_TYPE_ID[name]] = robots.ROBOTS[name](**model_overrides.get(name, {}).pop("_build", {}))
+        for name, over in model_overrides.items():
+            m = self.models[robots.ROBOT_TYPE_ID[name]] if name in robots.ROBOT_TYPE_ID else None
+            if m is None:
+                raise ValueError("model_overrides names robot %r, which is not in this batch" % (name,))
+            for k, v in over.items():
+                if k not in m:
+                    raise ValueError("unknown model table entry %r" % (k,))
+                m[k] = np.asarray(v, dtype=np.asarray(m[k]).dtype).reshape(np.shape(m[k])) if np.ndim(m[k]) else type(m[k])(v)
         # clips: one per robot type in a mixed batch, else the task's clip
         self.clips = [motion.MotionClip(f) for f in motion_files]
         if mixed_robots:
@@ -171,6 +183,7 @@ class VecQuadrupedEnv(object):
         self.action_space = action_space()
         self._env_step_counter = 0
         self._closed = False
+        self.launch_params_generation = 0     # bumped whenever something a launch takes by value changes (seed()): see there
 
     # ---- reference attribute surface -------------------------------------------------------
     @property
@@ -188,6 +201,9 @@ class VecQuadrupedEnv(object):
         if seed is not None and (int(seed) & 0xFFFFFFFFFFFFFFFF) != int(self.cfg.seed):
             self.cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
             _lib.check(self.L.orr_set_seed(self.h, self.cfg.seed), self.L)
+            # orr_step / orr_reset pass the handle's configuration (seed included) BY VALUE as a kernel argument: a hipGraph captured
+            # before this call replays the old seed.  Holders of such graphs (rollout.GraphRollout) compare this counter and re-capture
+            self.launch_params_generation += 1
         return [int(self.cfg.seed)]
 
     def close(self):
@@ -235,7 +251,9 @@ class VecQuadrupedEnv(object):
     def step_into(self, actions, obs_out, reward_out, done_out):
         """step() writing its three outputs into the caller's tensors (rows of a rollout buffer) instead of env.obs / env.reward /
         env.done: contiguous float32 [N,160] (16-byte aligned), float32 [N], uint8 [N] on the env device.  Nothing here depends on
-        host state that changes from call to call, so a sequence of these calls can be captured into a hipGraph and replayed."""
+        host state that changes from call to call, so a sequence of these calls can be captured into a hipGraph and replayed - with ONE
+        restriction: the launch takes the handle's configuration (the seed included) by value, so a graph captured before env.seed(new)
+        replays the old seed; `launch_params_generation` counts such changes and rollout.GraphRollout re-captures when it moves."""
         t = self.torch
         n = self.num_robot
         for x, shape, dt in ((actions, (n, _abi.NUM_MOTORS), t.float32), (obs_out, (n, _abi.OBS_DIM), t.float32), (reward_out, (n,), t.float32),
@@ -252,6 +270,16 @@ class VecQuadrupedEnv(object):
                                          self.done.data_ptr(), self._stream(), int(num_steps), C.byref(ms)), self.L)
         self._env_step_counter += int(num_steps)
         return float(ms.value)
+
+    def stress_actions(self, obs, noise, out):
+        """Bench helper: the policy-free stress actions of SURVEY.md section 8d (i) for any mix of robot types, one launch:
+        out[i] = clip((first target frame's joints of obs[i], joint -> motor space of robot i) - INIT_MOTOR_ANGLES + noise[i], +-2 pi)."""
+        t = self.torch
+        for x, cols in ((obs, _abi.OBS_DIM), (noise, _abi.NUM_MOTORS), (out, _abi.NUM_MOTORS)):
+            if x.dtype != t.float32 or x.device != self.obs.device or not x.is_contiguous() or tuple(x.shape) != (self.num_robot, cols):
+                raise ValueError("stress_actions: contiguous float32 [%d, %d] on the env device expected" % (self.num_robot, cols))
+        _lib.check(self.L.orr_stress_actions(self.h, obs.data_ptr(), noise.data_ptr(), out.data_ptr(), self._stream()), self.L)
+        return out
 
     def replay_reset(self, uniforms):
         """Parity entry: reset of all robots with the given draws ([N,28] in [0,1)) instead of the Philox stream."""

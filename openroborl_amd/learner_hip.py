@@ -11,9 +11,15 @@ fp32 reference the tests compare this against), different execution:
     minibatch on the same work, more GPU time than the GEMMs;
   * one rank: an epoch (gathers of all minibatches, forward, backward, Adam) is captured once and replayed - ~30 launches per
     minibatch cost no host time; several ranks: one graph per minibatch, the all-reduce (RCCL) and Adam between replays.
+    ORR_FORCE_DIST=1 with an initialised process group takes the several-ranks path even for ONE rank (a one-GPU box can then run
+    per-minibatch graphs + the RCCL all-reduce + Adam between replays; the result equals the one-graph path bit for bit).
+Scalar hyper-parameters (lr, betas, eps, clip, vf_coef, the policy's std, the world size) are by-value kernel arguments, i.e. frozen
+into a captured graph: update() compares them with the values the graphs were captured with and captures again when one changed
+(the reference feeds optim_stepsize * cur_lrmult every step: ppo1/pposgd_simple.py; run.py uses schedule='constant').
 There is no fallback: without a GPU and the HIP library the constructor raises.
 """
 import ctypes as C
+import os
 
 from . import _abi, _lib
 
@@ -68,6 +74,25 @@ class FusedPPO(object):
         if not (dist.is_available() and dist.is_initialized()):
             return 1
         return dist.get_world_size(self.group)
+
+    def _several(self):
+        """The several-ranks execution (per-minibatch graphs, all-reduce and Adam between replays): more than one rank, or
+        ORR_FORCE_DIST=1 with a process group (one-rank rehearsal of exactly that path, e.g. on RCCL with the one GPU of a test box)."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return False
+        return dist.get_world_size(self.group) > 1 or bool(os.environ.get("ORR_FORCE_DIST"))
+
+    def _graph_key(self, several):
+        return (self.lr, self.b1, self.b2, self.eps, self.clip, self.vf_coef, float(self.model.std), self.adam_flags, self._world(), several)
+
+    @staticmethod
+    def fit_minibatch(num_samples, minibatch):
+        """Largest minibatch size <= `minibatch` that divides `num_samples` (update() needs equal minibatches: static buffers)."""
+        m = max(1, min(int(minibatch), int(num_samples)))
+        while num_samples % m:
+            m -= 1
+        return m
 
     def _adam(self, world):
         _lib.check(self.L.orr_adam_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.total,
@@ -152,14 +177,14 @@ class FusedPPO(object):
         else:
             dist.all_reduce(self.flat_g, group=self.group)   # RCCL, in place on the device
 
-    def _epoch_eager(self, P, world):
+    def _epoch_eager(self, P, world, several):
         for s in range(P["nmb"]):
             self._minibatch(P, s)
-            if world > 1:
+            if several:
                 self._allreduce()
             self._adam(world)
 
-    def _capture(self, P, world):
+    def _capture(self, P, several):
         """One rank: one graph for the whole epoch.  Several ranks: one graph per minibatch (the collective runs between replays)."""
         t = self.torch
         keep = [x.clone() for x in (self.flat_p, self.m, self.v, self.state)]
@@ -172,7 +197,7 @@ class FusedPPO(object):
                 self._adam(1)
         t.cuda.current_stream(self.dev).wait_stream(side)
         graphs = []
-        if world == 1:
+        if not several:
             gr = t.cuda.CUDAGraph()
             with t.cuda.graph(gr):
                 for s in range(P["nmb"]):
@@ -199,8 +224,9 @@ class FusedPPO(object):
         B = int(obs.shape[0])
         M = min(self.minibatch, B)
         if B % M:
-            raise ValueError("FusedPPO: the number of samples (%d) must be a multiple of the minibatch size (%d)" % (B, M))
-        world = self._world()
+            raise ValueError("FusedPPO: the number of samples (%d) must be a multiple of the minibatch size (%d); "
+                             "FusedPPO.fit_minibatch(%d, %d) = %d is the largest size that divides it" % (B, M, B, M, self.fit_minibatch(B, M)))
+        world, several = self._world(), self._several()
         with t.no_grad():
             if old_logp is None:
                 old_logp = self.model.log_prob(obs, actions)
@@ -211,14 +237,15 @@ class FusedPPO(object):
             aux[:, 12].copy_(old_logp)
             aux[:, 13].copy_(adv)
             aux[:, 14].copy_(ret)
-            if self.use_graph and P["graphs"] is None:
-                self._capture(P, world)
+            if self.use_graph and (P["graphs"] is None or P.get("graph_key") != self._graph_key(several)):
+                self._capture(P, several)
+                P["graph_key"] = self._graph_key(several)
             total = t.zeros(2, dtype=t.float32, device=self.dev)
             for _ in range(epochs):
                 P["perm"].copy_(t.randperm(B, device=self.dev, generator=generator))
                 if not self.use_graph:
-                    self._epoch_eager(P, world)
-                elif world == 1:
+                    self._epoch_eager(P, world, several)
+                elif not several:
                     P["graphs"][0].replay()
                 else:
                     for gr in P["graphs"]:
@@ -237,17 +264,19 @@ class FusedPPO(object):
     def _bcast_root(self):
         import torch.distributed as dist
         root = self.flat_p.clone()
+        # `src` of a broadcast is a GLOBAL rank: the root of a subgroup is its own rank 0, whatever global rank that is
+        src = 0 if self.group is None else dist.get_global_rank(self.group, 0)
         if dist.get_backend(self.group) == "gloo":
             host = root.cpu()
-            dist.broadcast(host, src=0, group=self.group)
+            dist.broadcast(host, src=src, group=self.group)
             root.copy_(host)
         else:
-            dist.broadcast(root, src=0, group=self.group)
+            dist.broadcast(root, src=src, group=self.group)
         return root
 
     def sync(self):
         """Every rank takes rank 0's parameters (mpi_adam.py:64-70; the reference calls it once before training)."""
-        if self._world() > 1:
+        if self._several():
             with self.torch.no_grad():
                 self.flat_p.copy_(self._bcast_root())
             if hasattr(self.model, "mark_updated"):
@@ -255,5 +284,5 @@ class FusedPPO(object):
 
     def check_synced(self):
         """Raises unless this rank's parameters equal rank 0's bit for bit (mpi_adam.py:72-82; the reference checks every 100 steps)."""
-        if self._world() > 1 and not bool(self.torch.equal(self._bcast_root(), self.flat_p)):
+        if self._several() and not bool(self.torch.equal(self._bcast_root(), self.flat_p)):
             raise RuntimeError("FusedPPO.check_synced: this rank's parameters differ from rank 0's")

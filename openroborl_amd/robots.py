@@ -48,7 +48,7 @@ def _pa(m, d):
 def _build(name, init_pos, init_quat, init_motor_angles, motor_dir, motor_offset, joint_of_motor, kp, kd,
            base_mass, base_inertia, hip_xy, hip_z, coxa, femur, tibia, pitch_axis,
            hip_m, hip_com, hip_I, up_m, up_com, up_I, lo_m, lo_com, lo_I, toe_m, toe_r,
-           limits, chassis_half, hip_r, knee_r, foot_friction, shank_r=0.0, shank_at=0.0):
+           limits, chassis_half, hip_r, knee_r, foot_friction, shank_r=0.0, shank_at=0.0, contact_stiffness=0.0, contact_damping=0.0):
     m = {
         "name": name,
         "init_pos": np.array(init_pos, dtype=np.float64),
@@ -64,6 +64,8 @@ def _build(name, init_pos, init_quat, init_motor_angles, motor_dir, motor_offset
         "toe_radius": float(toe_r),
         "shank_radius": float(shank_r),
         "foot_friction": float(foot_friction),
+        "contact_stiffness": float(contact_stiffness),
+        "contact_damping": float(contact_damping),
     }
     link_mass = np.zeros(12)
     link_com = np.zeros((12, 3))
@@ -134,10 +136,11 @@ def _build(name, init_pos, init_quat, init_motor_angles, motor_dir, motor_offset
     return m
 
 
-def laikago():
-    """robots/laikago.py constants + authored inertial / collision data."""
-    return _build(
-        "laikago",
+def laikago(**over):
+    """robots/laikago.py constants + authored inertial / collision data.  over: replaces keyword arguments of _build (experiments on
+    the hand-authored entries: tools/policy_probe.py --sensitivity)."""
+    return _build(**dict(dict(
+        name="laikago",
         init_pos=[0, 0, 0.48], init_quat=[0.5, 0.5, 0.5, 0.5],               # laikago.py:48-49
         init_motor_angles=[0, 0.67, -1.25] * 4,                              # laikago.py:62
         motor_dir=[-1, 1, 1, 1, 1, 1, -1, 1, 1, 1, 1, 1],                    # laikago.py:50
@@ -160,13 +163,13 @@ def laikago():
         limits=[(-1.0471975512, 1.0471975512), (-0.5235987756, 3.9269908170), (-2.7750735107, -0.6108652382)],
         # lower legs are feet too (minitaur.py:842-844): a second contact sphere at the upper end of the shank (hand-authored, as the
         # URDF's collision shapes are unavailable); the thigh's knee proxy (knee_r, termination only) is the larger of the two
-        chassis_half=[0.27, 0.09, 0.055], hip_r=0.045, knee_r=0.035, foot_friction=1.0, shank_r=0.02, shank_at=0.03)
+        chassis_half=[0.27, 0.09, 0.055], hip_r=0.045, knee_r=0.035, foot_friction=1.0, shank_r=0.02, shank_at=0.03), **over))
 
 
-def mini_cheetah():
-    """robots/mini_cheetah.py constants + MIT mini-cheetah published inertial figures."""
-    return _build(
-        "mini_cheetah",
+def mini_cheetah(**over):
+    """robots/mini_cheetah.py constants + MIT mini-cheetah published inertial figures.  over: as in laikago()."""
+    return _build(**dict(dict(
+        name="mini_cheetah",
         init_pos=[0, 0, 0.28], init_quat=[0.0, 0.0, 0.0, 1.0],               # mini_cheetah.py:49-50
         init_motor_angles=[0, -0.78, 1.74] * 4,                              # mini_cheetah.py:63
         motor_dir=[1] * 12, motor_offset=[0.0] * 12,                         # mini_cheetah.py:51,53
@@ -192,7 +195,7 @@ def mini_cheetah():
         limits=[(-1e9, 1e9)] * 3,                                            # continuous joints
         # knee proxy radius 0: with a finite knee sphere the shipped minicheetah_trot policy is stopped by knee
         # "contacts" within ~10 steps while still upright; the thigh/shank of this robot are thin plates
-        chassis_half=[0.19, 0.049, 0.05], hip_r=0.04, knee_r=0.0, foot_friction=1.0, shank_r=0.0094, shank_at=0.0196)   # shank sphere [0.012 @ 0.02]
+        chassis_half=[0.19, 0.049, 0.05], hip_r=0.04, knee_r=0.0, foot_friction=1.0, shank_r=0.0094, shank_at=0.0196), **over))   # shank sphere [0.012 @ 0.02]
 
 
 ROBOTS = {"laikago": laikago, "mini_cheetah": mini_cheetah}

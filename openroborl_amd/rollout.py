@@ -62,6 +62,9 @@ class GraphRollout(object):
     re-pack, T x (policy, env step), log-probabilities) are captured once and replayed as ONE hipGraph.  The first segment runs
     eagerly (first launches load code objects, which a capture must not do); the capture happens on the second call.
 
+    Kernel arguments that are passed by value - the env's configuration incl. the seed (env.seed()), the policy's std - are frozen
+    into a captured graph; collect() notices when they change (env.launch_params_generation, policy.std) and captures again.
+
     The returned tensors are views of the static buffers: they are overwritten by the next collect() (clone what must survive it,
     e.g. the last row of `dones` that the next segment's GAE takes as first_starts)."""
 
@@ -76,6 +79,10 @@ class GraphRollout(object):
         self.rewards, self.vpred, self.noise, self.logp = f(T, n), f(T, n), f(T, n, 12), f(T, n)
         self.dones = t.zeros((T, n), dtype=t.uint8, device=dev)
         self.graph, self.calls = None, 0
+        self._captured_for = None          # (env.launch_params_generation, policy.std) the graph was captured with
+
+    def _launch_params(self):
+        return (getattr(self.env, "launch_params_generation", 0), float(self.policy.std))
 
     def _segment(self):
         import math
@@ -101,7 +108,12 @@ class GraphRollout(object):
             if self.calls == 1:
                 self._segment()
             else:
+                # the captured launches carry the env's configuration (seed) and the policy's std as BY-VALUE kernel arguments: a graph
+                # captured before env.seed(new) / a new std would silently replay the old values - drop it and capture again
+                if self.graph is not None and self._captured_for != self._launch_params():
+                    self.graph = None
                 if self.graph is None:
+                    self._captured_for = self._launch_params()
                     counter = env._env_step_counter
                     self.graph = t.cuda.CUDAGraph()
                     with t.cuda.graph(self.graph):

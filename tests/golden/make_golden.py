@@ -247,9 +247,23 @@ class _Unpickler(pickle.Unpickler):
         return type(name, (_Stub,), {})
 
 
+def _clip_target_bounds(name):
+    """ImitationTask.get_target_obs_bounds (imitation_task.py:303-335) over the reference's own MotionData of one clip: root position
+    +-2, root rotation +-1, joint min / max over the frames, tiled over the four target frames."""
+    m = motion_data.MotionData(os.path.join(MOTIONS, name + ".txt"))
+    fr = np.asarray(m.get_frames())
+    jl, jh = fr[:, 7:].min(axis=0), fr[:, 7:].max(axis=0)
+    low = np.concatenate([-2 * np.ones(3), -np.ones(4), jl])
+    high = np.concatenate([2 * np.ones(3), np.ones(4), jh])
+    return np.tile(low, 4), np.tile(high, 4)
+
+
 def gen_spaces_and_policies():
     out = {}
-    for pol in ("laikago_pace", "minicheetah_trot"):
+    clips = sorted(f[:-4] for f in os.listdir(MOTIONS) if f.endswith(".txt"))
+    tb = {c: _clip_target_bounds(c) for c in clips}
+    match = {}
+    for pol in sorted(f[:-4] for f in os.listdir(POLICIES) if f.endswith(".zip")):
         with zipfile.ZipFile(os.path.join(POLICIES, pol + ".zip")) as z:
             data = json.loads(z.read("data"))
             for key in ("observation_space", "action_space"):
@@ -257,6 +271,16 @@ def gen_spaces_and_policies():
                 obj = _Unpickler(io.BytesIO(base64.b64decode(ser))).load()
                 out["%s/%s/low" % (pol, key)] = np.asarray(obj.__dict__["low"])
                 out["%s/%s/high" % (pol, key)] = np.asarray(obj.__dict__["high"])
+            # which clip was this policy trained on?  The zips carry no clip name; the 76 target-observation bounds pickled in them
+            # are those of the training clip (imitation_task.py:303-335, wrapper_env.py:127-145).  Every clip whose bounds agree to
+            # float32 is recorded (a clip and its time reversal have the same bounds); the zip's own name picks among them.
+            lo, hi = out["%s/observation_space/low" % pol][84:], out["%s/observation_space/high" % pol][84:]
+            err = {c: float(max(np.abs(lo - tb[c][0]).max(), np.abs(hi - tb[c][1]).max())) for c in clips}
+            same = sorted(c for c in clips if err[c] < 1e-6)
+            named = [c for c in same if pol.rstrip("0123456789") == c]
+            match[pol] = {"clip": (named or same)[0], "clips_with_equal_bounds": same,
+                          "max_abs_bound_difference": err[(named or same)[0]],
+                          "next_best": sorted((e, c) for c, e in err.items() if c not in same)[0][::-1]}
             params = np.load(io.BytesIO(z.read("parameters")))
             if pol == "laikago_pace":
                 # variable names, in the order stable-baselines saved them, with shapes (data): what a zip must contain for
@@ -267,6 +291,8 @@ def gen_spaces_and_policies():
             w = {k.replace("/", "__").replace(":", "_"): params[k].astype(np.float32) for k in params.files
                  if k.startswith("model/pi") }
             np.savez_compressed(os.path.join(HERE, "policy_%s.npz" % pol), **w)
+    with open(os.path.join(HERE, "policy_clips.json"), "w") as f:
+        json.dump(match, f, indent=1, sort_keys=True)
     np.savez_compressed(os.path.join(HERE, "spaces.npz"), **out)
 
 

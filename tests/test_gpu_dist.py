@@ -129,3 +129,100 @@ def test_train_loop_two_ranks_gloo_on_one_gpu(tmp_path):
     assert recs and recs[-1]["iter"] == 100 and recs[-1]["samples"] == 101 * 8 * 256 * 2      # both shards counted
     assert not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]                    # only rank 0 logs
     assert recs[-1]["episodes"] > 0 and os.path.exists(tmp_path / "p.zip")
+
+
+RCCL_LEARNER_WORKER = r"""
+import os, sys, torch
+sys.path.insert(0, %r)
+import torch.distributed as dist
+from openroborl_amd import dist as odist, learner_hip, ppo
+dev = torch.device("cuda:0")
+B, M = 16384, 4096
+def run():
+    model = ppo.ActorCritic(dev, seed=7)
+    g = torch.Generator().manual_seed(100)
+    obs = torch.randn(B, 160, generator=g).to(dev)
+    act = (torch.randn(B, 12, generator=g) * 0.2).to(dev)
+    adv, ret = torch.randn(B, generator=g).to(dev), torch.randn(B, generator=g).to(dev)
+    with torch.no_grad():
+        old = model.log_prob(obs, act) + 0.05 * adv
+    learner = learner_hip.FusedPPO(model, lr=1e-4, minibatch=M)
+    learner.sync()
+    gen = torch.Generator(device=dev); gen.manual_seed(3)
+    learner.update(obs, act, adv, ret, old_logp=old, epochs=2, generator=gen)
+    learner.check_synced()
+    # a new learning rate must reach the next update although the graphs were captured with the old one (ADVICE r3)
+    learner.lr = 3e-4
+    learner.update(obs, act, adv, ret, old_logp=old, epochs=1, generator=gen)
+    return learner, learner.flat_p.clone()
+if os.environ.get("ORR_FORCE_DIST"):
+    rank, world, local = odist.init_from_env()
+    assert dist.is_initialized() and dist.get_backend() == "nccl" and world == 1
+    learner, p = run()
+    assert learner._several() and len(next(iter(learner._plans.values()))["graphs"]) == B // M      # one graph per minibatch
+    dist.barrier(); dist.destroy_process_group()
+else:
+    learner, p = run()
+    assert not learner._several() and len(next(iter(learner._plans.values()))["graphs"]) == 1       # one graph per epoch
+torch.save(p.cpu(), sys.argv[1])
+print("learner ok")
+"""
+
+
+def test_fused_learner_several_ranks_path_through_rccl_one_rank(tmp_path):
+    """The several-ranks path of learner_hip.FusedPPO - per-minibatch graphs, all-reduce of the flat gradient IN PLACE ON THE DEVICE,
+    Adam between replays, the broadcast behind sync() / check_synced() - on the real RCCL backend with a one-rank group
+    (ORR_FORCE_DIST=1; the gloo rehearsals stage the gradient through the host and never touch these calls).  An all-reduce over one
+    rank is the identity, so the parameters must equal the no-group path (one graph per epoch) bit for bit, including after a
+    change of the learning rate, which both paths must pick up although their graphs were captured before it."""
+    import torch
+    script = tmp_path / "worker.py"
+    script.write_text(RCCL_LEARNER_WORKER % (ROOT,))
+    base = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    base.pop("ORR_FORCE_DIST", None)
+    plain = subprocess.run([sys.executable, str(script), str(tmp_path / "plain.pt")], env=base, capture_output=True, text=True, timeout=300)
+    assert plain.returncode == 0 and "learner ok" in plain.stdout, plain.stdout[-2000:] + plain.stderr[-3000:]
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(base, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ORR_FORCE_DIST="1")
+    rccl = subprocess.run([sys.executable, str(script), str(tmp_path / "rccl.pt")], env=env, capture_output=True, text=True, timeout=300)
+    assert rccl.returncode == 0 and "learner ok" in rccl.stdout, rccl.stdout[-2000:] + rccl.stderr[-3000:]
+    assert torch.equal(torch.load(tmp_path / "plain.pt"), torch.load(tmp_path / "rccl.pt"))
+
+
+def test_train_loop_through_rccl_one_rank(tmp_path):
+    """train.py, 20 iterations, as the multi-GPU run executes it (process group on nccl, sync(), per-minibatch graphs + device all-reduce,
+    check_synced, the episode all_gather of device buffers) with a one-rank group, against the same run without a group: the same
+    log lines and the same saved weights."""
+    import json
+    import torch
+    from openroborl_amd import policy as pol
+    cmd = [sys.executable, os.path.join(ROOT, "train.py"), "--num-robot", "256", "--horizon", "8", "--minibatch", "1024", "--iters", "20",
+           "--sync-check-every", "10"]
+    base = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    base.pop("ORR_FORCE_DIST", None)
+    plain = subprocess.run(cmd + ["--save", str(tmp_path / "plain.zip")], env=base, capture_output=True, text=True, timeout=600)
+    assert plain.returncode == 0, plain.stdout[-2000:] + plain.stderr[-3000:]
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(base, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ORR_FORCE_DIST="1")
+    rccl = subprocess.run(cmd + ["--save", str(tmp_path / "rccl.zip")], env=env, capture_output=True, text=True, timeout=600)
+    assert rccl.returncode == 0, rccl.stdout[-2000:] + rccl.stderr[-3000:]
+    strip = lambda out: [{k: v for k, v in json.loads(ln).items() if k != "sec"} for ln in out.splitlines() if ln.startswith("{")]   # noqa: E731
+    a, b = strip(plain.stdout), strip(rccl.stdout)
+    assert a and a[-1]["iter"] == 19 and a == b
+    pa, pb = pol.load_parameters(str(tmp_path / "plain.zip")), pol.load_parameters(str(tmp_path / "rccl.zip"))
+    assert sorted(pa) == sorted(pb) and all((pa[k] == pb[k]).all() for k in pa)
+
+
+def test_bench_launcher_through_rccl_one_rank():
+    """bench.py --spawn --gpus 1 with ORR_FORCE_DIST=1: launcher -> fresh torchrun child -> nccl init -> describe() -> barriers,
+    the MAX all-reduce of the elapsed time and the episode all_gather on RCCL - the chain the driver's 8-GPU run takes, with one rank."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ORR_FORCE_DIST="1", ORR_BENCH_WARMUP_FLOOR="200")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--spawn", "--gpus", "1", "--steps", "40", "--warmup", "5",
+                          "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["dist"] == {"backend": "nccl", "world": 1, "device_of_rank": [0]} and d["n_gpus"] == 1 and d["value"] > 1e6
+    assert d["config"]["episodes_gathered"] >= 0 and d["roofline"]["kernel_ms"] > 0

@@ -15,15 +15,18 @@ pytestmark = pytest.mark.gpu
 CLIP = {"laikago": "laikago_pace", "mini_cheetah": "minicheetah_trot"}
 
 
-def make_pair(robot="laikago", n=32, randomizer=False, auto_reset=False, seed=3, mode="test", mixed=None, legacy_grid=False):
+def make_pair(robot="laikago", n=32, randomizer=False, auto_reset=False, seed=3, mode="test", mixed=None, legacy_grid=False,
+              model_overrides=None):
     import torch
     from openroborl_amd.env import VecQuadrupedEnv
     if mixed:
         env = VecQuadrupedEnv(num_robot=n, seed=seed, mode=mode, enable_randomizer=randomizer, auto_reset=auto_reset,
-                              mixed_robots=mixed, motion_file=[CLIP[m] for m in mixed], legacy_grid=legacy_grid)
+                              mixed_robots=mixed, motion_file=[CLIP[m] for m in mixed], legacy_grid=legacy_grid,
+                              model_overrides=model_overrides)
     else:
         env = VecQuadrupedEnv(num_robot=n, seed=seed, robot=robot, motion_file=CLIP[robot], mode=mode,
-                              enable_randomizer=randomizer, auto_reset=auto_reset, legacy_grid=legacy_grid)
+                              enable_randomizer=randomizer, auto_reset=auto_reset, legacy_grid=legacy_grid,
+                              model_overrides=model_overrides)
     orc = ol.OracleEnv(env.cfg, env.models, env.clips, n, robot_type=env.robot_type, clip_id=env.clip_id, threads=8)
     return env, orc
 
@@ -69,13 +72,17 @@ def compare_fields(env, orc, names, atol, rtol=0.0, what=""):
 RIGID = ["POS", "QUAT", "LINVEL", "ANGVEL", "Q", "QD"]
 
 
-@pytest.mark.parametrize("robot", ["laikago", "mini_cheetah"])
-def test_physics_substep_parity(robot):
-    """Row C in isolation: ABA + contact/limit/friction rows + PGS + integration, fixed torques."""
+SOFT_TOES = {"contact_stiffness": 30000.0, "contact_damping": 1000.0, "foot_friction": 3.0}
+
+
+@pytest.mark.parametrize("robot,soft", [("laikago", False), ("mini_cheetah", False), ("laikago", True), ("mini_cheetah", True)])
+def test_physics_substep_parity(robot, soft):
+    """Row C in isolation: ABA + contact/limit/friction rows + PGS + integration, fixed torques.  soft: the toe's normal rows with
+    Bullet's contact stiffness / damping (cfm on the diagonal, own erp) and a friction coefficient of 3."""
     import torch
     from tests.parity_inputs import substep_parity_inputs
     n = 64
-    env, orc = make_pair(robot, n=n)
+    env, orc = make_pair(robot, n=n, model_overrides={robot: SOFT_TOES} if soft else None)
     env.reset(); orc.reset()
     _, _, _, st, tau = substep_parity_inputs(robot, n)       # the same seeded inputs tools/pybullet_ref.py feeds to PyBullet
     push_state(env, st); orc.state[:] = st
@@ -606,6 +613,42 @@ def test_non_finite_state_is_caught_by_the_state_guard(auto_reset):
         assert torch.isfinite(obs).all()                       # the reset observation
         assert torch.isfinite(env.state[:, :lay.sl("RING").start]).all()
     else:
+        env.reset(bad.to(torch.uint8))
+    obs, rew, done, _ = env.step(a)
+    assert torch.isfinite(obs).all() and torch.isfinite(rew).all() and not done.any()
+    env.close()
+
+
+@pytest.mark.parametrize("auto_reset", [True, False])
+def test_non_finite_action_is_caught_by_the_action_guard(auto_reset):
+    """The third entry of the non-finite guard: the ACTION.  The +-0.2 rad clip of the motor command is fmin / fmax, which silently drops
+    a NaN, while the last-action sensor and the Butterworth history would keep it for the rest of the episode: orr_step records a NaN /
+    inf action like a non-finite incoming state (ORR_DONE_NAN, reward 0) and computes with 0 in its place, so nothing non-finite
+    enters the state record or the observation.  Neighbours in the same wavefront (robots 3..7 share waves with 0..2) are untouched:
+    their step equals the step of the same batch with clean actions bit for bit."""
+    import torch
+    n = 8
+    env, orc = make_pair("laikago", n=n, auto_reset=auto_reset, seed=6)
+    orc.close()
+    env.reset()
+    start = env.state_dict()
+    a = torch.zeros(n, 12, device=env.device)
+    obs_c, rew_c, done_c = (x.clone() for x in env.step(a)[:3])
+    clean = env.state.clone()
+    env.load_state_dict(start)
+    a_bad = a.clone()
+    a_bad[0, 3] = float("nan"); a_bad[1, 0] = float("inf"); a_bad[2, 11] = float("-inf")
+    obs, rew, done, _ = env.step(a_bad)
+    torch.cuda.synchronize()
+    bad = torch.tensor([1, 1, 1, 0, 0, 0, 0, 0], dtype=torch.bool, device=env.device)
+    reason = env.field_int("DONE_REASON")[:, 0]
+    print("NAN_ACTION_GUARD auto_reset=%s reasons %s" % (auto_reset, reason.cpu().numpy().tolist()))
+    assert done.bool()[bad].all() and ((reason[bad] & _abi.DONE_NAN) != 0).all() and (rew[bad] == 0).all()
+    assert torch.equal(obs[~bad], obs_c[~bad]) and torch.equal(rew[~bad], rew_c[~bad]) and torch.equal(done[~bad], done_c[~bad])
+    assert torch.equal(env.state[~bad], clean[~bad])
+    lay = env.layout
+    assert torch.isfinite(obs).all() and torch.isfinite(env.state[:, :lay.sl("RING").start]).all()    # nothing non-finite was stored
+    if not auto_reset:
         env.reset(bad.to(torch.uint8))
     obs, rew, done, _ = env.step(a)
     assert torch.isfinite(obs).all() and torch.isfinite(rew).all() and not done.any()

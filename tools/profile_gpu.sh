@@ -10,6 +10,7 @@ EXTRA=${3:-}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
+python3 -c "import sys; sys.path.insert(0, '$ROOT'); from openroborl_amd import _lib; print(_lib.library_hash())" > $OUT/source_hash.txt
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $ROOT/bench.py --config $CFG --steps 40 --warmup 10 --no-cpu-baseline $EXTRA"
 BENCH_TRACE="python3 $ROOT/bench.py --config $CFG --no-cpu-baseline $EXTRA"   # = the default bench.py run

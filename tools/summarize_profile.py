@@ -51,5 +51,11 @@ if "FETCH_SIZE" in summary and "WRITE_SIZE" in summary:
     fe, wr = summary["FETCH_SIZE"]["mean_per_launch"] * 1024, summary["WRITE_SIZE"]["mean_per_launch"] * 1024
     summary["hbm_bytes_per_launch"] = fe + wr
     summary["hbm_bytes_per_launch_fetch_x2"] = 2 * fe + wr
+# which kernel sources the counters belong to: tools/profile_gpu.sh records the hash of the library the profiled command loaded;
+# bench.py refuses a summary whose hash differs from its own library's ("pmc_stale")
+try:
+    summary["source_hash"] = open(os.path.join(src, "source_hash.txt")).read().strip()
+except OSError:
+    summary["source_hash"] = None
 json.dump(summary, open(os.path.join(dst, name + "_pmc_summary.json"), "w"), indent=1, sort_keys=True)
 print(json.dumps(summary, indent=1, sort_keys=True)[:3000])

@@ -38,6 +38,11 @@ def main():
     ap.add_argument("--legacy-gae-index", action="store_true",
                     help="reproduce the reference's neighbouring-robot episode-start index in the GAE recursion (ppo_imitation.py:88); "
                          "only for curve-by-curve comparisons with the reference at num_robot > 1")
+    ap.add_argument("--mpi-adam", action="store_true",
+                    help="the reference's MpiAdam arithmetic (stable_baselines/common/mpi_adam.py:53-58: epsilon outside the bias correction, i.e. "
+                         "NOT scaled by sqrt(1 - beta2^t)) instead of torch.optim.Adam's; with adam_epsilon 1e-5 (run.py:118) the reference's "
+                         "effective epsilon is ~30x larger in the first steps.  Default off: the recorded training runs used torch's form")
+    ap.add_argument("--sync-check-every", type=int, default=100, help="replica consistency check (MpiAdam.check_synced, mpi_adam.py:47-48: every 100 updates)")
     ap.add_argument("--tune-gemms", action="store_true", help="let PyTorch's TunableOp pick the learner's GEMM kernels (graph-replayed learner: 16.8 -> 16.3 ms per iteration after ~3 s of tuning)")
     args = ap.parse_args()
 
@@ -63,7 +68,16 @@ def main():
         learner = ppo.PPO(model, lr=args.lr, minibatch=args.minibatch)
     else:
         from openroborl_amd import learner_hip
-        learner = learner_hip.FusedPPO(model, lr=args.lr, minibatch=args.minibatch)
+        # equal minibatches only (static buffers of the graph-replayed update): the largest size <= --minibatch that divides the
+        # segment, e.g. --num-robot 1000 x horizon 32 = 32000 samples run as 2 x 16000 instead of failing on 16384
+        mb = learner_hip.FusedPPO.fit_minibatch(args.num_robot * args.horizon, args.minibatch)
+        if mb != min(args.minibatch, args.num_robot * args.horizon) and rank == 0:
+            print("train.py: minibatch %d -> %d (must divide the %d samples of a segment)" % (args.minibatch, mb, args.num_robot * args.horizon),
+                  file=sys.stderr)
+        if mb < 256 and args.num_robot * args.horizon >= 4096:
+            raise SystemExit("train.py: %d samples per segment have no divisor between 256 and %d; pick another --num-robot / --horizon "
+                             "or use --torch-learner (handles a short last minibatch)" % (args.num_robot * args.horizon, args.minibatch))
+        learner = learner_hip.FusedPPO(model, lr=args.lr, minibatch=mb, mpi_adam_epsilon=args.mpi_adam)
         learner.sync()                                        # MpiAdam.sync before training (ppo_imitation.py:274)
     gen = torch.Generator(device=dev)
     gen.manual_seed(args.seed * 1000 + rank)
@@ -89,7 +103,8 @@ def main():
                                   ret.reshape(-1), old_logp=buf["logp"].reshape(-1) if "logp" in buf else None,
                                   epochs=args.epochs, generator=gen)
         samples += T * n * world
-        if world > 1 and it % 100 == 99 and hasattr(learner, "check_synced"):
+        # (> 1 rank, or ORR_FORCE_DIST=1: the one-rank rehearsal of the several-ranks path on RCCL runs the check too)
+        if (world > 1 or os.environ.get("ORR_FORCE_DIST")) and it % args.sync_check_every == args.sync_check_every - 1 and hasattr(learner, "check_synced"):
             learner.check_synced()                            # like MpiAdam every 100 updates (mpi_adam.py:47-48)
         stats = odist.gather_env_episodes(env, args.horizon)   # means come from the exact per-rank sums, not the truncated list
         if rank == 0 and (it % 10 == 0 or it == args.iters - 1):
@@ -106,7 +121,7 @@ def main():
         with open(args.log, "w") as f:
             json.dump(log, f, indent=1)
     env.close()
-    if world > 1:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 
