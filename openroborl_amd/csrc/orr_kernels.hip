@@ -51,6 +51,16 @@ __device__ long long g_wave_timeline[4 * 2048];   // per wave of the last launch
 #define PT_TIMELINE(flag)
 #endif
 
+// Development aid (tools/dual_contact.py): -DORR_COUNT_DUAL_CONTACT counts, per leg and sub-step, how often the toe sphere and the shank
+// sphere of a lower leg are within the contact margin / penetrating at the same time (the engine makes ONE contact point per leg, Bullet
+// one per touching shape: DESIGN.md section 9).  One-wave kernel only.
+#if defined(ORR_COUNT_DUAL_CONTACT) && !defined(ORR_TU_STEP_W2)
+__device__ unsigned long long g_dual_contact[8];
+#define ORR_DUAL_COUNT(k, cond) do { const unsigned long long b_ = __ballot(cond); if (threadIdx.x == 0 && b_) atomicAdd(&g_dual_contact[k], (unsigned long long)__popcll(b_)); } while (0)
+#else
+#define ORR_DUAL_COUNT(k, cond)
+#endif
+
 using namespace orr;
 
 #define O(name) ORR_OFF_##name
@@ -817,6 +827,18 @@ int32_t orr_time_steps(orr_handle* h, const float* actions_dev, float* obs_dev, 
   return 0;
 }
 
+#if defined(ORR_COUNT_DUAL_CONTACT)
+// development aid: read (and optionally clear) the toe / shank contact counters of the -DORR_COUNT_DUAL_CONTACT build
+int orr_debug_dual_contact(unsigned long long* out8, int reset) {
+  HIPCHK(hipDeviceSynchronize(), "orr_debug_dual_contact: sync");
+  HIPCHK(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_dual_contact), 8 * sizeof(unsigned long long)), "orr_debug_dual_contact: read");
+  if (reset) {
+    unsigned long long z[8] = {0};
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_dual_contact), z, sizeof(z)), "orr_debug_dual_contact: clear");
+  }
+  return 0;
+}
+#endif
 #ifdef ORR_PHASE_TIMERS
 // development aid: read (and optionally clear) the per-phase cycle totals of the instrumented wave
 int orr_debug_phase_cycles(long long* out40, int reset) {

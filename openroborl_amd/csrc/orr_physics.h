@@ -484,6 +484,17 @@ __device__ __forceinline__ void row_setup(const Shared& S, const orr_config& cfg
     const bool shank = S.m.shank_radius > 0.0f && dist_s < dist_t;
     const float dist = shank ? dist_s : dist_t;
     R.active = dist < cfg.contact_margin;
+    {   // instrumented build only (tools/dual_contact.py): normal-row lanes count the leg-sub-steps by which spheres touch
+      const bool cnt = enable && d == 0, has_s = S.m.shank_radius > 0.0f;
+      const bool t_in = dist_t < cfg.contact_margin, s_in = has_s && dist_s < cfg.contact_margin;
+      ORR_DUAL_COUNT(0, cnt);                                        // leg-sub-steps
+      ORR_DUAL_COUNT(1, cnt && (t_in || s_in));                      // ... with a contact row
+      ORR_DUAL_COUNT(2, cnt && t_in && s_in);                        // both spheres within the contact margin (Bullet: two contact points)
+      ORR_DUAL_COUNT(3, cnt && dist_t < 0.0f && has_s && dist_s < 0.0f);   // both spheres penetrating
+      ORR_DUAL_COUNT(4, cnt && s_in && !t_in);                       // shank only
+      ORR_DUAL_COUNT(5, cnt && shank && R.active);                   // the row was made at the shank sphere
+      (void)cnt; (void)has_s; (void)t_in; (void)s_in;
+    }
     const float Pw[3] = {(shank ? cs[0] : cw[0]) + Lb.ow[0], (shank ? cs[1] : cw[1]) + Lb.ow[1], dist};
     const float dir[3] = {d == 1 ? 1.0f : 0.0f, d == 2 ? 1.0f : 0.0f, d == 0 ? 1.0f : 0.0f};
     float rr[3] = {Pw[0] - S.s[O(POS)], Pw[1] - S.s[O(POS) + 1], Pw[2] - S.s[O(POS) + 2]};

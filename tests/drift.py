@@ -81,18 +81,148 @@ def format_table(tab, title=""):
     return "\n".join(lines)
 
 
-# HIP quantile <= FACTOR x float32-oracle quantile + FLOOR (a few float32 ulps, for fields where the float32 oracle happens to be exact).
-# Two float32 builds of the SAME source (-O2 vs -O3 -march=native) differ from each other by 0.4-1.4x on the median / p99 and
-# 0.2-4.4x on the max over 1024 robots (heavy tail), measured on the CPU; HIP vs the -O2 build on the GPU box: 0.5-1.0 / 0.3-2.1 / 0.1-2.1.
-# The tail quantiles are a handful of robots in chaotic contact states: an unrelated change of the kernel's rounding (one 6x6 solve
-# re-associated) moved a p99 ratio from 1.08 to 2.05, so only the MEDIAN is held to the factor of 2; p99 gets 3.  The MAX over 1024
-# robots is asserted (factor 10) only for the rigid state: the task-level fields (reference pose, target observation, reward) contain
-# discrete events - the cycle sync re-anchors the reference origin in the step where the phase wraps, quaternions are standardised to
-# w >= 0 - which ONE robot of a thousand takes a step earlier or later than the float64 oracle (seen: target-observation max 1.0 in the
-# HIP run and 0.13 in the float32 oracle after a recompile that changed nothing but instruction scheduling); they are reported only.
-FACTOR = {"median": 2.0, "p99": 3.0, "max": 10.0}
+# ---- the floor's own spread ---------------------------------------------------------------------------------------
+# How much do two float32 evaluations of the SAME algorithm on the SAME sample differ from each other?  K float32 runs of the oracle
+# from start states that differ from the test's start by one float32 ulp per rigid-state component (random sign), plus the
+# -O3 -march=native build from the unperturbed start: each gives a quantile per field / horizon; the largest ratio between any two of
+# them is what "float32 noise" does to that quantile, and that ratio x (1 + MARGIN) is the factor the HIP path is held to
+# (tools/drift_floor_spread.py writes tests/golden/drift_factors.json and profiles/r04_drift_floor_spread_<robot>.txt on the GPU box, from
+# the start states of the HIP reset: the test's exact sample).  Round 3's factors (2 / 3 / 10, loosened twice after red runs) are gone.
+MARGIN = 0.25
+FACTOR_MIN = 1.5          # a quantile the K runs happen to agree on to 1 % still gets a sane factor
 MAX_ASSERTED = ("POS", "QUAT", "Q", "LINVEL", "ANGVEL", "QD")
+TASK_LEVEL = ("REF_POSE", "obs_target", "reward")     # fields with discrete events (cycle sync, quaternion standardisation): see OUTLIER_X
+# task-level fields: a robot that takes a discrete event (the cycle sync re-anchors the reference origin in the step where the phase
+# wraps) one step earlier or later than the float64 oracle shows an error of the size of the event, not of float32 noise.  Their max is
+# therefore not a quantile of a noise distribution; instead the NUMBER of such robots (error > OUTLIER_X x the p99 of the unperturbed
+# float32 run) is bounded by what the K float32 runs show: max_k count_k + 3 sqrt(mean_k count_k) + 1 (the counts are Poisson-like).
+OUTLIER_X = 10.0
 FLOOR = 2e-6
+_FACTORS = None
+
+
+def perturb_one_ulp(state32, lay, rng):
+    """A copy of the float32 state with every rigid-state component (POS .. QD) moved by one ulp, random direction."""
+    out = state32.copy()
+    lo, hi = lay.sl("POS").start, lay.sl("QD").stop
+    x = out[:, lo:hi]
+    sign = np.where(rng.rand(*x.shape) < 0.5, -np.inf, np.inf).astype(np.float32)
+    out[:, lo:hi] = np.nextafter(x, sign)
+    return out
+
+
+def run_family(orc64, floors, lay, models, robot_type, steps, seed=0, noise=0.125, dev_step=None, dev_state64=None, actions=None):
+    """Advance the float64 oracle, every float32 run in `floors` and (optionally) the device with identical actions (driven by the float64
+    oracle's observation, as in run_three_way).  -> {horizon: {name: [err_k[n] for k in floors (+ device last)]}}, {horizon: alive[n]}."""
+    n = orc64.n
+    rng = np.random.RandomState(seed)
+    obs64 = orc64.obs.copy()
+    alive = np.ones(n, dtype=bool)
+    out, alive_at = {}, {}
+    for k in range(steps):
+        a = actions[k] if actions is not None else reference_tracking_actions(obs64, models, robot_type, rng, noise)
+        sides = [f.step(a) for f in floors]
+        if dev_step is not None:
+            sides.append(dev_step(a))
+        obs64, r64, d64 = orc64.step(a.astype(np.float64))
+        h = k + 1
+        if h in HORIZONS or h == steps:
+            states = [f.state.astype(np.float64) for f in floors] + ([dev_state64()] if dev_step is not None else [])
+            rec = {}
+            for name in FIELDS:
+                sl = lay.sl(name)
+                rec[name] = [np.abs(s[:, sl] - orc64.state[:, sl]).max(axis=1) for s in states]
+            for name, sl in OBS_GROUPS:
+                rec[name] = [np.abs(np.asarray(o, dtype=np.float64)[:, sl] - obs64[:, sl]).max(axis=1) for o, _, _ in sides]
+            rec["reward"] = [np.abs(np.asarray(r, dtype=np.float64) - r64) for _, r, _ in sides]
+            out[h] = rec
+            alive_at[h] = alive.copy()
+        for _, _, d in sides:
+            alive &= ~np.asarray(d, dtype=bool)
+        alive &= ~np.asarray(d64, dtype=bool)
+    return out, alive_at
+
+
+def spread_table(out, alive_at, n_floor):
+    """Per horizon / field / quantile over the first n_floor runs (run 0 = the unperturbed parity build the test compares with):
+    q0, min, max, the largest ratio between two runs and the factor derived from it; per task-level field the outlier counts."""
+    names = list(FIELDS) + [g for g, _ in OBS_GROUPS] + ["reward"]
+    tab = {}
+    for h in sorted(out):
+        m = alive_at[h]
+        tab[h] = {"alive": int(m.sum())}
+        for name in names:
+            errs = [e[m] for e in out[h][name]]
+            row = {}
+            for q, pct in QUANTS:
+                v = np.array([np.percentile(e, pct) for e in errs[:n_floor]])
+                lo = max(float(v.min()), FLOOR)
+                ratio = max(float(v.max()), FLOOR) / lo
+                row[q] = {"q0": float(v[0]), "min": float(v.min()), "max": float(v.max()), "max_ratio_between_two_runs": ratio,
+                          "factor": max(FACTOR_MIN, ratio * (1.0 + MARGIN))}
+                if len(errs) > n_floor:
+                    row[q]["device"] = float(np.percentile(errs[n_floor], pct))
+            if name in TASK_LEVEL:
+                thr = OUTLIER_X * max(float(np.percentile(errs[0], 99.0)), FLOOR)
+                counts = [int((e > thr).sum()) for e in errs[:n_floor]]
+                row["outliers"] = {"threshold": thr, "counts": counts,
+                                   "limit": int(max(counts) + np.ceil(3.0 * np.sqrt(np.mean(counts))) + 1)}
+                if len(errs) > n_floor:
+                    row["outliers"]["device"] = int((errs[n_floor] > thr).sum())
+            tab[h][name] = row
+    return tab
+
+
+def format_spread(tab, title=""):
+    lines = [title, "%-22s %3s %6s %-6s | %9s %9s %9s | %8s %7s | %9s %6s" % (
+        "field", "h", "alive", "quant", "f32 run 0", "min", "max", "max/min", "factor", "HIP", "HIP/q0")]
+    for h in sorted(tab):
+        for name in list(FIELDS) + [g for g, _ in OBS_GROUPS] + ["reward"]:
+            for q, _ in QUANTS:
+                r = tab[h][name][q]
+                dev = r.get("device")
+                lines.append("%-22s %3d %6d %-6s | %9.2e %9.2e %9.2e | %8.2f %7.2f | %9s %6s" % (
+                    name, h, tab[h]["alive"], q, r["q0"], r["min"], r["max"], r["max_ratio_between_two_runs"], r["factor"],
+                    "-" if dev is None else "%.2e" % dev, "-" if dev is None else "%.2f" % (dev / max(r["q0"], 1e-30))))
+            if "outliers" in tab[h][name]:
+                o = tab[h][name]["outliers"]
+                lines.append("%-22s %3d %6d %-6s | robots beyond %.2e: f32 runs %s -> limit %d | HIP %s" % (
+                    name, h, tab[h]["alive"], "events", o["threshold"], o["counts"], o["limit"], o.get("device", "-")))
+    return "\n".join(lines)
+
+
+RING_GROUPS = (("angles+quat", slice(0, 16)), ("base rates", slice(16, 19)))
+
+
+def ring_errors(state64, ref64, lay, mask, depth, entry):
+    """Per robot: largest difference of the latency ring's contents from the float64 oracle's, per group of entry columns."""
+    sl = lay.sl("RING")
+    a, b = state64[mask][:, sl].reshape(-1, depth, entry), ref64[mask][:, sl].reshape(-1, depth, entry)
+    return {name: np.abs(a[:, :, cols] - b[:, :, cols]).max(axis=(1, 2)) for name, cols in RING_GROUPS}
+
+
+def ring_spread(per_run):
+    """per_run: [ring_errors(...) of each float32 run] -> {group: {quantile: {q0, min, max, max_ratio_between_two_runs, factor}}}."""
+    tab = {}
+    for name, _ in RING_GROUPS:
+        tab[name] = {}
+        for q, pct in (("median", 50.0), ("max", 100.0)):
+            v = np.array([np.percentile(r[name], pct) for r in per_run])
+            ratio = max(float(v.max()), FLOOR) / max(float(v.min()), FLOOR)
+            tab[name][q] = {"q0": float(v[0]), "min": float(v.min()), "max": float(v.max()), "max_ratio_between_two_runs": ratio,
+                            "factor": max(FACTOR_MIN, ratio * (1.0 + MARGIN))}
+    return tab
+
+
+def factors(robot):
+    """The committed factor table of `robot` (tests/golden/drift_factors.json)."""
+    global _FACTORS
+    if _FACTORS is None:
+        import json
+        import os
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "drift_factors.json")) as f:
+            _FACTORS = json.load(f)
+    return _FACTORS[robot]
 
 
 SMALL_SAMPLE = (("median", 50.0, 2.0), ("p90", 90.0, 3.0))     # tests with 64-256 robots: the max of a heavy-tailed sample is one robot's chaos
