@@ -56,7 +56,9 @@ __device__ long long g_wave_timeline[4 * 2048];   // per wave of the last launch
 // one per touching shape: DESIGN.md section 9).  One-wave kernel only.
 #if defined(ORR_COUNT_DUAL_CONTACT) && !defined(ORR_TU_STEP_W2)
 __device__ unsigned long long g_dual_contact[8];
-#define ORR_DUAL_COUNT(k, cond) do { const unsigned long long b_ = __ballot(cond); if (threadIdx.x == 0 && b_) atomicAdd(&g_dual_contact[k], (unsigned long long)__popcll(b_)); } while (0)
+// (called inside the contact branch of row_setup, where lanes 0..3 of every robot are inactive: the first ACTIVE lane adds the wave's count)
+#define ORR_DUAL_COUNT(k, cond) do { const unsigned long long b_ = __ballot(cond), act_ = __ballot(1); \
+    if (b_ && (int)(threadIdx.x & 63u) == __ffsll((long long)act_) - 1) atomicAdd(&g_dual_contact[k], (unsigned long long)__popcll(b_)); } while (0)
 #else
 #define ORR_DUAL_COUNT(k, cond)
 #endif
