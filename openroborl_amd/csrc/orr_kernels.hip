@@ -234,6 +234,19 @@ __global__ __launch_bounds__((MODE == 0 && WPE == 1 ? 64 * ORR_WPB : 64)) __attr
   // (0.332 / 0.332 / 0.335; tools/build_variants.py: -DORR_PRIO_SHIFT=n, -DORR_NO_PRIO_ALTERNATION).
   const int prio_phase = WPE == 2 ? (int)(((unsigned)wave_id / (unsigned)(P.simds > 0 ? P.simds : 1)) & 1u) : 0;
 #endif
+  // What the PD law of a sub-step reads - the delayed angle of the lane's motor (control observation), the joint's true angle and rate -
+  // is produced at the END of the previous sub-step: the control-observation word by this very lane, angle and rate by the integration
+  // (read from LDS there anyway, for the ring entry).  Carried over in registers (ORR_CARRY_PD), the top of the loop has no LDS round
+  // trip of its own: a lone wave has nothing to overlap one with there.  Same values, bit for bit.  4096 robots 0.2235 -> 0.2205 ms.
+  // ONE-wave build only: with two waves per SIMD the partner wave fills those gaps anyway and the three registers carried across the
+  // whole sub-step cost more than they save (8192 robots 0.3130 -> 0.3160 ms with it).  Measured and NOT kept in the one-wave build:
+  // carrying the base rotation the same way (nine words that leg_dynamics reads back from LDS: 0.2206, neutral), and issuing the loads
+  // of the leg dynamics' first reads (base rotation / velocity, own joint angle, the leg's joint rates: 19 registers) in front of the
+  // PD law (0.2208 -> 0.2223: worse).
+#ifndef ORR_CARRY_PD
+#define ORR_CARRY_PD (WPE == 1)
+#endif
+  float co_own = S.co[ml], qm_c = (S.s[O(Q) + mj] - m_off) * m_dir, qdm_c = S.s[O(QD) + mj] * m_dir;
   for (int sstep = 0; sstep < c.action_repeat; sstep++) {
 #ifndef ORR_NO_PRIO_ALTERNATION
 #ifndef ORR_PRIO_SHIFT
@@ -244,12 +257,13 @@ __global__ __launch_bounds__((MODE == 0 && WPE == 1 ? 64 * ORR_WPB : 64)) __attr
     if (kLanes != 16 && sstep > 0) ctrl_obs(P, rec, S, lane);
     {  // every lane (no divergent `if`: it would cost more than it skips); lanes 12..15 repeat motor 0 and store into dump slots
       const float lerp = (float)(sstep + 1) * inv_repeat;  // process_action (minitaur.py:438-460)
-      const float cur = map_pi(S.co[ml]);
+      const bool carry = ORR_CARRY_PD && kLanes == 16;
+      const float cur = map_pi(carry ? co_own : S.co[ml]);
       const float prev = m_has_prev ? m_prev : cur;
       float cmd = prev + lerp * (m_target - prev);
       cmd = fminf(fmaxf(cmd, cur - c.max_angle_change), cur + c.max_angle_change);  // _clip_motor_commands (:706-723)
-      const float qm = (S.s[O(Q) + mj] - m_off) * m_dir;  // pd latency 0 (:359-363)
-      const float qdm = S.s[O(QD) + mj] * m_dir;
+      const float qm = carry ? qm_c : (S.s[O(Q) + mj] - m_off) * m_dir;  // pd latency 0 (:359-363)
+      const float qdm = carry ? qdm_c : S.s[O(QD) + mj] * m_dir;
       // MotorModel.convert_to_torque, POSITION mode (minitaur_motor.py:163-171)
       S.tau[lane < 12 ? mj : lane] = m_gain * (-1.0f * (m_kp * (qm - cmd)) - m_kd * qdm);
     }
@@ -268,7 +282,9 @@ __global__ __launch_bounds__((MODE == 0 && WPE == 1 ? 64 * ORR_WPB : 64)) __attr
         fall = RP.fall[robot];
       } else
       fall = physics_substep(P, S, K, lane, sub, sstep == c.action_repeat - 1, X, limit_idle);
-      ring_push_and_ctrl_obs(rec, S, lane, valid, F, ring, (S.s[O(Q) + mj] - m_off) * m_dir);
+      qm_c = (S.s[O(Q) + mj] - m_off) * m_dir;
+      qdm_c = S.s[O(QD) + mj] * m_dir;
+      ring_push_and_ctrl_obs(rec, S, lane, valid, F, ring, qm_c, &co_own);
     } else {
       fall = physics_substep(P, S, K, lane, sub, sstep == c.action_repeat - 1, X, limit_idle);
       receive_obs(P, rec, S, lane, valid);

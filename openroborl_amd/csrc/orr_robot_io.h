@@ -162,8 +162,10 @@ __device__ __forceinline__ void ring_prefetch(const RingLatency& L, const float*
   F.e1[0] = p1[lane]; F.e1[1] = p1[hi];
 }
 // mang: this lane's true motor angle (lane < 12), computed by the caller from its register copy of the motor constants
+// co_own (optional): receives the control-observation word this lane computes (S.co[lane]: the delayed motor angle of motor `lane`
+// for lanes < 12), so that the PD law of the next sub-step need not read it back from LDS
 __device__ __forceinline__ void ring_push_and_ctrl_obs(float* rec, Shared& S, int lane, bool valid, const RingFetch& F, RingCursor& C,
-                                                       float mang) {
+                                                       float mang, float* co_own = nullptr) {
   static_assert(ORR_RING_ENTRY == 20, "lane mapping below assumes 20-word entries");
   C.head = ring_wrap_up(C.head + 1);
   C.len = C.len + 1 > ORR_RING_DEPTH ? ORR_RING_DEPTH : C.len + 1;
@@ -176,7 +178,9 @@ __device__ __forceinline__ void ring_push_and_ctrl_obs(float* rec, Shared& S, in
   const float vb = pick4(lane, rate[0], rate[1], rate[2], 0.0f);   // lanes >= 4: never stored
   const float a0 = F.new0 ? va : F.e0[0], a1 = F.new1 ? va : F.e1[0];
   const float b0 = F.new0 ? vb : F.e0[1], b1 = F.new1 ? vb : F.e1[1];
-  S.co[lane] = F.same ? a0 : (1.0f - F.al) * a0 + F.al * a1;
+  const float co_a = F.same ? a0 : (1.0f - F.al) * a0 + F.al * a1;
+  S.co[lane] = co_a;
+  if (co_own) *co_own = co_a;
   S.co[lane < 3 ? 16 + lane : 19] = F.same ? b0 : (1.0f - F.al) * b0 + F.al * b1;   // lanes >= 3: the pad word (no divergent `if`)
   WSYNC();
   // the push is stored AFTER the prefetched entries were consumed: loads and stores share one in-order counter (vmcnt) on this

@@ -88,6 +88,15 @@ def run(pol, clip, robot, n, seed, steps=600, ref_state_init_prob=None, model_ov
     warm = env.field_int("WARMUP")[:, 0].clone().bool()
     dur = env.clips[0].frame_duration * (env.clips[0].num_frames - 1)
     phase0 = (env.field("TIME_OFFSET")[:, 0].clone() / dur) % 1.0
+    # what the teleport into the reference state does to the robot in its very first sub-step (zero motor torques): normal impulses per
+    # leg and the change of the base's vertical velocity - the reference pose may put toes into the ground (the contact rows then push them
+    # out with erp x depth / dt) or leave the robot in the air
+    start = env.state.clone()
+    vz0 = env.field("LINVEL")[:, 2].clone()
+    env.debug_physics(torch.zeros(n, 12, device=dev), 1)
+    kick = (env.field("LINVEL")[:, 2] - vz0).clone()
+    lam_n = env.field("LAMBDA")[:, 0::3].clone()                 # normal impulse per leg [N s]
+    env.state.copy_(start)
     alive = torch.ones(n, dtype=torch.bool, device=dev)
     length = torch.zeros(n, device=dev)
     ret = torch.zeros(n, device=dev)
@@ -131,8 +140,31 @@ def run(pol, clip, robot, n, seed, steps=600, ref_state_init_prob=None, model_ov
            "fall_step_histogram": {"edges": [0, 5, 10, 20, 40, 80, 160, 320, 600],
                                    "counts": np.histogram(ln[~al], bins=[0, 5, 10, 20, 40, 80, 160, 320, 600])[0].tolist()},
            "fall_step_histogram_warmup": np.histogram(ln[(~al) & wm], bins=[0, 5, 10, 20, 40, 80, 160, 320, 600])[0].tolist()}
+    # reference-state-init episodes by the clip phase they start in, 32 bins: finished fraction, legs with a ground contact in the first
+    # sub-step, largest normal impulse [N s] and vertical velocity change [m/s] of that sub-step
+    kc, ln_ = kick.cpu().numpy(), lam_n.cpu().numpy()
+    detail = []
+    for k in range(32):
+        m = (~wm) & (ph >= k / 32.0) & (ph < (k + 1) / 32.0)
+        if m.sum() == 0:
+            detail.append(None)
+            continue
+        detail.append({"phase": (k + 0.5) / 32.0, "episodes": int(m.sum()), "finished": float(al[m].mean()),
+                       "legs_in_contact": float((ln_[m] > 0).sum(axis=1).mean()), "max_normal_impulse": float(ln_[m].max(axis=1).mean()),
+                       "dvz_first_substep": float(kc[m].mean())})
+    out["by_reset_phase_32"] = detail
     env.close()
     return out
+
+
+def fmt_phase(o):
+    lines = ["  %s on %s: reference-state-init episodes by the clip phase at reset (finished | legs in contact, max normal impulse [N s], dvz [m/s] "
+             "of the first sub-step)" % (o["policy"], o["clip"])]
+    for d in o["by_reset_phase_32"]:
+        if d:
+            lines.append("    phase %.3f  n %3d  finished %.2f | %.1f legs  %.4f N s  %+.3f m/s" % (
+                d["phase"], d["episodes"], d["finished"], d["legs_in_contact"], d["max_normal_impulse"], d["dvz_first_substep"]))
+    return "\n".join(lines)
 
 
 def fmt(o):
@@ -266,6 +298,8 @@ def main():
             o["clip_is_the_zip_name"] = named
             res["rows"].append(o)
             print(fmt(o), flush=True)
+            if named and seed == args.seeds[0] and pol in ("minicheetah_trot", "laikago_pace"):
+                print(fmt_phase(o), flush=True)
         if not args.no_controls and named:
             for p in (1.0, 0.0):
                 o = run(pol, clip, robot, args.robots, args.seeds[0], ref_state_init_prob=p)
