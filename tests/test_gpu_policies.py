@@ -1,0 +1,64 @@
+"""All five PyBullet-trained policies the reference ships (task/policies/*.zip), on the HIP path, with their levels pinned BOTH ways.
+
+They are the only PyBullet-derived artefacts in the reference tree, i.e. the only behavioural evidence about SURVEY 8a row C that exists
+here.  `laikago_pace` and `minicheetah_trot` walk the 600-step episode; the three that no table entry was ever
+tuned against - `laikago_spin`, `laikago_trot`, `laikago_trot0` - fall on this engine.  That is a finding, not something to hide or to
+fit away: the test asserts the measured level of each, so that any change of the engine or of a table that moves one of them - in either
+direction - fails here and has to be looked at (and written up)."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def test_every_shipped_zip_is_matched_to_exactly_one_clip_pair():
+    """The zips carry no clip name; the 76 target-observation bounds pickled in them single out the training clip (and its time reversal)."""
+    with open(os.path.join(ROOT, "tests", "golden", "policy_clips.json")) as f:
+        match = json.load(f)
+    assert sorted(match) == ["laikago_pace", "laikago_spin", "laikago_trot", "laikago_trot0", "minicheetah_trot"]
+    for pol, m in match.items():
+        assert m["max_abs_bound_difference"] < 1e-6 and m["next_best"][1] > 0.2, (pol, m)
+        assert m["clip"] == pol.rstrip("0") and 1 <= len(m["clips_with_equal_bounds"]) <= 2
+
+
+# policy: (clip, robot, robots, finished lo, finished hi, mean survival lo, hi [steps])   measured: DESIGN.md section 7c
+LEVELS = {
+    "laikago_pace": ("laikago_pace", "laikago", 256, 0.97, 1.0, 590, 600),          # 1.000, 600
+    "laikago_spin": ("laikago_spin", "laikago", 256, 0.0, 0.05, 30, 120),           # 0.000, 52
+    "laikago_trot": ("laikago_trot", "laikago", 256, 0.0, 0.05, 80, 260),           # 0.000-0.003, 138-143
+    "laikago_trot0": ("laikago_trot", "laikago", 256, 0.0, 0.05, 60, 230),          # 0.000-0.001, 110-117
+    "minicheetah_trot": ("minicheetah_trot", "mini_cheetah", 1024, 0.84, 0.95, 490, 580),   # 0.883-0.901, 531-542
+}
+
+
+@pytest.mark.parametrize("pol", sorted(LEVELS))
+def test_all_five_shipped_policies(pol):
+    import policy_probe
+    clip, robot, n, f_lo, f_hi, l_lo, l_hi = LEVELS[pol]
+    o = policy_probe.run(pol, clip, robot, n, seed=1, raw=True)
+    print("POLICY_PROBE " + policy_probe.fmt(o))
+    assert f_lo <= o["finished"] <= f_hi, (pol, o["finished"])
+    assert l_lo <= o["len"] <= l_hi, (pol, o["len"])
+    assert o["reasons"]["non_finite"] == 0
+    t = o["terms"]
+    assert all(0.0 <= t[k] <= 1.0 + 1e-3 for k in t), t        # the five terms recomputed from the state record are consistent with the reward
+    if pol == "laikago_pace":
+        assert o["reward_per_step"] > 0.6
+    if pol == "minicheetah_trot":
+        # where the ~10 % fall: not the warm-up starts (VERDICT r3's hypothesis) but two windows of the trot cycle,
+        # half a cycle apart, and early in the episode
+        r = o["_raw"]
+        fell = ~r["finished"]
+        rsi = ~r["warmup"]
+        windows = ((r["phase"] >= 0.125) & (r["phase"] < 0.25)) | (r["phase"] >= 0.875)
+        assert fell[rsi].sum() >= 40
+        assert (windows & fell & rsi).sum() >= 0.95 * (fell & rsi).sum()                      # measured: every one of them
+        assert r["finished"][rsi & ~windows].mean() >= 0.99                                     # every other phase: everybody finishes
+        assert np.percentile(r["len"][fell], 95) <= 80                                         # the fallers fall within the first 2.5 s
+        assert 0.75 <= r["finished"][r["warmup"]].mean() <= 0.95                               # warm-up episodes: 0.85, like the rest

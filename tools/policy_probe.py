@@ -73,7 +73,7 @@ def reward_terms(t, env, ref_pose, ref_vel, reward):
     return t.stack([pose, vel, ee, rpose, rvel], dim=1)
 
 
-def run(pol, clip, robot, n, seed, steps=600, ref_state_init_prob=None, model_over=None, config_over=None):
+def run(pol, clip, robot, n, seed, steps=600, ref_state_init_prob=None, model_over=None, config_over=None, raw=False):
     import torch
     from openroborl_amd import policy as polmod
     from openroborl_amd.env import VecQuadrupedEnv
@@ -153,6 +153,8 @@ def run(pol, clip, robot, n, seed, steps=600, ref_state_init_prob=None, model_ov
                        "legs_in_contact": float((ln_[m] > 0).sum(axis=1).mean()), "max_normal_impulse": float(ln_[m].max(axis=1).mean()),
                        "dvz_first_substep": float(kc[m].mean())})
     out["by_reset_phase_32"] = detail
+    if raw:      # per-robot arrays (tests): finished, warm-up episode, clip phase at reset, steps survived
+        out["_raw"] = {"finished": al, "warmup": wm, "phase": ph, "len": ln}
     env.close()
     return out
 
