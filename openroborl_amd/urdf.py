@@ -97,6 +97,18 @@ def parse_urdf(text):
             if i is not None:
                 g = lambda k: float(i.get(k, "0"))
                 d["inertia"] = np.array([[g("ixx"), g("ixy"), g("ixz")], [g("ixy"), g("iyy"), g("iyz")], [g("ixz"), g("iyz"), g("izz")]])
+        # Bullet's per-link contact properties (URDF <contact> block: lateral_friction, stiffness + damping) and a spherical collision
+        # shape: what the toe links of the reference's robots carry (the table's foot_friction, contact_stiffness / contact_damping,
+        # toe_radius)
+        ct = ln.find("contact")
+        if ct is not None:
+            for tag, key in (("lateral_friction", "lateral_friction"), ("stiffness", "contact_stiffness"), ("damping", "contact_damping")):
+                e = ct.find(tag)
+                if e is not None:
+                    d[key] = float(e.get("value"))
+        sp = ln.find("collision/geometry/sphere")
+        if sp is not None:
+            d["sphere_radius"] = float(sp.get("radius"))
         links[ln.get("name")] = d
     for jn in root.findall("joint"):
         o, ax, lim = jn.find("origin"), jn.find("axis"), jn.find("limit")
@@ -157,6 +169,13 @@ def model_from_urdf(text, template, names):
                 m["link_inertia_pa"][j] = _pa(ld["mass"], c - cc) + _pa(tl["mass"], c_t - cc)
                 m["toe_pos"][leg] = Wc @ td["xyz"]
                 m["lower_com"][leg] = c
+                # contact properties of the toe link, when the URDF states them (the four toes of the reference's robots are alike)
+                if "lateral_friction" in tl:
+                    m["foot_friction"] = tl["lateral_friction"]
+                if "contact_stiffness" in tl:
+                    m["contact_stiffness"], m["contact_damping"] = tl["contact_stiffness"], tl.get("contact_damping", 0.0)
+                if "sphere_radius" in tl:
+                    m["toe_radius"] = tl["sphere_radius"]
             W, origin_shift = Wc, np.zeros(3)
     return m
 
@@ -215,8 +234,12 @@ def model_to_urdf(model, names, rng=None):
                 Wt = K @ frame() if rng is not None else np.eye(3)
                 rpy_t, xyz_t = mat_to_rpy(Wc.T @ Wt), Wc.T @ model["toe_pos"][leg]
                 out.append('<joint name="%s" type="fixed"><parent link="%s"/><child link="toe%d"/><origin xyz="%.17g %.17g %.17g" '
-                           'rpy="%.17g %.17g %.17g"/></joint><link name="toe%d"/>'
-                           % (names["toes"][leg], child, leg, xyz_t[0], xyz_t[1], xyz_t[2], rpy_t[0], rpy_t[1], rpy_t[2], leg))
+                           'rpy="%.17g %.17g %.17g"/></joint><link name="toe%d"><contact><lateral_friction value="%.17g"/>%s</contact>'
+                           '<collision><geometry><sphere radius="%.17g"/></geometry></collision></link>'
+                           % (names["toes"][leg], child, leg, xyz_t[0], xyz_t[1], xyz_t[2], rpy_t[0], rpy_t[1], rpy_t[2], leg,
+                              model["foot_friction"],
+                              '<stiffness value="%.17g"/><damping value="%.17g"/>' % (model["contact_stiffness"], model["contact_damping"])
+                              if model.get("contact_stiffness", 0.0) > 0 else "", model["toe_radius"]))
             W, parent, shift = Wc, child, np.zeros(3)
     out.append("</robot>")
     return "\n".join(out)
@@ -230,5 +253,5 @@ if __name__ == "__main__":   # python -m openroborl_amd.urdf <file.urdf> laikago
     got = model_from_urdf(open(path).read(), hand, LAIKAGO_JOINTS if name == "laikago" else MINI_CHEETAH_JOINTS)
     np.set_printoptions(precision=6, suppress=True, linewidth=160)
     for k in ("base_mass", "base_inertia", "link_mass", "link_com", "link_inertia", "link_inertia_pa", "joint_pos", "joint_axis", "joint_lo",
-              "joint_hi", "toe_pos", "lower_com"):
+              "joint_hi", "toe_pos", "lower_com", "toe_radius", "foot_friction", "contact_stiffness", "contact_damping"):
         print("== %s\nURDF:\n%s\nrobots.py:\n%s" % (k, np.asarray(got[k]), np.asarray(hand[k])))

@@ -28,6 +28,8 @@ def test_round_trip_through_rotated_urdf(name, names):
         np.testing.assert_allclose(got["joint_lo"][fin], model["joint_lo"][fin], atol=1e-12)
         np.testing.assert_allclose(got["joint_hi"][fin], model["joint_hi"][fin], atol=1e-12)
         assert np.all(got["joint_lo"][~fin] < -1e8) and np.all(got["joint_hi"][~fin] > 1e8)
+        # the toe link's <contact> block and collision sphere (Bullet's per-link contact properties)
+        assert got["toe_radius"] == pytest.approx(model["toe_radius"]) and got["foot_friction"] == pytest.approx(model["foot_friction"])
         # what the kernel requires of a model (orr_set_model): joints about +-x (hip) / +-y (upper, lower leg) of the kinematic frame
         ax = got["joint_axis"].reshape(4, 3, 3)
         assert np.allclose(np.abs(ax[:, 0]), [1, 0, 0], atol=1e-12) and np.allclose(np.abs(ax[:, 1:]), [0, 1, 0], atol=1e-12)
@@ -45,3 +47,16 @@ def test_parser_reads_plain_urdf_elements():
     j = joints["j"]
     assert j["parent"] == "a" and j["child"] == "b" and j["lower"] == -1 and j["upper"] == 2 and np.allclose(j["xyz"], [0, 0.5, 0])
     assert np.allclose(urdf.mat_to_rpy(j["R"]), [0.1, 0.2, 0.3], atol=1e-12)
+
+
+def test_toe_contact_block_fills_the_soft_contact_entries():
+    """URDF <contact><stiffness/><damping/><lateral_friction/> on the toe links -> contact_stiffness / contact_damping / foot_friction
+    of the table (Bullet's BT_CONTACT_FLAG_CONTACT_STIFFNESS_DAMPING)."""
+    model = robots.laikago()
+    soft = dict(model, contact_stiffness=30000.0, contact_damping=1000.0, foot_friction=3.0, toe_radius=0.03)
+    text = urdf.model_to_urdf(soft, urdf.LAIKAGO_JOINTS, np.random.RandomState(2))
+    assert "<stiffness" in text and text.count("<contact>") == 4
+    got = urdf.model_from_urdf(text, robots.laikago(), urdf.LAIKAGO_JOINTS)
+    assert (got["contact_stiffness"], got["contact_damping"], got["foot_friction"], got["toe_radius"]) == (30000.0, 1000.0, 3.0, 0.03)
+    rigid = urdf.model_from_urdf(urdf.model_to_urdf(model, urdf.LAIKAGO_JOINTS), robots.laikago(), urdf.LAIKAGO_JOINTS)
+    assert rigid["contact_stiffness"] == 0.0 and "<stiffness" not in urdf.model_to_urdf(model, urdf.LAIKAGO_JOINTS)

@@ -108,6 +108,11 @@ def dump_urdf(robot):
         d = p.getDynamicsInfo(b, link)
         rec = {"link": link, "mass": d[0], "lateral_friction": d[1], "inertia_diag": list(d[2]), "inertial_pos": list(d[3]),
                "inertial_orn": list(d[4])}
+        # getDynamicsInfo: ..., restitution [5], rolling [6] and spinning [7] friction, contact damping [8] and stiffness [9] (-1 = the link has
+        # no <contact><stiffness/><damping/> block: rigid contact).  The table entries contact_stiffness / contact_damping (orr_model,
+        # ABI v4; DESIGN.md sections 4 and 7c) are these two numbers of the TOE links
+        if len(d) > 9:
+            rec.update(restitution=d[5], rolling_friction=d[6], spinning_friction=d[7], contact_damping=d[8], contact_stiffness=d[9])
         if link >= 0:
             ji = w.info[link]
             rec.update(joint_name=ji[1].decode(), joint_type=ji[2], lower=ji[8], upper=ji[9], link_name=ji[12].decode(),
@@ -124,6 +129,10 @@ def dump_urdf(robot):
         print("%-34s m=%.6g I=%s com=%s joint_at=%s axis=%s limits=(%.6g, %.6g)" % (
             rec["joint_name"], rec["mass"], [round(x, 9) for x in rec["inertia_diag"]], [round(x, 6) for x in rec["inertial_pos"]],
             [round(x, 6) for x in rec["parent_frame_pos"]], rec["axis"], rec["lower"], rec["upper"]))
+    for rec in links:
+        if rec.get("contact_stiffness", -1.0) > 0:
+            print("%-34s contact_stiffness=%.6g contact_damping=%.6g lateral_friction=%.6g" % (
+                rec.get("link_name", "base"), rec["contact_stiffness"], rec["contact_damping"], rec["lateral_friction"]))
     print("written", path)
 
 
