@@ -348,7 +348,6 @@ __global__ __launch_bounds__((MODE == 0 && WPE == 1 ? 64 * ORR_WPB : 64)) __attr
   // nondeterministic value instead of an uninitialised variable: reading it is defined behaviour in every lane, and unlike a constant
   // it gives the compiler nothing to merge with the atomic's result (a merged value made it wait for the atomic right away)
   unsigned long long log_slot = __builtin_nondeterministic_value(log_slot);
-  float reset_ipos = 0.0f;
   {
     const float* rp = &S.s[O(REF_POSE)];
     float pe = 0.0f, qc[4], dq[4];
@@ -372,9 +371,6 @@ __global__ __launch_bounds__((MODE == 0 && WPE == 1 ? 64 * ORR_WPB : 64)) __attr
     // round trip of several microseconds).  It is issued HERE, as soon as the end of the episode is known, and consumed after the
     // reset: the observation, the target observation and the first stages of the reset run while it is in flight
     if (lane == 0 && valid && reason != 0) log_slot = atomicAdd((unsigned long long*)&P.counters[ORR_CNT_EPISODES], 1ull);
-    // the one reset constant that is not in registers already (INIT_POSITION, lanes 0..2): loaded here, every step, never waited for
-    // unless this robot resets - by then the observation and the target observation have covered its round trip
-    reset_ipos = mc->init_pos[lane < 3 ? lane : 0];
     WSYNC();
     if (lane == 0) {
       seti(S, O(EP_STEP), ep_step);
@@ -403,11 +399,7 @@ __global__ __launch_bounds__((MODE == 0 && WPE == 1 ? 64 * ORR_WPB : 64)) __attr
     WSYNC();
     if (c.flags & ORR_FLAG_AUTO_RESET) {
       PT(31);
-      const MotorConst mk = {mj, m_off, m_dir, m_init, reset_ipos};      // in registers since the top of the launch (the PD law's constants)
-#ifndef ORR_RESET_FROM_REGS
-#define ORR_RESET_FROM_REGS 1
-#endif
-      reset_robot(P, rec, S, lane, valid, total_snapshot, obs, nullptr, ORR_RESET_FROM_REGS ? &mk : nullptr);
+      reset_robot(P, rec, S, lane, valid, total_snapshot, obs);
     }
     if (logs && P.ep_log) {
       if (slot < (unsigned long long)P.ep_log_cap) {

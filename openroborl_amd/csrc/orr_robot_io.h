@@ -93,12 +93,7 @@ __device__ __forceinline__ void base_rotation(Shared& S, int lane, float rel[4],
 
 // Minitaur.receive_obs + get_true_obs (minitaur.py:304-334): push the true observation.  entry: optional copy of the pushed
 // entry (20 words, LDS) for callers that build the control observation without reading the ring back (reset_robot).
-// The per-motor constants of lane's motor (lanes 12..15: motor 0) as the step kernel holds them in registers over the whole launch.
-// Handed to the inline reset (reset_robot, receive_obs), they spare it three dependent round trips to the device table - the reset waves are
-// the last to finish in every launch, so their length is the launch's length.
-struct MotorConst { int joint; float off, dir, init; float ipos; };   // ipos: INIT_POSITION component of lanes 0..2 (issued early by the caller)
-__device__ static void receive_obs(const KParams& P, float* rec, Shared& S, int lane, bool valid, float* entry = nullptr,
-                                   const MotorConst* mk = nullptr) {
+__device__ static void receive_obs(const KParams& P, float* rec, Shared& S, int lane, bool valid, float* entry = nullptr) {
   const ColdPtr mc = model_cold(P, geti(S, O(ROBOT_TYPE)));
   const int head = (geti(S, O(RING_HEAD)) + 1) % ORR_RING_DEPTH, len = geti(S, O(RING_LEN));
   float rel[4], Rb[9], rate[3];
@@ -107,9 +102,8 @@ __device__ static void receive_obs(const KParams& P, float* rec, Shared& S, int 
   for (int i = lane; i < ORR_RING_ENTRY; i += kLanes) {
     float val = 0.0f;
     if (i < 12) {
-      // get_true_motor_angles (:543-553); word i < 12 is computed by lane i, whose own motor it is
-      if (mk && kLanes == 16) val = (S.s[O(Q) + mk->joint] - mk->off) * mk->dir;
-      else { int j = mc->joint_of_motor[i]; val = (S.s[O(Q) + j] - mc->motor_offset[i]) * mc->motor_dir[i]; }
+      int j = mc->joint_of_motor[i];
+      val = (S.s[O(Q) + j] - mc->motor_offset[i]) * mc->motor_dir[i];  // get_true_motor_angles (:543-553)
     } else if (i < 16) {
       val = i == 12 ? rel[0] : (i == 13 ? rel[1] : (i == 14 ? rel[2] : rel[3]));
     } else if (i < 19) {

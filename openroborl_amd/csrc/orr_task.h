@@ -367,9 +367,8 @@ __device__ static void sensors_push(Shared& S, int lane, bool fill_all) {
 // imitation_task.py:166-199); SURVEY.md Appendix A.2.  Writes the 160-d observation into obs (LDS).
 // ================================================================================================
 // uni_replay (parity replay only, else NULL): 28 draws in [0, 1) that replace the Philox stream
-// mk (optional): the lane's per-motor constants from the caller's registers (MotorConst, orr_robot_io.h)
 __device__ static void reset_robot(const KParams& P, float* rec, Shared& S, int lane, bool valid, long long total_step_count, float* obs,
-                                   const float* uni_replay = nullptr, const MotorConst* mk = nullptr) {
+                                   const float* uni_replay = nullptr) {
   const orr_config& c = P.cfg;
   // every reset starts a new episode = a new RNG stream (robot, episode)
   const uint32_t robot = (uint32_t)geti(S, O(ROBOT_INDEX)), ep = (uint32_t)geti(S, O(EPISODE_IDX)) + 1u;
@@ -379,8 +378,8 @@ __device__ static void reset_robot(const KParams& P, float* rec, Shared& S, int 
   // the cold table: all lanes load (clamped index), no divergent `if` around the loads
   const ColdPtr mc = model_cold(P, geti(S, O(ROBOT_TYPE)));
   const int lm = lane < 12 ? lane : 0, l3 = lane < 3 ? lane : 0;
-  const int rj = mk ? mk->joint : mc->joint_of_motor[lm];
-  const float r_q0 = mk ? mk->init + mk->off : mc->init_motor_angles[lm] + mc->motor_offset[lm], r_p0 = mk ? mk->ipos : mc->init_pos[l3];
+  const int rj = mc->joint_of_motor[lm];
+  const float r_q0 = mc->init_motor_angles[lm] + mc->motor_offset[lm], r_p0 = mc->init_pos[l3];
   if (lane < 3) {
     S.s[O(POS) + lane] = r_p0 + (lane < 2 ? S.s[O(GRID_OFFSET) + lane] : 0.0f);
     S.s[O(LINVEL) + lane] = 0.0f; S.s[O(ANGVEL) + lane] = 0.0f;
@@ -445,7 +444,7 @@ __device__ static void reset_robot(const KParams& P, float* rec, Shared& S, int 
   // ring entries #1 and #2 of the new episode are kept (LDS) so that the control observations of the reset are blended from them
   // directly: reading the ring back would be a store -> load round trip through memory each time
   float* e1 = S.ph.end.red;            // 20 words each
-  receive_obs(P, rec, S, lane, valid, e1, mk);  // ring entry #1
+  receive_obs(P, rec, S, lane, valid, e1);  // ring entry #1
   // 3. sensor histories <- 3 copies of the current readings (minitaur.py:270-271; sensor_wrappers.py:122-129)
   PT(17);
   WSYNC();
@@ -500,7 +499,7 @@ __device__ static void reset_robot(const KParams& P, float* rec, Shared& S, int 
   WSYNC();
   PT(22);
   float* e2 = S.ph.end.red + 56;         // ring entry #2; entry #1 was saved in registers below before red[] was reused
-  receive_obs(P, rec, S, lane, valid, e2, mk);  // ring entry #2 (imitation_task.py:792)
+  receive_obs(P, rec, S, lane, valid, e2);  // ring entry #2 (imitation_task.py:792)
   {
     // control observation with two entries in the ring (Minitaur._get_delay_obs, minitaur.py:336-357): latency <= 0 -> newest;
     // int(latency / dt) + 1 >= 2 -> the OLDEST entry (#1, the default pose: SURVEY 8a quirk 3); else blend newest / #1
