@@ -178,6 +178,14 @@ def load():
             else:
                 raise RuntimeError("libopenroborl_hip.so is missing or stale and could not be built: %r "
                                    "(set ORR_ALLOW_STALE_LIB=1 to use a stale library anyway)" % (e,))
+    # PyTorch-ROCm brings its own copy of the HIP runtime.  If this library is mapped FIRST it pulls in the system's libamdhip64, torch
+    # then loads its own, and the process holds two runtimes - the second one to initialise finds "no ROCm-capable device" (seen with
+    # `python __graft_entry__.py smoke`, where build() loaded the library before anything had imported torch).  Importing torch first
+    # makes the dynamic loader resolve this library's HIP symbols against the runtime torch has already mapped.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(path)
     vp = C.c_void_p
     L.orr_last_error.restype = C.c_char_p

@@ -103,10 +103,23 @@ def run(pol, clip, robot, n, seed, steps=600, ref_state_init_prob=None, model_ov
     terms = torch.zeros(n, 5, device=dev)
     first_reason = torch.zeros(n, dtype=torch.int32, device=dev)
     reason_f = env.field_int("DONE_REASON")[:, 0]
-    for _ in range(steps):
+    trace = []      # every 10th step, means over the robots still up: how the simulated robot sits relative to the reference it tracks
+    for k in range(steps):
         act, _, _ = model.act(obs, deterministic=True)
         rp, rv = env.field("REF_POSE").clone(), env.field("REF_VEL").clone()
         obs, rew, done, _ = env.step(act.contiguous())
+        if k % 10 == 9 and k < 200 and bool(alive.any()):
+            m = alive
+            ref_now = env.field("REF_POSE")                       # the pose the robot should be in NOW (updated inside the step)
+            dq = (env.field("Q") - ref_now[:, 7:])[m]              # URDF joint order: (hip-x, upper, lower) x 4 legs
+            trace.append({"step": k + 1, "alive": float(m.float().mean()),
+                          "dz": float((env.field("POS")[:, 2] - ref_now[:, 2])[m].mean()),
+                          "dvx_world": float((env.field("LINVEL")[:, 0] - env.field("REF_VEL")[:, 0])[m].mean()),
+                          "dq_hip_x": float(dq[:, 0::3].mean()), "dq_upper": float(dq[:, 1::3].mean()), "dq_lower": float(dq[:, 2::3].mean()),
+                          "dq_front_minus_rear_upper": float((dq[:, [1, 4]].mean() - dq[:, [7, 10]].mean())),
+                          "rms_dq": float((dq ** 2).mean().sqrt()),
+                          "normal_impulse_front": float(env.field("LAMBDA")[:, 0:6:3][m].sum(1).mean()),
+                          "normal_impulse_rear": float(env.field("LAMBDA")[:, 6:12:3][m].sum(1).mean())})
         a = alive.float()
         ret += rew * a
         terms += reward_terms(torch, env, rp, rv, rew) * a[:, None]
@@ -153,6 +166,7 @@ def run(pol, clip, robot, n, seed, steps=600, ref_state_init_prob=None, model_ov
                        "legs_in_contact": float((ln_[m] > 0).sum(axis=1).mean()), "max_normal_impulse": float(ln_[m].max(axis=1).mean()),
                        "dvz_first_substep": float(kc[m].mean())})
     out["by_reset_phase_32"] = detail
+    out["trace"] = trace
     if raw:      # per-robot arrays (tests): finished, warm-up episode, clip phase at reset, steps survived
         out["_raw"] = {"finished": al, "warmup": wm, "phase": ph, "len": ln}
     env.close()
@@ -166,6 +180,17 @@ def fmt_phase(o):
         if d:
             lines.append("    phase %.3f  n %3d  finished %.2f | %.1f legs  %.4f N s  %+.3f m/s" % (
                 d["phase"], d["episodes"], d["finished"], d["legs_in_contact"], d["max_normal_impulse"], d["dvz_first_substep"]))
+    return "\n".join(lines)
+
+
+def fmt_trace(o):
+    lines = ["  %s on %s: simulated robot relative to its reference, means over the robots still up (dz [m], world-x velocity error [m/s], joint "
+             "errors sim - ref [rad] by joint class, front - rear upper-leg error, rms joint error; normal impulses per sub-step front / rear [N s])"
+             % (o["policy"], o["clip"])]
+    for t in o["trace"]:
+        lines.append("    step %3d up %.2f | dz %+.4f dvx %+.3f | hip-x %+.3f upper %+.3f lower %+.3f  f-r %+.3f  rms %.3f | N front %.4f rear %.4f" % (
+            t["step"], t["alive"], t["dz"], t["dvx_world"], t["dq_hip_x"], t["dq_upper"], t["dq_lower"], t["dq_front_minus_rear_upper"],
+            t["rms_dq"], t["normal_impulse_front"], t["normal_impulse_rear"]))
     return "\n".join(lines)
 
 
@@ -302,6 +327,8 @@ def main():
             print(fmt(o), flush=True)
             if named and seed == args.seeds[0] and pol in ("minicheetah_trot", "laikago_pace"):
                 print(fmt_phase(o), flush=True)
+            if named and seed == args.seeds[0]:
+                print(fmt_trace(o), flush=True)
         if not args.no_controls and named:
             for p in (1.0, 0.0):
                 o = run(pol, clip, robot, args.robots, args.seeds[0], ref_state_init_prob=p)
