@@ -144,12 +144,13 @@ __device__ __forceinline__ void rot_sym_full(const float R[9], const float S[6],
 // spatial inertia about O (I symmetric, first moment h, mass m) times a spatial motion vector (w; v)
 __device__ __forceinline__ void spatial_inertia_mul(const float I[6], const float h[3], float m, const float w[3], const float v[3],
                                                     float oa[3], float ol[3]) {
-  float t[3], u[3];
-  symv(I, w, t);
-  cross3(h, v, u);
-  oa[0] = t[0] + u[0]; oa[1] = t[1] + u[1]; oa[2] = t[2] + u[2];
-  cross3(h, w, u);
-  ol[0] = m * v[0] - u[0]; ol[1] = m * v[1] - u[1]; ol[2] = m * v[2] - u[2];
+  // multiply-add chains (the separate cross products + adds were six instructions more)
+  oa[0] = fmaf(I[0], w[0], fmaf(I[3], w[1], fmaf(I[4], w[2], fmaf(h[1], v[2], -h[2] * v[1]))));
+  oa[1] = fmaf(I[3], w[0], fmaf(I[1], w[1], fmaf(I[5], w[2], fmaf(h[2], v[0], -h[0] * v[2]))));
+  oa[2] = fmaf(I[4], w[0], fmaf(I[5], w[1], fmaf(I[2], w[2], fmaf(h[0], v[1], -h[1] * v[0]))));
+  ol[0] = fmaf(m, v[0], fmaf(h[2], w[1], -h[1] * w[2]));
+  ol[1] = fmaf(m, v[1], fmaf(h[0], w[2], -h[2] * w[0]));
+  ol[2] = fmaf(m, v[2], fmaf(h[1], w[0], -h[0] * w[1]));
 }
 
 // one joint on the way down the leg: pose of the link behind it, its motion axis S = (s; d x s) about O, spatial
@@ -164,11 +165,9 @@ __device__ __forceinline__ void joint_down(const Shared& S, const LegConst& K, i
   const float ad = K.jdir[k] * S.s[O(QD) + j];
   ad_out = ad;
   // pose: d += Rw_parent r;  Rw = Rw_parent R(a)
-  {
-    float t[3];
-    mv3(Rw, K.r[k], t);
-    d[0] += t[0]; d[1] += t[1]; d[2] += t[2];
-  }
+#pragma unroll
+  for (int i = 0; i < 3; i++)     // accumulated into d by multiply-adds (a separate sum + add is one instruction more per component)
+    d[i] = fmaf(Rw[3 * i], K.r[k][0], fmaf(Rw[3 * i + 1], K.r[k][1], fmaf(Rw[3 * i + 2], K.r[k][2], d[i])));
 #pragma unroll
   for (int i = 0; i < 3; i++) {
     const float p0 = Rw[3 * i], p1 = Rw[3 * i + 1], p2 = Rw[3 * i + 2];
@@ -273,8 +272,8 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
   float I[6], h[3], m = K.m, f[6], pacc[6];
   {
     float c[3];
-    mv3(Rw, K.com, c);
-    c[0] += d[0]; c[1] += d[1]; c[2] += d[2];
+#pragma unroll
+    for (int i = 0; i < 3; i++) c[i] = fmaf(Rw[3 * i], K.com[0], fmaf(Rw[3 * i + 1], K.com[1], fmaf(Rw[3 * i + 2], K.com[2], d[i])));
     h[0] = m * c[0]; h[1] = m * c[1]; h[2] = m * c[2];
     rot_sym_full(Rw, K.Ic, I);
 #ifndef ORR_BIAS_COM
@@ -346,9 +345,11 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
   float Fo[6], bo;
   {
     spatial_inertia_mul(I, h, m, so, svo, &Fo[0], &Fo[3]);
-    bo = S.tau[3 * leg + (part < 3 ? part : 2)] - (dot3(so, &f[0]) + dot3(svo, &f[3]));
-    const float hc0 = dot3(s0, &Fo[0]) + dot3(sv0, &Fo[3]), hc1 = dot3(s1, &Fo[0]) + dot3(sv1, &Fo[3]);
-    const float hc2 = dot3(s2, &Fo[0]) + dot3(sv2, &Fo[3]);
+    auto dot6 = [](const float a[3], const float b[3], const float x[3], const float y[3]) __attribute__((always_inline)) {
+      return fmaf(a[0], x[0], fmaf(a[1], x[1], fmaf(a[2], x[2], fmaf(b[0], y[0], fmaf(b[1], y[1], b[2] * y[2])))));   // one chain: 6, not 7
+    };
+    bo = S.tau[3 * leg + (part < 3 ? part : 2)] - dot6(so, svo, &f[0], &f[3]);
+    const float hc0 = dot6(s0, sv0, &Fo[0], &Fo[3]), hc1 = dot6(s1, sv1, &Fo[0], &Fo[3]), hc2 = dot6(s2, sv2, &Fo[0], &Fo[3]);
     {  // part-3 lanes: index 3 = dump slot
       LegExchange& X = S.ph.sub.dyn.legx[leg];
 #pragma unroll
@@ -637,9 +638,8 @@ __device__ __forceinline__ void row_setup_bank_a(const Shared& S, const orr_conf
   for (int k = 0; k < 3; k++) {
     // velocity of the contact point per unit joint rate: s x (P - o) = s x rr + (d x s), rr and d relative to the base COM
     const LinkCache& L = S.ph.sub.dyn.lc[3 * leg + k];
-    float cr[3];
-    cross3(L.s, rr, cr);
-    cr[0] += L.sv[0]; cr[1] += L.sv[1]; cr[2] += L.sv[2];
+    const float cr[3] = {fmaf(L.s[1], rr[2], fmaf(-L.s[2], rr[1], L.sv[0])), fmaf(L.s[2], rr[0], fmaf(-L.s[0], rr[2], L.sv[1])),
+                         fmaf(L.s[0], rr[1], fmaf(-L.s[1], rr[0], L.sv[2]))};
     if (k == 0) { G.c00 = cr[0]; G.c01 = cr[1]; G.c02 = cr[2]; }
     else if (k == 1) { G.c10 = cr[0]; G.c11 = cr[1]; G.c12 = cr[2]; }
     else { G.c20 = cr[0]; G.c21 = cr[1]; G.c22 = cr[2]; }
