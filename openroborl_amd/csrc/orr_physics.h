@@ -1012,6 +1012,16 @@ __device__ __forceinline__ void pgs_sweeps(int iters, unsigned int mask, int lan
 // knee rows have J = e_knee (the column is an element of wq), joint-limit rows J = +-e_joint (one multiply), contact rows
 // the full 9 terms (6 base + the 3 joints of their leg, whose index is static per slot).  Knee rows always, joint-limit
 // rows one by one, contact rows per leg.
+#ifndef ORR_DIAG_VCC
+#define ORR_DIAG_VCC 1
+#endif
+// x, but 0 in lane K of the robot's 16 (compare + select through vcc, two instructions, no lane mask kept in SGPRs)
+template <int K>
+__device__ __forceinline__ float zero_in_lane(float x, int lane) {
+  float o;
+  asm("v_cmp_eq_u32 vcc, %2, %1\n\tv_cndmask_b32_e64 %0, %3, 0, vcc" : "=v"(o) : "v"(lane), "n"(K), "v"(x) : "vcc");
+  return o;
+}
 template <bool HAS_B>
 __device__ __forceinline__ void delassus_columns(const Shared& S, unsigned int mask, int lane, int sub, Row& A, Row& B, const ContactGeom& G,
                                                  float (&AcA)[kMaxRows], float (&AcB)[kMaxRows], float (&lam)[kMaxRows]) {
@@ -1025,11 +1035,22 @@ __device__ __forceinline__ void delassus_columns(const Shared& S, unsigned int m
     const float l0 = bcast_lane<src>(inB ? B.lam : A.lam, sub);
     lam[r] = l0;
     A.w += a * l0;
+#if ORR_DIAG_VCC
+    // the diagonal entry of the scaled column is zero (y of the updated row does not move).  `lane == src` as a compare into vcc right
+    // here: as a C++ select the compiler keeps one lane mask per row (16 SGPR pairs) alive over the whole sub-step loop, which is what
+    // pushed the SGPR file over its limit (46 spilled, every use reloaded with two v_readlane)
+    AcA[r] = inB ? -a * A.jdi : zero_in_lane<src>(-a * A.jdi, lane);
+#else
     AcA[r] = (!inB && lane == src) ? 0.0f : -a * A.jdi;
+#endif
     if (r >= 16 && r < 20 && A.nrm_slot == r) A.lam_n = l0;
     if (HAS_B) {
       B.w += b * l0;
+#if ORR_DIAG_VCC
+      AcB[r] = inB ? zero_in_lane<src>(-b * B.jdi, lane) : -b * B.jdi;
+#else
       AcB[r] = (inB && lane == src) ? 0.0f : -b * B.jdi;
+#endif
     }
     asm("" : "+v"(AcA[r]), "+v"(AcB[r]));  // keep the scaled value (do not re-derive it inside the sweeps)
   };
