@@ -147,6 +147,57 @@ def test_static_stance_holds(robot):
     env.close()
 
 
+def _make_env_model(robot, **over):
+    cfg = config.make_config(1, mode="test", enable_randomizer=False, auto_reset=False)
+    model = robots.ROBOTS[robot]()
+    model.update(over)
+    for k, v in list(model.items()):
+        if isinstance(v, np.ndarray) and v.dtype == np.float64:
+            model[k] = ol.dec32(v)
+        elif isinstance(v, float):
+            model[k] = ol.dec32(v)
+    clip = motion.MotionClip("laikago_pace" if robot == "laikago" else "minicheetah_trot")
+    models = [None, None]
+    models[robots.ROBOT_TYPE_ID[robot]] = model
+    return ol.OracleEnv(cfg, models, [clip], 1, robot_type=robots.ROBOT_TYPE_ID[robot]), model
+
+
+@pytest.mark.parametrize("stiffness,damping", [(30000.0, 1000.0), (10000.0, 300.0)])
+def test_soft_toe_contact_settles_at_the_spring_law(stiffness, damping):
+    """Bullet's contact stiffness / damping on the toe links (orr_model::contact_stiffness / contact_damping, DESIGN.md section 4): a
+    normal row with cfm = 1 / (dt k + d) and erp = dt k / (dt k + d) is an implicit spring-damper, so a robot standing still must sink
+    into the ground until every toe carries F = k x depth; with rigid toes the same stance rests at (almost) zero depth.  The toe
+    depth is read off the forward kinematics; the normal impulses still add up to the weight."""
+    depth = {}
+    for name, over in (("rigid", {}), ("soft", {"contact_stiffness": stiffness, "contact_damping": damping})):
+        env, model = _make_env_model("laikago", **over)
+        lay = env.lay
+        s = env.state[0]
+        dirj, offj, moj = pr.joint_maps(model)
+        s[lay.sl("Q")] = np.array(model["init_motor_angles"])[moj] * dirj + offj
+        s[lay.sl("QUAT")] = model["init_quat"]
+        s[lay.sl("POS")] = model["init_pos"]
+        s[lay.sl("QD")] = 0; s[lay.sl("LINVEL")] = 0; s[lay.sl("ANGVEL")] = 0
+        kp, kd = np.array(model["kp"]), np.array(model["kd"])
+        for _ in range(3000):
+            qm = (s[lay.sl("Q")][model["joint_of_motor"]] - model["motor_offset"]) * model["motor_dir"]
+            qdm = s[lay.sl("QD")][model["joint_of_motor"]] * model["motor_dir"]
+            tau = -kp * (qm - model["init_motor_angles"]) - kd * qdm
+            assert env.L.orc_physics_substep(env.h, P(s), P(np.ascontiguousarray(tau))) == 0
+        out, masses = np.zeros(34 * 3), np.zeros(13)
+        env.L.orc_fk_probe(env.h, P(s), P(out), P(masses))
+        toe_z = out[26 * 3:].reshape(8, 3)[1::2, 2] - model["toe_radius"]          # clearance of the four toe spheres (negative = depth)
+        lam_n = s[lay.sl("LAMBDA")].reshape(4, 3)[:, 0]
+        np.testing.assert_allclose(lam_n.sum() / 1e-3, masses.sum() * 10.0, rtol=2e-2)     # the weight is carried either way
+        depth[name] = (-toe_z, lam_n / 1e-3)
+        env.close()
+    d_rigid, _ = depth["rigid"]
+    d_soft, force = depth["soft"]
+    assert np.all(np.abs(d_rigid) < 3e-4)                                          # rigid: rests on the surface (erp pushes depth out)
+    np.testing.assert_allclose(d_soft, force / stiffness, rtol=0.15, atol=1e-4)    # soft: Hooke's law per toe
+    assert np.all(d_soft > 3.0 * np.abs(d_rigid).max())
+
+
 def test_friction_pyramid_bounds_tangential_impulse():
     """Robot sliding sideways on its feet: |lambda_t| <= mu * lambda_n per axis, and it decelerates."""
     env, model = make_env("laikago")
