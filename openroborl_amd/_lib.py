@@ -37,8 +37,10 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O2", "-fPIC", "-shared", "-std=c++17",
 # ranges cost it 8 % (8192 robots: 0.382 -> 0.352 ms), while the default scheduler costs the one-wave variant 9 % (tools/ab_variants.sh).
 # -O3 instead of -O2: another 1.5 % for this unit (0.3554 -> 0.3500 ms; the schedule-metric bias, the AMDGPU pressure trackers and the
 # high-pressure reschedule stage make no difference, the SLP vectoriser costs 70 %).
-HIPCC_FLAGS_W2 = ["-O3" if f == "-O2" else f for i, f in enumerate(HIPCC_FLAGS)
-                  if "amdgpu-sched-strategy" not in f and not (f == "-mllvm" and i + 1 < len(HIPCC_FLAGS) and "amdgpu-sched-strategy" in HIPCC_FLAGS[i + 1])]
+# Round 4: of the compiler's other scheduling strategies the register-pressure-minded `iterative-maxocc` suits this unit best
+# (8192 robots, interleaved A/B: default 0.3086 ms, iterative-maxocc 0.3022, max-memory-clause 0.3090, iterative-minreg 0.3207; the one-wave
+# unit keeps iterative-ilp: maxocc 0.2218 against 0.2180, max-ilp 0.2349, max-memory-clause 0.2329; profiles/r04_ab11_8192.txt, r04_ab12_4096.txt).
+HIPCC_FLAGS_W2 = ["-O3" if f == "-O2" else ("-amdgpu-sched-strategy=iterative-maxocc" if "amdgpu-sched-strategy" in f else f) for f in HIPCC_FLAGS]
 
 EXPORTS = [
     "orr_last_error", "orr_abi_version", "orr_source_hash", "orr_state_stride", "orr_layout_count", "orr_layout_name",
