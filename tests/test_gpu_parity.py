@@ -70,8 +70,6 @@ def compare_fields(env, orc, names, atol, rtol=0.0, what=""):
 
 
 RIGID = ["POS", "QUAT", "LINVEL", "ANGVEL", "Q", "QD"]
-
-
 SOFT_TOES = {"contact_stiffness": 30000.0, "contact_damping": 1000.0, "foot_friction": 3.0}
 
 
@@ -177,11 +175,13 @@ def test_short_rollout_tracks_oracle():
     env.close(); orc.close(); o32.close()
 
 
-def test_mixed_batch_parity():
-    """BASELINE config 5: interleaved Laikago / mini-cheetah robots in one launch (divergent wavefronts)."""
+@pytest.mark.parametrize("soft_type", [None, "mini_cheetah"])
+def test_mixed_batch_parity(soft_type):
+    """BASELINE config 5: interleaved Laikago / mini-cheetah robots in one launch (divergent wavefronts).  soft_type: that robot type's
+    toes with Bullet's contact stiffness / damping, the other type rigid - the two contact models side by side in every wavefront."""
     import torch
     n = 64
-    env, orc = make_pair(n=n, mixed=["laikago", "mini_cheetah"])
+    env, orc = make_pair(n=n, mixed=["laikago", "mini_cheetah"], model_overrides={soft_type: SOFT_TOES} if soft_type else None)
     og = env.reset().cpu().numpy()
     oo = orc.reset()
     np.testing.assert_allclose(og, oo, atol=2e-6)
