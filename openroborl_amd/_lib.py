@@ -33,7 +33,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O2", "-fPIC", "-shared", "-std=c++17",
                "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
 
 # The second translation unit (orr_kernels_w2.hip = the step kernel compiled for two waves per SIMD, used for batches of more than
-# 4 x #SIMDs robots) keeps the compiler's DEFAULT scheduler: at 256 registers that variant spills, and the ILP schedule's long live
+# 4 x #SIMDs robots) used the compiler's DEFAULT scheduler up to round 3: at 256 registers that variant spills, and the ILP schedule's long live
 # ranges cost it 8 % (8192 robots: 0.382 -> 0.352 ms), while the default scheduler costs the one-wave variant 9 % (tools/ab_variants.sh).
 # -O3 instead of -O2: another 1.5 % for this unit (0.3554 -> 0.3500 ms; the schedule-metric bias, the AMDGPU pressure trackers and the
 # high-pressure reschedule stage make no difference, the SLP vectoriser costs 70 %).

@@ -11,8 +11,9 @@
 // Two translation units are built from this file.  The main one (everything) is compiled with the instruction-level-parallelism
 // scheduler: one wave per SIMD, ~300 registers, nothing to hide latency but the wave's own independent instructions.  The second
 // one (orr_kernels_w2.hip: #define ORR_TU_STEP_W2 + #include of this file) holds ONLY the two-waves-per-SIMD instantiation of the step
-// kernel and is compiled with the compiler's default (occupancy-minded) scheduler: at 256 registers that variant spills, and the ILP
-// schedule's longer live ranges cost it 8 % (0.382 vs 0.352 ms at 8192 robots; the default scheduler costs the one-wave variant 9 %).
+// kernel and is compiled with an occupancy-minded scheduler (-O3 + iterative-maxocc since round 4, the compiler's default before): at
+// 256 registers that variant spills, and the ILP schedule's longer live ranges cost it 8 % (0.382 vs 0.352 ms at 8192 robots; the default
+// scheduler costs the one-wave variant 9 %).
 #ifdef ORR_TU_STEP_W2
 #undef ORR_PHASE_TIMERS      // the development timers live in the main translation unit only
 #endif
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(64) void orr_reset_kernel(KParams P, const uint8_t*
 // positions and the fall flag is given -- the device-side counterpart of the oracle's replay mode, fed with the fixtures that the
 // reference's own Python produced (tests/test_gpu_golden_task.py).
 // WPE = waves per SIMD the kernel is compiled for.  WPE 1: up to 512 VGPRs (~300 used), one wave on each of the 1024 SIMDs = 4096 robots
-// resident at once: the best a batch of <= 4096 robots can do.  WPE 2 (<= 256 VGPRs, 10 of them spilled outside the sub-step loop; LDS 19.3 KB per wave, so
+// resident at once: the best a batch of <= 4096 robots can do.  WPE 2 (<= 256 VGPRs, 28 of them spilled, one scratch access inside the sub-step loop; LDS 19.3 KB per wave, so
 // eight waves fit a CU): for larger batches.  A lone wave issues one vector instruction per ~5 cycles, the SIMD can take one per 2:
 // two co-resident waves of this kernel take 1.12x as long as one alone (tools/wave_pairing.py), i.e. 1.8x the throughput per SIMD,
 // where the WPE-1 kernel would run the second thousand waves after the first.  orr_step picks the variant from the batch size and the

@@ -43,6 +43,95 @@ __device__ __forceinline__ void chol6_solve(const float L[21], const float invdi
   }
 }
 
+// The same factorisation on PACKED float pairs (v_pk_fma_f32 / v_pk_mul_f32: two multiply-adds per issued instruction; round 4, v38).
+// The factor is kept by COLUMNS with the rows below the diagonal paired (2,3) and (4,5): a rank-1 update of the trailing columns and a
+// forward substitution step then work on whole pairs with the scalar factor as an op_sel broadcast.  Every entry sees the operations of
+// chol6 / chol6_solve in the same order (the sums run over k ascending either way; the backward substitution stays scalar: by columns it
+// would subtract in descending order), each step ONE fused multiply-add.  ORR_CHOL_PK: 0 = scalar code above, 1 = packed factorisation
+// and solves, 2 = also the column of T, the elimination terms -T_k F_k^T / T_k b_k and the 16-lane sums in that layout (leg_dynamics).
+// 4096 robots 0.2187 -> 0.2164 ms, 8192 robots 0.3033 -> 0.3005 ms (interleaved A/B, profiles/r04_ab17_*.log).
+#ifndef ORR_CHOL_PK
+#define ORR_CHOL_PK 2
+#endif
+typedef float pk2 __attribute__((ext_vector_type(2)));
+// c - a * s and c - a * b as ONE fused operation per component (v_pk_fma_f32; the scalar rides as an op_sel broadcast).  Spelled out, not
+// left to the compiler's contraction of `c - a * s`: in the row solves it kept some of those as v_pk_mul + v_pk_add, i.e. other bits
+// than the scalar code's v_fma.
+__device__ __forceinline__ pk2 pk_nfma(pk2 a, float s, pk2 c) { return __builtin_elementwise_fma(-a, pk2{s, s}, c); }
+struct Chol6Pk {
+  float l10, l32, l54;            // the sub-diagonal entries outside the pairs
+  pk2 c0a, c0b;                   // column 0: rows (2,3), (4,5)
+  pk2 c1a, c1b;                   // column 1: rows (2,3), (4,5)
+  pk2 c2b, c3b;                   // columns 2, 3: rows (4,5)
+  float idg[6];                   // 1 / diagonal
+};
+// A by columns of its lower triangle: d0, d1, d3, d5 diagonal entries, a10 = A[1][0], d2a = (A[2][2], A[3][2]), d4a = (A[4][4], A[5][4]),
+// aKa = (A[2][K], A[3][K]), aKb = (A[4][K], A[5][K])
+__device__ __forceinline__ void chol6_pk(float d0, float d1, float d3, float d5, float a10, pk2 d2a, pk2 d4a,
+                                         pk2 a0a, pk2 a0b, pk2 a1a, pk2 a1b, pk2 a2b, pk2 a3b, Chol6Pk& F) {
+  // column 0
+  const float r0 = rsq(d0);
+  const float l10 = a10 * r0;
+  const pk2 c0a = a0a * r0, c0b = a0b * r0;
+  d1 = fmaf(-l10, l10, d1);
+  a1a = pk_nfma(c0a, l10, a1a); a1b = pk_nfma(c0b, l10, a1b);
+  d2a = pk_nfma(c0a, c0a.x, d2a);                            // (2,2), (3,2)
+  d3 = fmaf(-c0a.y, c0a.y, d3);
+  a2b = pk_nfma(c0b, c0a.x, a2b); a3b = pk_nfma(c0b, c0a.y, a3b);
+  d4a = pk_nfma(c0b, c0b.x, d4a);                            // (4,4), (5,4)
+  d5 = fmaf(-c0b.y, c0b.y, d5);
+  // column 1
+  const float r1 = rsq(d1);
+  const pk2 c1a = a1a * r1, c1b = a1b * r1;
+  d2a = pk_nfma(c1a, c1a.x, d2a);
+  d3 = fmaf(-c1a.y, c1a.y, d3);
+  a2b = pk_nfma(c1b, c1a.x, a2b); a3b = pk_nfma(c1b, c1a.y, a3b);
+  d4a = pk_nfma(c1b, c1b.x, d4a);
+  d5 = fmaf(-c1b.y, c1b.y, d5);
+  // column 2
+  const float r2 = rsq(d2a.x);
+  const float l32 = d2a.y * r2;
+  const pk2 c2b = a2b * r2;
+  d3 = fmaf(-l32, l32, d3);
+  a3b = pk_nfma(c2b, l32, a3b);
+  d4a = pk_nfma(c2b, c2b.x, d4a);
+  d5 = fmaf(-c2b.y, c2b.y, d5);
+  // column 3
+  const float r3 = rsq(d3);
+  const pk2 c3b = a3b * r3;
+  d4a = pk_nfma(c3b, c3b.x, d4a);
+  d5 = fmaf(-c3b.y, c3b.y, d5);
+  // columns 4, 5
+  const float r4 = rsq(d4a.x);
+  const float l54 = d4a.y * r4;
+  d5 = fmaf(-l54, l54, d5);
+  F.idg[0] = r0; F.idg[1] = r1; F.idg[2] = r2; F.idg[3] = r3; F.idg[4] = r4; F.idg[5] = rsq(d5);
+  F.l10 = l10; F.l32 = l32; F.l54 = l54;
+  F.c0a = c0a; F.c0b = c0b; F.c1a = c1a; F.c1b = c1b; F.c2b = c2b; F.c3b = c3b;
+}
+// right-hand side (b0, b1, (b2,b3), (b4,b5))
+__device__ __forceinline__ void chol6_solve_pk(const Chol6Pk& F, float b0, float b1, pk2 b23, pk2 b45, float x[6]) {
+  float y[6];
+  y[0] = b0 * F.idg[0];
+  b1 = fmaf(-F.l10, y[0], b1); b23 = pk_nfma(F.c0a, y[0], b23); b45 = pk_nfma(F.c0b, y[0], b45);
+  y[1] = b1 * F.idg[1];
+  b23 = pk_nfma(F.c1a, y[1], b23); b45 = pk_nfma(F.c1b, y[1], b45);
+  y[2] = b23.x * F.idg[2];
+  b23.y = fmaf(-F.l32, y[2], b23.y); b45 = pk_nfma(F.c2b, y[2], b45);
+  y[3] = b23.y * F.idg[3];
+  b45 = pk_nfma(F.c3b, y[3], b45);
+  y[4] = b45.x * F.idg[4];
+  b45.y = fmaf(-F.l54, y[4], b45.y);
+  y[5] = b45.y * F.idg[5];
+  // backward substitution: x[i] = (y[i] - sum_{k > i} L[k][i] x[k]) / L[i][i], k ascending (the order of chol6_solve)
+  x[5] = y[5] * F.idg[5];
+  x[4] = fmaf(-F.l54, x[5], y[4]) * F.idg[4];
+  x[3] = fmaf(-F.c3b.y, x[5], fmaf(-F.c3b.x, x[4], y[3])) * F.idg[3];
+  x[2] = fmaf(-F.c2b.y, x[5], fmaf(-F.c2b.x, x[4], fmaf(-F.l32, x[3], y[2]))) * F.idg[2];
+  x[1] = fmaf(-F.c1b.y, x[5], fmaf(-F.c1b.x, x[4], fmaf(-F.c1a.y, x[3], fmaf(-F.c1a.x, x[2], y[1])))) * F.idg[1];
+  x[0] = fmaf(-F.c0b.y, x[5], fmaf(-F.c0b.x, x[4], fmaf(-F.c0a.y, x[3], fmaf(-F.c0a.x, x[2], fmaf(-F.l10, x[1], y[0]))))) * F.idg[0];
+}
+
 // Per-lane constants, loaded once per launch and kept in registers over the 33 sub-steps (a lone wave per SIMD cannot
 // hide the LDS round trips of re-reading them every sub-step).  Lane (leg = lane & 3, part = (lane >> 2) & 3) walks the
 // joints 0..min(part, 2) of its leg and owns link `part` (part 3: an idle copy with zero inertia): the chain constants of
@@ -217,7 +306,11 @@ __device__ __forceinline__ float part_suffix_sum(float x) {
 #ifndef ORR_ROW_SOLVE
 #define ORR_ROW_SOLVE 0     // 1: the rows solve with the Cholesky factor of A0 (kept in registers) instead of multiplying by an explicit A0^-1
 #endif
+#if ORR_CHOL_PK
+struct BaseFactor { Chol6Pk F; };
+#else
 struct BaseFactor { float L[21], idg[6]; };
+#endif
 __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst& K, int lane, BaseFactor& BF) {
   const int leg = lane & 3, part = (lane >> 2) & 3;
   float Rb[9];  // kinematic base frame -> world: kept current by base_rotation() (after every change of the quaternion)
@@ -360,14 +453,26 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
   }
   WSYNC();
   // ---- every lane of the leg: all three F columns and H ----
-  float F[3][6], b[3];
+  float b[3];
+#if ORR_CHOL_PK >= 2
+  pk2 F2[3][3];   // F2[k][p] = (F_k[2p], F_k[2p+1]): the columns of F come out of LDS as aligned pairs
+#else
+  float F[3][6];
+#endif
   float H00, H01, H02, H11, H12, H22;
   {
     const LegExchange& X = S.ph.sub.dyn.legx[leg];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
+#if ORR_CHOL_PK >= 2
+      static_assert(sizeof(X.F[0]) == 24 && alignof(LegExchange) >= 8, "pairs");
+      const pk2* XF = reinterpret_cast<const pk2*>(&X.F[k][0]);
+#pragma unroll
+      for (int q = 0; q < 3; q++) F2[k][q] = XF[q];
+#else
 #pragma unroll
       for (int i = 0; i < 6; i++) F[k][i] = X.F[k][i];
+#endif
       b[k] = X.b[k];
     }
     H00 = X.Hc[0][0]; H01 = X.Hc[1][0]; H11 = X.Hc[1][1]; H02 = X.Hc[2][0]; H12 = X.Hc[2][1]; H22 = X.Hc[2][2];
@@ -384,16 +489,54 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
   const float hq1 = part == 0 ? Hi[3] : (part == 1 ? Hi[1] : (part == 2 ? Hi[5] : 0.0f));
   const float hq2 = part == 0 ? Hi[4] : (part == 1 ? Hi[5] : (part == 2 ? Hi[2] : 0.0f));
   float Tq[6];  // column `part` of T = F H^-1
+#if ORR_CHOL_PK >= 2
+  pk2 Tq2[3];
+#pragma unroll
+  for (int q = 0; q < 3; q++) { Tq2[q] = F2[0][q] * hq0 + F2[1][q] * hq1 + F2[2][q] * hq2; Tq[2 * q] = Tq2[q].x; Tq[2 * q + 1] = Tq2[q].y; }
+#else
 #pragma unroll
   for (int i = 0; i < 6; i++) Tq[i] = F[0][i] * hq0 + F[1][i] * hq1 + F[2][i] * hq2;
+#endif
   {  // part-3 lanes: one shared dump slot; H^-1 is the same in all lanes of the leg, every one of them stores it
     LegSolve& Q = S.leg[leg];
     float* const tdst = part < 3 ? &Q.T[part][0] : &S.tdump[0];
+#if ORR_CHOL_PK >= 2
+#pragma unroll
+    for (int q = 0; q < 3; q++) reinterpret_cast<pk2*>(tdst)[q] = Tq2[q];
+#else
 #pragma unroll
     for (int i = 0; i < 6; i++) tdst[i] = Tq[i];
+#endif
 #pragma unroll
     for (int i = 0; i < 6; i++) Q.Hi[i] = Hi[i];
   }
+#if ORR_CHOL_PK >= 2
+  // The base matrix is accumulated, summed over the 16 lanes and factorised in ONE layout: the lower triangle by columns with the rows
+  // (2,3) and (4,5) paired (Chol6Pk).  Entry (j, i), j >= i, is the (i, j) entry of the old upper-triangle form: own inertia - Tq[i] Fo[j],
+  // i.e. column i = (own column) - Tq[i] * (Fo[i..5]) with Fo in pairs -- the same products and sums, 13 instead of 21 instructions.
+  float a0[6];
+  {
+    const pk2 Fo23 = {Fo[2], Fo[3]}, Fo45 = {Fo[4], Fo[5]};
+    float d0 = fmaf(-Tq[0], Fo[0], Iacc[0]), a10 = fmaf(-Tq[0], Fo[1], Iacc[3]);
+    pk2 a0a = pk_nfma(Fo23, Tq[0], pk2{Iacc[4], Hacc[0]}), a0b = pk_nfma(Fo45, Tq[0], pk2{Hacc[1], Hacc[2]});
+    float d1 = fmaf(-Tq[1], Fo[1], Iacc[1]);
+    pk2 a1a = pk_nfma(Fo23, Tq[1], pk2{Iacc[5], Hacc[3]}), a1b = pk_nfma(Fo45, Tq[1], pk2{Hacc[4], Hacc[5]});
+    pk2 d2a = pk_nfma(Fo23, Tq[2], pk2{Iacc[2], Hacc[6]}), a2b = pk_nfma(Fo45, Tq[2], pk2{Hacc[7], Hacc[8]});
+    float d3 = fmaf(-Tq[3], Fo[3], Macc[0]);
+    pk2 a3b = pk_nfma(Fo45, Tq[3], pk2{Macc[3], Macc[4]});
+    pk2 d4a = pk_nfma(Fo45, Tq[4], pk2{Macc[1], Macc[5]});
+    float d5 = fmaf(-Tq[5], Fo[5], Macc[2]);
+    pk2 p01 = __builtin_elementwise_fma(Tq2[0], pk2{bo, bo}, pk2{pacc[0], pacc[1]}), p23 = __builtin_elementwise_fma(Tq2[1], pk2{bo, bo}, pk2{pacc[2], pacc[3]});
+    pk2 p45 = __builtin_elementwise_fma(Tq2[2], pk2{bo, bo}, pk2{pacc[4], pacc[5]});
+    // base system: sum over all bodies / legs / joints = over the robot's 16 lanes (DPP butterfly fused into the adds)
+    auto sum2 = [](pk2& v) __attribute__((always_inline)) { v.x = row_sum16(v.x); v.y = row_sum16(v.y); };
+    d0 = row_sum16(d0); a10 = row_sum16(a10); d1 = row_sum16(d1); d3 = row_sum16(d3); d5 = row_sum16(d5);
+    sum2(a0a); sum2(a0b); sum2(a1a); sum2(a1b); sum2(d2a); sum2(a2b); sum2(a3b); sum2(d4a); sum2(p01); sum2(p23); sum2(p45);
+    static_assert(ORR_ROW_SOLVE, "the packed factor is kept for the rows");
+    chol6_pk(d0, d1, d3, d5, a10, d2a, d4a, a0a, a0b, a1a, a1b, a2b, a3b, BF.F);
+    chol6_solve_pk(BF.F, -p01.x, -p01.y, -p23, -p45, a0);
+  }
+#else
   // this lane's term of the elimination: -T_k F_k^T on the matrix, +T_k b_k on the force (Fo is zero in the part-3 lanes)
 #define TFT(i, j) (Tq[i] * Fo[j])
   Iacc[0] -= TFT(0, 0); Iacc[1] -= TFT(1, 1); Iacc[2] -= TFT(2, 2);
@@ -412,6 +555,17 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
 #pragma unroll
   for (int i = 0; i < 9; i++) Hacc[i] = row_sum16(Hacc[i]);
   float a0[6];
+#if ORR_CHOL_PK
+  {
+    // A0 = [[I, skew-ish H], [H^T, M]] (rows / columns 0..2 angular, 3..5 linear), lower triangle by columns
+    static_assert(ORR_ROW_SOLVE, "the packed factor is kept for the rows");
+    chol6_pk(Iacc[0], Iacc[1], Macc[0], Macc[2], /*(1,0)*/ Iacc[3], /*(2,2),(3,2)*/ pk2{Iacc[2], Hacc[6]}, /*(4,4),(5,4)*/ pk2{Macc[1], Macc[5]},
+             /*col 0 rows 2,3*/ pk2{Iacc[4], Hacc[0]}, /*rows 4,5*/ pk2{Hacc[1], Hacc[2]},
+             /*col 1 rows 2,3*/ pk2{Iacc[5], Hacc[3]}, /*rows 4,5*/ pk2{Hacc[4], Hacc[5]},
+             /*col 2 rows 4,5*/ pk2{Hacc[7], Hacc[8]}, /*col 3 rows 4,5*/ pk2{Macc[3], Macc[4]}, BF.F);
+    chol6_solve_pk(BF.F, -pacc[0], -pacc[1], pk2{-pacc[2], -pacc[3]}, pk2{-pacc[4], -pacc[5]}, a0);
+  }
+#else
   {
     float A6[36];
     float Im[9], Mm[9];
@@ -449,6 +603,8 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
     for (int i = 0; i < 6; i++) S.IA0inv[i * 6 + col] = x[i];   // lanes >= 6 store the same column again (col = lane % 6)
 #endif
   }
+#endif
+#endif   // ORR_CHOL_PK >= 2
   // joint accelerations qdd = H^-1 (b - F^T a0): row `part` of H^-1 for the lane's own joint; written as the unconstrained
   // velocity u* = u + dt udot by the lane that owns the joint (it has the joint rate)
   const float dt = P.cfg.sim_dt;
@@ -702,8 +858,12 @@ __device__ __forceinline__ void row_response(Shared& S, const orr_config& cfg, R
       fb2[p] = jb - (TL[p] * jl0 + TL[3 + p] * jl1 + TL[6 + p] * jl2);
     }
 #if ORR_ROW_SOLVE
+#if ORR_CHOL_PK
+    chol6_solve_pk(BF.F, fb2[0].x, fb2[0].y, fb2[1], fb2[2], a0);
+#else
     const float fb[6] = {fb2[0].x, fb2[0].y, fb2[1].x, fb2[1].y, fb2[2].x, fb2[2].y};
     chol6_solve(BF.L, BF.idg, fb, a0);
+#endif
 #pragma unroll
     for (int p = 0; p < 3; p++) a02[p] = v2f{a0[2 * p], a0[2 * p + 1]};
 #else
