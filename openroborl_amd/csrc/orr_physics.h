@@ -139,6 +139,14 @@ __device__ __forceinline__ void chol6_solve_pk(const Chol6Pk& F, float b0, float
 struct LegConst {
   float r[3][3], jdir[3], joff[3];  // chain: joint origin in the parent frame, internal angle = jdir * (q - joff)
   float com[3], m, Ic[6];           // own link: COM in the link frame, mass, inertia about the COM (xx yy zz xy xz yz)
+#ifndef ORR_MSUB          // carried in a register by the one-wave build only: the 256-register build pays more for the live register than for the two adds
+#ifdef ORR_TU_STEP_W2
+#define ORR_MSUB 0
+#else
+#define ORR_MSUB 1
+#endif
+#endif
+  float msub;                       // mass of the subtree behind the own joint (own + later links of the leg): constant over a launch
   float damp_l, damp_a;             // Bullet base damping coefficients in the lane that owns the base body, 0 elsewhere
   float jdir_own, joff_own;         // the lane's own joint (part < 3; jdir 0 for part 3): scalars, NOT selects over jdir[] / joff[] --
                                     // the compiler turns such a select into a dynamically indexed load, which pushes the whole
@@ -155,6 +163,7 @@ __device__ __forceinline__ void load_own_coord(const Shared& S, int lane, OwnCoo
   X.x0 = lane < 3 ? 0.0f : (lane < 6 ? S.s[O(POS) + lane - 3] : S.s[O(Q) + lane - 6]);
   X.x1 = lane < 2 ? S.s[O(Q) + 10 + lane] : 0.0f;
 }
+__device__ __forceinline__ float part_suffix_sum(float x);
 __device__ static void load_leg_const(const KParams& P, const Shared& S, int lane, LegConst& K) {
   const int leg = lane & 3, part = (lane >> 2) & 3, own = 3 * leg + (part < 3 ? part : 2);
   const ColdPtr mc = model_cold(P, geti(S, O(ROBOT_TYPE)));
@@ -183,6 +192,9 @@ __device__ static void load_leg_const(const KParams& P, const Shared& S, int lan
 #pragma unroll
     for (int i = 0; i < 6; i++) K.Ic[i] = (real || base) ? mc->inertia[body][i] * ir + mc->inertia_pa[body][i] * mr : 0.0f;
     K.m = (real || base) ? mass : 0.0f;
+#if ORR_MSUB
+    K.msub = part_suffix_sum(K.m);
+#endif
   }
   K.jdir_own = real ? S.m.jdir[own] : 0.0f;
   K.joff_own = S.m.joff[own];
@@ -248,9 +260,13 @@ __device__ __forceinline__ void spatial_inertia_mul(const float I[6], const floa
 #ifndef ORR_JOINT_DOWN_V2
 #define ORR_JOINT_DOWN_V2 1
 #endif
-template <int AX>
+#ifndef ORR_LD_V3
+#define ORR_LD_V3 1   // round 4, v39: leg dynamics with fewer selects / repeated products (see the spots)
+#endif
+template <int AX, bool SAME_AXIS = false>
 __device__ __forceinline__ void joint_down(const Shared& S, const LegConst& K, int k, int j, float sn, float cs, float Rw[9], float d[3],
-                                           float Vw[3], float Vv[3], float Aa[3], float Al[3], float s[3], float sv[3], float& ad_out) {
+                                           float Vw[3], float Vv[3], float Aa[3], float Al[3], float s[3], float sv[3], float& ad_out,
+                                           float* c0 = nullptr) {
   const float ad = K.jdir[k] * S.s[O(QD) + j];
   ad_out = ad;
   // pose: d += Rw_parent r;  Rw = Rw_parent R(a)
@@ -270,7 +286,12 @@ __device__ __forceinline__ void joint_down(const Shared& S, const LegConst& K, i
   // products: s x s = 0 and (s ad) x (sv ad) + (sv ad) x (s ad) = 0), then V += S ad: 30 instructions instead of 39 per joint step.
   // 4096 robots 0.2256 -> 0.2236 ms, 8192 robots 0.3158 -> 0.3136 ms (round 4, interleaved A/B).
   {
-    const float c0x = Vw[1] * s[2] - Vw[2] * s[1], c0y = Vw[2] * s[0] - Vw[0] * s[2], c0z = Vw[0] * s[1] - Vw[1] * s[0];
+    // SAME_AXIS: the joint's axis is the previous joint's (hip pitch -> knee: both about the link's y, a pure translation between them),
+    // so Vw x s = (Vw_prev + qd_prev s) x s = Vw_prev x s: the previous joint's product is taken over (-6 instructions)
+    float c0x, c0y, c0z;
+    if (SAME_AXIS && ORR_LD_V3) { c0x = c0[0]; c0y = c0[1]; c0z = c0[2]; }
+    else { c0x = Vw[1] * s[2] - Vw[2] * s[1]; c0y = Vw[2] * s[0] - Vw[0] * s[2]; c0z = Vw[0] * s[1] - Vw[1] * s[0]; }
+    if (c0) { c0[0] = c0x; c0[1] = c0y; c0[2] = c0z; }
     const float c1x = fmaf(Vv[1], s[2], fmaf(-Vv[2], s[1], Vw[1] * sv[2] - Vw[2] * sv[1]));
     const float c1y = fmaf(Vv[2], s[0], fmaf(-Vv[0], s[2], Vw[2] * sv[0] - Vw[0] * sv[2]));
     const float c1z = fmaf(Vv[0], s[1], fmaf(-Vv[1], s[0], Vw[0] * sv[1] - Vw[1] * sv[0]));
@@ -336,22 +357,43 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
     const float cA = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(cso), 0x114, 0xF, 0xF, true));
     const float sB = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sno), 0x118, 0xF, 0xF, true));  // row_shr:8
     const float cB = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(cso), 0x118, 0xF, 0xF, true));
+#if ORR_LD_V3
+    // the selects over `part` as bank-masked DPP moves (a bank = the four lanes of one part): a lane keeps its own value where the mask
+    // is off, and a shift from beyond the row writes 0 (bound_ctrl) -- the own values of the part-3 lanes are sin 0 = 0, cos 0 = 1
+    //   sn0 / cs0 = [own, shr4, shr8, own]   sn1 = [0 (from beyond the row), own, shr4, own = 0]   cs1 = [1, own, shr4, own = 1]
+    sn0 = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(sno), __float_as_int(sno), 0x114, 0xF, 0x2, false));
+    sn0 = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(sn0), __float_as_int(sno), 0x118, 0xF, 0x4, false));
+    cs0 = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(cso), __float_as_int(cso), 0x114, 0xF, 0x2, false));
+    cs0 = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(cs0), __float_as_int(cso), 0x118, 0xF, 0x4, false));
+    sn1 = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(sno), __float_as_int(sno), 0x114, 0xF, 0x5, true));
+    cs1 = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(cso), __float_as_int(cso), 0x114, 0xF, 0x4, false));
+    cs1 = part == 0 ? 1.0f : cs1;
+    (void)sA; (void)cA; (void)sB; (void)cB;
+#else
     sn0 = part == 0 ? sno : (part == 1 ? sA : (part == 2 ? sB : 0.0f));
     cs0 = part == 0 ? cso : (part == 1 ? cA : (part == 2 ? cB : 1.0f));
     sn1 = part == 1 ? sno : (part == 2 ? sA : 0.0f);
     cs1 = part == 1 ? cso : (part == 2 ? cA : 1.0f);
+#endif
     sn2 = part == 2 ? sno : 0.0f;
     cs2 = part == 2 ? cso : 1.0f;
   }
+  float c0k[3];
   joint_down<0>(S, K, 0, 3 * leg, sn0, cs0, Rw, d, Vw, Vv, Aa, Al, s0, sv0, ad0);
-  joint_down<1>(S, K, 1, 3 * leg + 1, sn1, cs1, Rw, d, Vw, Vv, Aa, Al, s1, sv1, ad1);
-  joint_down<1>(S, K, 2, 3 * leg + 2, sn2, cs2, Rw, d, Vw, Vv, Aa, Al, s2, sv2, ad2);
+  joint_down<1>(S, K, 1, 3 * leg + 1, sn1, cs1, Rw, d, Vw, Vv, Aa, Al, s1, sv1, ad1, c0k);
+  joint_down<1, true>(S, K, 2, 3 * leg + 2, sn2, cs2, Rw, d, Vw, Vv, Aa, Al, s2, sv2, ad2, c0k);
   // own joint: axis and rate
   float so[3], svo[3];
 #pragma unroll
   for (int i = 0; i < 3; i++) {
+#if ORR_LD_V3
+    // the joints behind a lane's own link are identity steps with zero offsets: for a part-1 lane (s2, sv2) ARE (s1, sv1), bit for bit
+    so[i] = part == 0 ? s0[i] : (part == 3 ? 0.0f : s2[i]);        // part 3 owns no joint: F, T columns = 0
+    svo[i] = part == 0 ? sv0[i] : (part == 3 ? 0.0f : sv2[i]);
+#else
     so[i] = part == 0 ? s0[i] : (part == 1 ? s1[i] : (part == 2 ? s2[i] : 0.0f));       // part 3 owns no joint: F, T columns = 0
     svo[i] = part == 0 ? sv0[i] : (part == 1 ? sv1[i] : (part == 2 ? sv2[i] : 0.0f));
+#endif
   }
   const float ado = part == 0 ? ad0 : (part == 1 ? ad1 : ad2);
   {  // pose and joint axis of the own link for the constraint rows (part-3 lanes: dump slot)
@@ -433,7 +475,11 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
   for (int i = 0; i < 6; i++) { I[i] = part_suffix_sum(I[i]); f[i] = part_suffix_sum(f[i]); }
 #pragma unroll
   for (int i = 0; i < 3; i++) h[i] = part_suffix_sum(h[i]);
+#if ORR_LD_V3 && ORR_MSUB
+  m = K.msub;
+#else
   m = part_suffix_sum(m);
+#endif
   // own column of F and of the leg's joint-space inertia H (entries H[i][part], i <= part), own bias torque
   float Fo[6], bo;
   {
