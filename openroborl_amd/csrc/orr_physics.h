@@ -925,6 +925,34 @@ __device__ __forceinline__ void row_response(Shared& S, const orr_config& cfg, R
   const float h0 = QL.Hi[0] * jl0 + QL.Hi[3] * jl1 + QL.Hi[4] * jl2;
   const float h1 = QL.Hi[3] * jl0 + QL.Hi[1] * jl1 + QL.Hi[5] * jl2;
   const float h2 = QL.Hi[4] * jl0 + QL.Hi[5] * jl1 + QL.Hi[2] * jl2;
+#ifndef ORR_ROWRESP_V2     // 1: (a), 2: (a) + (b); the two-wave unit takes (a) only: four more live registers cost it 30 spilled ones
+#ifdef ORR_TU_STEP_W2
+#define ORR_ROWRESP_V2 1
+#else
+#define ORR_ROWRESP_V2 2
+#endif
+#endif
+#if ORR_ROWRESP_V2
+  // round 4, v40.  (a) The diagonal J W = Jb . a0 + jl . mq_L without the own-leg selects: with fb = Jb - T_L jl (above) and
+  // mq_L = H_L^-1 jl - T_L^T a0 it is jl . (H_L^-1 jl) + fb . a0 -- nine multiply-adds (three of them on pairs) instead of 26 instructions.
+  // (b) "H_L^-1 jl for the own leg, 0 for the others" as a multiply-add with a 0 / 1 factor per leg instead of twelve selects.
+  const v2f dg = fb2[0] * a02[0] + fb2[1] * a02[1] + fb2[2] * a02[2];    // first: fb dies here
+  float dgs = dg.x + dg.y;
+  asm volatile("" : "+v"(dgs));
+  const float own0 = leg == 0 ? 1.0f : 0.0f, own1 = leg == 1 ? 1.0f : 0.0f, own2 = leg == 2 ? 1.0f : 0.0f, own3 = leg == 3 ? 1.0f : 0.0f;
+#pragma unroll
+  for (int L4 = 0; L4 < 4; L4++) {
+    const v2f* TK = reinterpret_cast<const v2f*>(&S.leg[L4].T[0][0]);
+    const float own = L4 == 0 ? own0 : (L4 == 1 ? own1 : (L4 == 2 ? own2 : own3));
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const v2f t2 = TK[3 * k] * a02[0] + TK[3 * k + 1] * a02[1] + TK[3 * k + 2] * a02[2];
+      const float hk = k == 0 ? h0 : (k == 1 ? h1 : h2);
+      mq[3 * L4 + k] = ORR_ROWRESP_V2 >= 2 ? fmaf(own, hk, -(t2.x + t2.y)) : ((L4 == leg ? hk : 0.0f) - (t2.x + t2.y));   // the same value either way
+    }
+  }
+  const float diag = fmaf(jl0, h0, fmaf(jl1, h1, fmaf(jl2, h2, dgs)));
+#else
   float diag = 0.0f;
 #pragma unroll
   for (int L4 = 0; L4 < 4; L4++) {
@@ -939,6 +967,7 @@ __device__ __forceinline__ void row_response(Shared& S, const orr_config& cfg, R
   }
 #pragma unroll
   for (int i = 0; i < 6; i++) diag += R.Jb[i] * a0[i];
+#endif
   // an inactive row stores too (zeros: its Jacobian is zero; its impulse stays zero anyway)
 #pragma unroll
   for (int i = 0; i < 6; i++) S.ph.sub.W[slot][i] = a0[i];
