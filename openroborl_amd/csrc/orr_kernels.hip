@@ -25,7 +25,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-// The constraint rows need A0^-1 (Jb - T_L jl): every row lane solves with the Cholesky factor of A0, which stays in 27 registers from
+// The constraint rows need A0^-1 (Jb - T_L jl): every row lane solves with the Cholesky factor of A0, which stays in registers (15 entries + 6 reciprocal pivots, Chol6Pk) from
 // the leg dynamics on (-54 instructions per sub-step there: no unit-column solve, no A0^-1 through LDS; +15 per bank in the row
 // response).  4096 robots 0.2338 -> 0.2295 ms; the two-wave unit (256 registers, spilling) is neutral (8192 robots 0.3265 vs 0.3255 ms)
 // and takes it too, so that both variants of the kernel keep giving the same bits.  ORR_ROW_SOLVE=0: the explicit inverse in LDS.

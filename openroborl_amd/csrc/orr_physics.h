@@ -216,14 +216,15 @@ __device__ static void load_leg_const(const KParams& P, const Shared& S, int lan
 //   qdd_L = H_L^-1 (tau_L - C_L - F_L^T a0)
 // A leg is a chain of three joints about coordinate axes of the link frames (hip x, upper / lower leg y), so its
 // world joint axis is a column of the link rotation.  What the constraint rows need afterwards is small and goes to
-// LDS: T_L (6x3), H_L^-1 per leg and A0^-1 (LegSolve / Shared::IA0inv) - the impulse response of a row is then
+// LDS (T_L (6x3), H_L^-1 per leg: LegSolve) or stays in registers (the Cholesky factor of A0: BaseFactor) - the impulse response of a row is then
 //   da0 = A0^-1 (Jb - T_L jl);  dqdd_L = H_L^-1 jl - T_L^T da0;  dqdd_K = -T_K^T da0  (K != L).
 // Lane (leg = lane & 3, part = (lane >> 2) & 3): all lanes of a leg walk down its joints, but each computes the costly
 // per-link terms (inertia about O, bias force) only for link `part` (lane 12 = (leg 0, part 3) for the base body itself);
 // subtree sums run over the parts with DPP row shifts, F / H / bias torques of the three joints are exchanged through LDS
 // (LegExchange).  The base system is then ASSEMBLED across the 16 lanes: lane (leg, k) contributes its own link's inertia /
 // bias force and the k-th term of the leg's elimination, -T_k F_k^T and T_k b_k (T_k = column k of F H^-1), and one 16-lane
-// DPP butterfly per entry sums bodies, legs and joints at once; the 6x6 solve itself is redundant in all lanes.
+// DPP butterfly per entry sums bodies, legs and joints at once; the 6x6 solve itself is redundant in all lanes.  Elimination terms, sums,
+// factorisation and solves share ONE layout on packed float pairs (Chol6Pk above).
 // ================================================================================================
 
 // R S R^T for a symmetric S (xx yy zz xy xz yz) and a general rotation R (row-major)
