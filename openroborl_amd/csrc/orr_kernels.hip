@@ -231,8 +231,9 @@ __global__ __launch_bounds__((MODE == 0 && WPE == 1 ? 64 * ORR_WPB : 64)) __attr
   // the leftover slots, and when the older one has finished the younger runs on alone at a lone wave's pace (half the SIMD idle).  The
   // two waves of a SIMD come from consecutive dispatch rounds (workgroup b: round b / #SIMDs), so raising the priority of the even rounds
   // in even sub-steps and of the odd rounds in odd sub-steps lets them take turns at being the favoured one and finish together.
-  // 8192 robots: 0.349 -> 0.331 ms (-5.3 %); turns of 2 or 4 sub-steps, or a second flip in the middle of a sub-step, are no better
-  // (0.332 / 0.332 / 0.335; tools/build_variants.py: -DORR_PRIO_SHIFT=n, -DORR_NO_PRIO_ALTERNATION).
+  // 8192 robots: 0.349 -> 0.331 ms (-5.3 %, round 3; turns of 2 or 4 sub-steps or a second flip in the middle of a sub-step were no
+  // better then: 0.332 / 0.332 / 0.335).  Round 4, final code: turns of FOUR sub-steps 0.3015 -> 0.2991 ms (2: 0.2995, 8 / 16: 0.3032 /
+  // 0.3027; without the alternation 0.317; tools/build_variants.py: -DORR_PRIO_TURN=n, -DORR_NO_PRIO_ALTERNATION).
   const int prio_phase = WPE == 2 ? (int)(((unsigned)wave_id / (unsigned)(P.simds > 0 ? P.simds : 1)) & 1u) : 0;
 #endif
   // What the PD law of a sub-step reads - the delayed angle of the lane's motor (control observation), the joint's true angle and rate -
@@ -250,10 +251,13 @@ __global__ __launch_bounds__((MODE == 0 && WPE == 1 ? 64 * ORR_WPB : 64)) __attr
   float co_own = S.co[ml], qm_c = (S.s[O(Q) + mj] - m_off) * m_dir, qdm_c = S.s[O(QD) + mj] * m_dir;
   for (int sstep = 0; sstep < c.action_repeat; sstep++) {
 #ifndef ORR_NO_PRIO_ALTERNATION
-#ifndef ORR_PRIO_SHIFT
-#define ORR_PRIO_SHIFT 0      // favoured for 2^ORR_PRIO_SHIFT sub-steps at a time (measured: tools/ab_variants.sh)
+#ifndef ORR_PRIO_TURN
+#define ORR_PRIO_TURN 4       // favoured for ORR_PRIO_TURN sub-steps at a time (measured: tools/ab_variants.sh, profiles/r04_ab25..28_8192.log)
 #endif
-    if (WPE == 2) { if (((sstep >> ORR_PRIO_SHIFT) ^ prio_phase) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+#ifndef ORR_PRIO_HI
+#define ORR_PRIO_HI 1
+#endif
+    if (WPE == 2) { if (((sstep / ORR_PRIO_TURN) ^ prio_phase) & 1) __builtin_amdgcn_s_setprio(ORR_PRIO_HI); else __builtin_amdgcn_s_setprio(0); }
 #endif
     if (kLanes != 16 && sstep > 0) ctrl_obs(P, rec, S, lane);
     {  // every lane (no divergent `if`: it would cost more than it skips); lanes 12..15 repeat motor 0 and store into dump slots
