@@ -40,7 +40,11 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O2", "-fPIC", "-shared", "-std=c++17",
 # Round 4: of the compiler's other scheduling strategies the register-pressure-minded `iterative-maxocc` suits this unit best
 # (8192 robots, interleaved A/B: default 0.3086 ms, iterative-maxocc 0.3022, max-memory-clause 0.3090, iterative-minreg 0.3207; the one-wave
 # unit keeps iterative-ilp: maxocc 0.2218 against 0.2180, max-ilp 0.2349, max-memory-clause 0.2329; profiles/r04_ab11_8192.txt, r04_ab12_4096.txt).
-HIPCC_FLAGS_W2 = ["-O3" if f == "-O2" else ("-amdgpu-sched-strategy=iterative-maxocc" if "amdgpu-sched-strategy" in f else f) for f in HIPCC_FLAGS]
+# Round 4, last sweep on the final code (tools/build_variants.py, four interleaved rounds, profiles/r04_ab25..29_8192.log): -Os instead of -O3
+# together with the priority knobs of the kernel (turns of four sub-steps, high priority past the loop) 0.2988 -> 0.2976 ms; -Os alone
+# is within the noise (0.2987), -Oz costs 1 %.  (What -Os changes here is the register allocation's luck, not the amount of code: every
+# function of the kernel is forced inline and every loop unrolled by pragma.)
+HIPCC_FLAGS_W2 = ["-Os" if f == "-O2" else ("-amdgpu-sched-strategy=iterative-maxocc" if "amdgpu-sched-strategy" in f else f) for f in HIPCC_FLAGS]
 
 EXPORTS = [
     "orr_last_error", "orr_abi_version", "orr_source_hash", "orr_state_stride", "orr_layout_count", "orr_layout_name",
