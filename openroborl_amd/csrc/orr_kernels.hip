@@ -257,7 +257,13 @@ __global__ __launch_bounds__((MODE == 0 && WPE == 1 ? 64 * ORR_WPB : 64)) __attr
 #ifndef ORR_PRIO_HI
 #define ORR_PRIO_HI 1
 #endif
-    if (WPE == 2) { if (((sstep / ORR_PRIO_TURN) ^ prio_phase) & 1) __builtin_amdgcn_s_setprio(ORR_PRIO_HI); else __builtin_amdgcn_s_setprio(0); }
+#ifndef ORR_PRIO_OFFSET
+#define ORR_PRIO_OFFSET 1     // the turns start one sub-step early: the younger wave of a SIMD leads with a turn of three and has the last two sub-steps
+#endif                        // (8192 robots 0.3012 -> 0.2998 ms; offsets 2 / 3 / 4 (= the older wave leads): 0.3030 / 0.3042 / 0.3046; equal priority for the
+#ifndef ORR_PRIO_EQUAL_FROM   // last 4 / 8 sub-steps: 0.3026 / 0.3014; profiles/r04_ab30_8192.log)
+#define ORR_PRIO_EQUAL_FROM 1000
+#endif
+    if (WPE == 2) { if (sstep < ORR_PRIO_EQUAL_FROM && ((((sstep + ORR_PRIO_OFFSET) / ORR_PRIO_TURN) ^ prio_phase) & 1)) __builtin_amdgcn_s_setprio(ORR_PRIO_HI); else __builtin_amdgcn_s_setprio(0); }
 #endif
     if (kLanes != 16 && sstep > 0) ctrl_obs(P, rec, S, lane);
     {  // every lane (no divergent `if`: it would cost more than it skips); lanes 12..15 repeat motor 0 and store into dump slots
