@@ -144,6 +144,9 @@ struct KParams {
   float* ep_log;
   int ep_log_cap;
   int simds;           // SIMDs of the device: workgroup b belongs to dispatch round b / simds (two-waves-per-SIMD variant: priority alternation)
+#ifdef ORR_WAVE_TIMELINE
+  long long* wave_times;   // development aid (tools/wave_times.py): 4 words per wave of the step kernel, either variant
+#endif
 };
 // The cold part of a robot type's model, as a GLOBAL-address-space pointer: loads through it are global_load instructions (a generic
 // pointer would make them FLAT loads, which also count on the LDS counter and serialise with every LDS access in between).

@@ -52,6 +52,18 @@ __device__ long long g_wave_timeline[4 * 2048];   // per wave of the last launch
 #define PT_TIMELINE(flag)
 #endif
 
+// Development aid (tools/wave_times.py): -DORR_WAVE_TIMELINE makes every wave of the step kernel - BOTH variants, product code otherwise -
+// record when it started and ended (100 MHz realtime counter), its shader cycles and the hardware slot it ran on (nothing else is
+// instrumented: two s_memrealtime / s_memtime pairs and one 32-byte store per wave)
+#ifdef ORR_WAVE_TIMELINE
+#define WT_INIT() const long long wt_r0 = wall_clock64(), wt_c0 = clock64()
+#define WT_STORE(flag) do { if ((threadIdx.x & 63u) == 0 && P.wave_times) { long long* w_ = P.wave_times + 4 * (size_t)wave_id; w_[0] = wt_r0; w_[1] = wall_clock64(); w_[2] = clock64() - wt_c0; \
+    w_[3] = ((flag) & 0xFF) | ((long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 8) | ((long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xF) << 40); } } while (0)
+#else
+#define WT_INIT()
+#define WT_STORE(flag)
+#endif
+
 // Development aid (tools/dual_contact.py): -DORR_COUNT_DUAL_CONTACT counts, per leg and sub-step, how often the toe sphere and the shank
 // sphere of a lower leg are within the contact margin / penetrating at the same time (the engine makes ONE contact point per leg, Bullet
 // one per touching shape: DESIGN.md section 9).  One-wave kernel only.
@@ -133,6 +145,7 @@ __global__ __launch_bounds__((MODE == 0 && WPE == 1 ? 64 * ORR_WPB : 64)) __attr
   const bool valid = in_range;
   const orr_config& c = P.cfg;
   PT_INIT();
+  WT_INIT();
   // curriculum counter as of the start of the launch (the last wave of the previous launch folded that launch's episodes in):
   // read here, far ahead of its only use (the time limit of an episode that starts in this launch)
   const long long total_snapshot = P.counters[ORR_CNT_TOTAL_STEP_COUNT];
@@ -456,6 +469,7 @@ __global__ __launch_bounds__((MODE == 0 && WPE == 1 ? 64 * ORR_WPB : 64)) __attr
     }
   }
   PT_TIMELINE((long long)((fin_mask & 1ull) | ((fin_mask >> 15) & 2ull) | ((fin_mask >> 30) & 4ull) | ((fin_mask >> 45) & 8ull)));   // one bit per robot of the wave
+  WT_STORE((long long)((fin_mask & 1ull) | ((fin_mask >> 15) & 2ull) | ((fin_mask >> 30) & 4ull) | ((fin_mask >> 45) & 8ull)));
 }
 
 namespace orr {
@@ -754,6 +768,10 @@ int32_t orr_bind(orr_handle* h, void* state_dev, int64_t* counters_dev, float* e
   return 0;
 }
 
+#ifdef ORR_WAVE_TIMELINE
+static long long* g_wave_times_dev = nullptr;
+static int g_wave_times_cap = 0;
+#endif
 static KParams make_params(const orr_handle* h) {
   KParams P;
   P.cfg = h->cfg;
@@ -764,6 +782,9 @@ static KParams make_params(const orr_handle* h) {
   P.ep_log = h->ep_log;
   P.ep_log_cap = h->ep_log_cap;
   P.simds = h->simds;
+#ifdef ORR_WAVE_TIMELINE
+  P.wave_times = g_wave_times_dev;
+#endif
   return P;
 }
 
@@ -869,6 +890,23 @@ int orr_debug_dual_contact(unsigned long long* out8, int reset) {
     unsigned long long z[8] = {0};
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_dual_contact), z, sizeof(z)), "orr_debug_dual_contact: clear");
   }
+  return 0;
+}
+#endif
+#ifdef ORR_WAVE_TIMELINE
+// development aid: per-wave timeline of the last step launch of either variant (4 words per wave: realtime start / end in 100 MHz ticks,
+// shader cycles, bits 0..7 mask of the robots that finished an episode | bits 8..39 HW_ID (wave slot, SIMD, CU, SE) | bits 40..43 XCC id).
+// The first call (waves > 0, out may be null) allocates the device buffer; launches after it are recorded.
+int orr_debug_wave_times(long long* out, int waves) {
+  HIPCHK(hipDeviceSynchronize(), "orr_debug_wave_times: sync");
+  if (waves > g_wave_times_cap) {
+    if (g_wave_times_dev) HIPCHK(hipFree(g_wave_times_dev), "orr_debug_wave_times: free");
+    HIPCHK(hipMalloc((void**)&g_wave_times_dev, (size_t)waves * 4 * sizeof(long long)), "orr_debug_wave_times: alloc");
+    HIPCHK(hipMemset(g_wave_times_dev, 0, (size_t)waves * 4 * sizeof(long long)), "orr_debug_wave_times: clear");
+    g_wave_times_cap = waves;
+    return 0;
+  }
+  if (out) HIPCHK(hipMemcpy(out, g_wave_times_dev, (size_t)waves * 4 * sizeof(long long), hipMemcpyDeviceToHost), "orr_debug_wave_times: read");
   return 0;
 }
 #endif

@@ -147,7 +147,8 @@ def test_headers_are_plain_c():
 @pytest.mark.parametrize("defs", [
     ["-DORR_CHOL_PK=0"], ["-DORR_CHOL_PK=1"], ["-DORR_CHOL_PK=0", "-DORR_ROW_SOLVE=0"], ["-DORR_ROWRESP_V2=0"], ["-DORR_ROWRESP_V2=1"],
     ["-DORR_LD_V3=0"], ["-DORR_MSUB=0"], ["-DORR_BRANCHFREE_ROWS=0"], ["-DORR_JOINT_DOWN_V2=0", "-DORR_BIAS_COM=0"], ["-DORR_DIAG_VCC=0"],
-    ["-DORR_GENERIC_PGS"], ["-DORR_PHASE_TIMERS"], ["-DORR_COUNT_DUAL_CONTACT"], ["-DORR_WPB=2"]])
+    ["-DORR_GENERIC_PGS"], ["-DORR_PHASE_TIMERS"], ["-DORR_COUNT_DUAL_CONTACT"], ["-DORR_WPB=2"], ["-DORR_WAVE_TIMELINE"],
+    ["-DORR_PRIO_TURN=2", "-DORR_PRIO_OFFSET=0", "-DORR_PRIO_TAIL=-1"], ["-DORR_NO_PRIO_ALTERNATION"]])
 def test_the_kernel_tuning_knobs_still_compile(defs):
     """The step kernel carries its measured alternatives as preprocessor knobs (each kept change can be switched
     back for an A/B on the GPU, tools/build_variants.py).  An alternative that no longer compiles is a lie in the measurement log: every
