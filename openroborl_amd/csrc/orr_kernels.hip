@@ -248,6 +248,12 @@ __global__ __launch_bounds__((MODE == 0 && WPE == 1 ? 64 * ORR_WPB : 64)) __attr
   // better then: 0.332 / 0.332 / 0.335).  Round 4, final code: turns of FOUR sub-steps 0.3015 -> 0.2991 ms (2: 0.2995, 8 / 16: 0.3032 /
   // 0.3027; without the alternation 0.317; tools/build_variants.py: -DORR_PRIO_TURN=n, -DORR_NO_PRIO_ALTERNATION).
   const int prio_phase = WPE == 2 ? (int)(((unsigned)wave_id / (unsigned)(P.simds > 0 ? P.simds : 1)) & 1u) : 0;
+  // Taking turns pairs the dispatch rounds (0, 1), (2, 3) ...: with an ODD number of rounds the last one has no partner of its own, and the
+  // plain age order - the oldest wave of a SIMD runs at nearly a lone wave's pace, the next one moves up when it ends - is the better
+  // pipeline (12288 robots = 3 rounds: 0.4925 -> 0.4693 ms without the turns; 16384 / 32768 robots = 4 / 8 rounds: 0.5767 / 1.103 ms with
+  // them against 0.5847 / 1.109 without; profiles/r04_ab34_large.log)
+  const bool prio_turns = WPE == 2 && ((((unsigned)gridDim.x * (unsigned)step_wpb<MODE, WPE>() + (unsigned)(P.simds > 0 ? P.simds : 1) - 1u) /
+                                        (unsigned)(P.simds > 0 ? P.simds : 1)) & 1u) == 0u;
 #endif
   // What the PD law of a sub-step reads - the delayed angle of the lane's motor (control observation), the joint's true angle and rate -
   // is produced at the END of the previous sub-step: the control-observation word by this very lane, angle and rate by the integration
@@ -276,7 +282,7 @@ __global__ __launch_bounds__((MODE == 0 && WPE == 1 ? 64 * ORR_WPB : 64)) __attr
 #ifndef ORR_PRIO_EQUAL_FROM   // last 4 / 8 sub-steps: 0.3026 / 0.3014; profiles/r04_ab30_8192.log)
 #define ORR_PRIO_EQUAL_FROM 1000
 #endif
-    if (WPE == 2) { if (sstep < ORR_PRIO_EQUAL_FROM && ((((sstep + ORR_PRIO_OFFSET) / ORR_PRIO_TURN) ^ prio_phase) & 1)) __builtin_amdgcn_s_setprio(ORR_PRIO_HI); else __builtin_amdgcn_s_setprio(0); }
+    if (WPE == 2 && prio_turns) { if (sstep < ORR_PRIO_EQUAL_FROM && ((((sstep + ORR_PRIO_OFFSET) / ORR_PRIO_TURN) ^ prio_phase) & 1)) __builtin_amdgcn_s_setprio(ORR_PRIO_HI); else __builtin_amdgcn_s_setprio(0); }
 #endif
     if (kLanes != 16 && sstep > 0) ctrl_obs(P, rec, S, lane);
     {  // every lane (no divergent `if`: it would cost more than it skips); lanes 12..15 repeat motor 0 and store into dump slots
