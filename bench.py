@@ -336,6 +336,8 @@ def main():
         tag = args.config + ("_norand" if args.no_randomizer else "")
         if os.environ.get("ORR_STEP_WAVES_PER_EU") == "1" and n > 4 * 4 * torch.cuda.get_device_properties(dev).multi_processor_count:
             tag += "_wpe1"          # a batch that would run the two-waves-per-SIMD variant, forced onto the one-wave kernel (comparison runs)
+        if os.environ.get("ORR_STEP_WAVES_PER_EU") == "2" and n <= 4 * 4 * torch.cuda.get_device_properties(dev).multi_processor_count:
+            tag += "_wpe2"          # the reverse (a small batch forced onto the two-wave kernel): the committed counters of this config are another kernel's
         lib_hash = env.L.orr_source_hash().decode()
         pmc_stale, pmc_seen = None, []
         for rnd in ("r04", "r03", "r02"):
