@@ -259,13 +259,14 @@ __global__ __launch_bounds__((MODE == 0 && WPE == 1 ? 64 * ORR_WPB : 64)) __attr
   // is produced at the END of the previous sub-step: the control-observation word by this very lane, angle and rate by the integration
   // (read from LDS there anyway, for the ring entry).  Carried over in registers (ORR_CARRY_PD), the top of the loop has no LDS round
   // trip of its own: a lone wave has nothing to overlap one with there.  Same values, bit for bit.  4096 robots 0.2235 -> 0.2205 ms.
-  // ONE-wave build only: with two waves per SIMD the partner wave fills those gaps anyway and the three registers carried across the
-  // whole sub-step cost more than they save (8192 robots 0.3130 -> 0.3160 ms with it).  Measured and NOT kept in the one-wave build:
+  // The two-wave build lost 1 % with it when it was introduced (8192 robots 0.3130 -> 0.3160 ms: three more registers across the sub-step)
+  // and takes it since the end of round 4: a wave pair runs 1.33 x the LONE time of its build whatever the scheduling (DESIGN.md section
+  // 10), and on the final code the carry is worth 0.3014 -> 0.2991 ms (profiles/r04_ab39_8192.log).  Measured and NOT kept in the one-wave build:
   // carrying the base rotation the same way (nine words that leg_dynamics reads back from LDS: 0.2206, neutral), and issuing the loads
   // of the leg dynamics' first reads (base rotation / velocity, own joint angle, the leg's joint rates: 19 registers) in front of the
   // PD law (0.2208 -> 0.2223: worse).
 #ifndef ORR_CARRY_PD
-#define ORR_CARRY_PD (WPE == 1)
+#define ORR_CARRY_PD 1
 #endif
   float co_own = S.co[ml], qm_c = (S.s[O(Q) + mj] - m_off) * m_dir, qdm_c = S.s[O(QD) + mj] * m_dir;
   for (int sstep = 0; sstep < c.action_repeat; sstep++) {
