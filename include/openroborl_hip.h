@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ORR_ABI_VERSION 4
+#define ORR_ABI_VERSION 5
 
 #define ORR_NUM_MOTORS 12 /* laikago.py:29, mini_cheetah.py:29 */
 #define ORR_NUM_LEGS 4
@@ -82,7 +82,11 @@ extern "C" {
   X(DONE_REASON, 1, I)   /* of the last step; survives the (auto-)reset that follows it */    \
   X(RESERVED_I, 2, I)                                                                         \
   /* latency ring (minitaur.py:127,313-357): ORR_RING_DEPTH entries of ORR_RING_ENTRY */      \
-  X(RING, ORR_RING_DEPTH * ORR_RING_ENTRY, F)
+  X(RING, ORR_RING_DEPTH * ORR_RING_ENTRY, F)                                                 \
+  /* ABI v5, behind the ring (never staged with the head): Bullet's friction anchors, one cached contact point per toe             \
+   * (btPersistentManifold::replaceContactPoint): the point on the toe in the lower-leg link frame (3) and on the plane in world (3) */ \
+  X(ANCHOR, 4 * 6, F)                                                                         \
+  X(ANCHOR_VALID, 4, I)  /* per leg: 1 = that toe holds a cached point */
 
 enum orr_state_offset_e {
 #define ORR_X_OFF(name, words, kind) ORR_OFF_##name, ORR_OFFEND_##name = ORR_OFF_##name + (words)-1,
@@ -139,6 +143,8 @@ typedef struct orr_config {
   float max_angle_change;    /* 0.2: laikago.py:71 MAX_MOTOR_ANGLE_CHANGE_PER_STEP */
   float dist_fail_threshold; /* 1.0: imitation_task.py:518 */
   float rot_fail_threshold;  /* pi/2 */
+  float friction_erp;        /* ABI v5: 0.2 = Bullet's m_frictionERP: share of a friction anchor's tangential drift removed per sub-step
+                                (friction rows get -drift * friction_erp / dt; only toes with orr_model::friction_anchor) */
 } orr_config;
 
 /* Robot model table (data, swappable without touching kernels).  All geometry is given in the
@@ -179,6 +185,9 @@ typedef struct orr_model {
   float contact_damping;                /* the toe's normal row gets cfm = 1 / (dt k + d), erp = dt k / (dt k + d) instead of the global
                                            contact_erp and cfm 0 (btMultiBodyConstraintSolver::setupMultiBodyContactConstraint).
                                            stiffness <= 0 = rigid contact (the global pair); ABI v4 */
+  int32_t friction_anchor;              /* URDF <contact><friction_anchor/> of the TOE link (ABI v5): the toe's contact point is CACHED while its
+                                           friction impulse stays inside the cone (btPersistentManifold::replaceContactPoint), and the friction
+                                           rows pull the cached pair of points together (orr_config::friction_erp).  0 = off */
   int32_t num_fall_proxies;             /* termination-only collision spheres on non-foot links */
   int32_t fall_body[ORR_MAX_FALL_PROXIES];
   float fall_pos[ORR_MAX_FALL_PROXIES][3];

@@ -1,7 +1,7 @@
 """ctypes mirror of include/openroborl_hip.h (struct layouts and constants only)."""
 import ctypes as C
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 NUM_MOTORS = 12
 POSE_DIM = 19
 VEL_DIM = 18
@@ -61,6 +61,7 @@ class OrrConfig(C.Structure):
         ("max_angle_change", C.c_float),
         ("dist_fail_threshold", C.c_float),
         ("rot_fail_threshold", C.c_float),
+        ("friction_erp", C.c_float),
     ]
 
 
@@ -93,6 +94,7 @@ class OrrModel(C.Structure):
         ("foot_friction", C.c_float),
         ("contact_stiffness", C.c_float),
         ("contact_damping", C.c_float),
+        ("friction_anchor", C.c_int32),
         ("num_fall_proxies", C.c_int32),
         ("fall_body", C.c_int32 * MAX_FALL_PROXIES),
         ("fall_pos", (C.c_float * 3) * MAX_FALL_PROXIES),

@@ -82,4 +82,5 @@ def make_config(num_robots, sim_params=None, mode="train", enable_randomizer=Non
     c.max_angle_change = 0.2                                          # laikago.py:71
     c.dist_fail_threshold = 1.0                                       # imitation_task.py:518
     c.rot_fail_threshold = 0.5 * math.pi
+    c.friction_erp = 0.2
     return c

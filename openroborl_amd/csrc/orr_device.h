@@ -95,6 +95,7 @@ static_assert(sizeof(ModelHot) == 512, "LDS budget: 4 robots per wave, two waves
 struct ModelCold {
   float init_pos[3];
   float foot_friction;
+  int friction_anchor;        // orr_model::friction_anchor (read by the anchor variant of the step kernel only)
   float init_motor_angles[12], motor_dir[12], motor_offset[12];
   int joint_of_motor[12];
   float kp[12], kd[12];
@@ -144,6 +145,7 @@ struct KParams {
   float* ep_log;
   int ep_log_cap;
   int simds;           // SIMDs of the device: workgroup b belongs to dispatch round b / simds (two-waves-per-SIMD variant: priority alternation)
+  int anchor_on;       // some robot type has orr_model::friction_anchor: the launches run the anchor variant of the step kernel, resets clear the anchors
 #ifdef ORR_WAVE_TIMELINE
   long long* wave_times;   // development aid (tools/wave_times.py): 4 words per wave of the step kernel, either variant
 #endif

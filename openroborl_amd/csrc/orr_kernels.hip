@@ -112,6 +112,8 @@ __global__ __launch_bounds__(64) void orr_reset_kernel(KParams P, const uint8_t*
   reset_robot(P, rec, S, lane, valid, total, obs, uniforms ? uniforms + (size_t)robot * 28 : nullptr);
   WSYNC();
   store_robot(rec, S, lane, valid);
+  if (P.anchor_on && valid)   // a new episode: no cached contact points (ANCHOR, ANCHOR_VALID: 28 words behind the ring)
+    for (int i = lane; i < ORR_OFFEND_ANCHOR_VALID - ORR_OFF_ANCHOR + 1; i += kLanes) rec[O(ANCHOR) + i] = 0.0f;
   if (obs_out && valid)
     for (int i = lane; i < ORR_OBS_DIM; i += kLanes) obs_out[(size_t)robot * ORR_OBS_DIM + i] = obs[i];
 }
@@ -138,7 +140,10 @@ __global__ __launch_bounds__(64) void orr_reset_kernel(KParams P, const uint8_t*
 #endif
 template <int MODE, int WPE>
 constexpr int step_wpb() { return MODE == 0 && WPE == 1 ? ORR_WPB : 1; }
-template <int MODE, int WPE = ORR_WAVES_PER_EU>
+// ANCHOR (ABI v5): the variant for robot types with orr_model::friction_anchor - Bullet's cached toe contact points (orr_physics.h:
+// AnchorState).  Same source; its own instantiations (one wave per SIMD whatever the batch size: an optional physics feature, not the
+// measured path), so that the default kernels carry nothing of it.
+template <int MODE, int WPE = ORR_WAVES_PER_EU, bool ANCHOR = false>
 __global__ __launch_bounds__((MODE == 0 && WPE == 1 ? 64 * ORR_WPB : 64)) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void orr_step_kernel(KParams P, const float* actions, float* obs_out, float* reward_out,
                                                       uint8_t* done_out, int nsub, ReplayArgs RP) {
   ORR_PROLOGUE_W((step_wpb<MODE, WPE>()));
@@ -154,7 +159,7 @@ __global__ __launch_bounds__((MODE == 0 && WPE == 1 ? 64 * ORR_WPB : 64)) __attr
     // Non-finite guard, entry half: a NaN in the INCOMING rigid state (POS..QD) does not survive the step - the velocity clamp (+-100,
     // v_med3) and the branch-free inverse trigonometric functions turn NaNs into finite numbers - so it is recorded here, in a spare
     // word of the LDS image behind the state head (never stored), and ORed into the exit half of the guard (ORR_DONE_NAN below).
-    static_assert(kHead > ORR_STATE_WORDS - ORR_RING_DEPTH * ORR_RING_ENTRY, "spare LDS word behind the state head");
+    static_assert(kHead > ORR_OFF_RING, "spare LDS word behind the state head (the head = everything in front of the ring)");
     bool bad_in = false;
     for (int i = lane; i < 37; i += kLanes) bad_in = bad_in || !(fabsf(S.s[O(POS) + i]) < 1e30f);
     const bool any_bad = ((__ballot(bad_in) >> (sub * kLanes)) & ((1ull << (kLanes - 1)) * 2ull - 1ull)) != 0ull;
@@ -169,6 +174,25 @@ __global__ __launch_bounds__((MODE == 0 && WPE == 1 ? 64 * ORR_WPB : 64)) __attr
     float rel[4], Rb[9];
     base_rotation(S, lane, rel, Rb);  // Shared::Rb for the first sub-step; the ring push keeps it current afterwards
   }
+  // friction anchors (ANCHOR variant only): the cached contact point of the lane's leg, from the record's words behind the ring
+  AnchorState AS = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, 0};
+  bool anchor_robot = false;
+  const int aleg = lane < 4 ? lane : (lane < 8 ? lane - 4 : (lane - 8) >> 1);   // leg of the lane's bank-A row (knee, normal, friction)
+  if constexpr (ANCHOR) {
+    anchor_robot = model_cold(P, geti(S, O(ROBOT_TYPE)))->friction_anchor != 0;
+    const float* an = rec + O(ANCHOR) + 6 * aleg;
+    AS.la[0] = an[0]; AS.la[1] = an[1]; AS.la[2] = an[2]; AS.wb[0] = an[3]; AS.wb[1] = an[4]; AS.wb[2] = an[5];
+    AS.valid = anchor_robot ? __float_as_int(rec[O(ANCHOR_VALID) + aleg]) : 0;
+  }
+  auto store_anchor = [&]() __attribute__((always_inline)) {      // the normal-row lanes (4..7) own the record's words
+    if constexpr (ANCHOR) {
+      if (valid && lane >= 4 && lane < 8) {
+        float* an = rec + O(ANCHOR) + 6 * aleg;
+        an[0] = AS.la[0]; an[1] = AS.la[1]; an[2] = AS.la[2]; an[3] = AS.wb[0]; an[4] = AS.wb[1]; an[5] = AS.wb[2];
+        rec[O(ANCHOR_VALID) + aleg] = __int_as_float(AS.valid);
+      }
+    }
+  };
   PT(0);
 
   if (MODE == 1) {
@@ -183,13 +207,14 @@ __global__ __launch_bounds__((MODE == 0 && WPE == 1 ? 64 * ORR_WPB : 64)) __attr
     load_own_coord(S, lane, X);
     int limit_idle = 0;
     for (int s = 0; s < nsub; s++) {
-      fall = physics_substep(P, S, K, lane, sub, true, X, limit_idle);
+      fall = physics_substep<ANCHOR>(P, S, K, lane, sub, true, X, limit_idle, &AS, anchor_robot);
       float rel[4], Rb[9];
       base_rotation(S, lane, rel, Rb);
       WSYNC();
     }
     if (valid && lane == 0 && done_out) done_out[robot] = (uint8_t)fall;
     store_robot(rec, S, lane, valid);
+    store_anchor();
     return;
   }
 
@@ -312,12 +337,12 @@ __global__ __launch_bounds__((MODE == 0 && WPE == 1 ? 64 * ORR_WPB : 64)) __attr
         WSYNC();
         fall = RP.fall[robot];
       } else
-      fall = physics_substep(P, S, K, lane, sub, sstep == c.action_repeat - 1, X, limit_idle);
+      fall = physics_substep<ANCHOR>(P, S, K, lane, sub, sstep == c.action_repeat - 1, X, limit_idle, &AS, anchor_robot);
       qm_c = (S.s[O(Q) + mj] - m_off) * m_dir;
       qdm_c = S.s[O(QD) + mj] * m_dir;
       ring_push_and_ctrl_obs(rec, S, lane, valid, F, ring, qm_c, &co_own);
     } else {
-      fall = physics_substep(P, S, K, lane, sub, sstep == c.action_repeat - 1, X, limit_idle);
+      fall = physics_substep<ANCHOR>(P, S, K, lane, sub, sstep == c.action_repeat - 1, X, limit_idle, &AS, anchor_robot);
       receive_obs(P, rec, S, lane, valid);
     }
     PT(10);
@@ -435,6 +460,7 @@ __global__ __launch_bounds__((MODE == 0 && WPE == 1 ? 64 * ORR_WPB : 64)) __attr
     if (c.flags & ORR_FLAG_AUTO_RESET) {
       PT(31);
       reset_robot(P, rec, S, lane, valid, total_snapshot, obs);
+      if constexpr (ANCHOR) AS = AnchorState{{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, 0};   // a new episode: no cached contact points
     }
     if (logs && P.ep_log) {
       if (slot < (unsigned long long)P.ep_log_cap) {
@@ -448,6 +474,7 @@ __global__ __launch_bounds__((MODE == 0 && WPE == 1 ? 64 * ORR_WPB : 64)) __attr
   WSYNC();
   PT(14);
   store_robot(rec, S, lane, valid);
+  store_anchor();
   if (valid) {   // the observation, in 16-byte pieces like the record (40 per robot)
     typedef f4 __attribute__((address_space(1))) * g4ptr;
     static_assert(ORR_OBS_DIM % 4 == 0, "16-byte pieces");
@@ -554,6 +581,7 @@ struct orr_handle {
   orr_config cfg;
   int simds;          // SIMDs of the device (4 per CU): a batch of more waves than that runs the two-waves-per-SIMD variant of the step kernel
   int force_wpe;      // ORR_STEP_WAVES_PER_EU (0 = automatic)
+  int anchor_types;   // bit t = robot type t has orr_model::friction_anchor: launches run the ANCHOR variant of the step kernel
   DevTables* tab_dev;
   DevTables tab_host;
   float fb[3], fa[3];
@@ -722,6 +750,9 @@ int32_t orr_set_model(orr_handle* h, int32_t robot_type, const orr_model* m) {
   H.toe_radius = m->toe_radius;
   H.shank_radius = m->shank_radius;
   Cd.foot_friction = m->foot_friction;
+  Cd.friction_anchor = m->friction_anchor != 0;
+  if (m->friction_anchor) h->anchor_types |= 1 << robot_type; else h->anchor_types &= ~(1 << robot_type);
+  if (m->friction_anchor && !(h->cfg.friction_erp >= 0.0f && h->cfg.friction_erp <= 1.0f)) return fail(-1, "orr_set_model: friction_anchor needs 0 <= orr_config::friction_erp <= 1");
   Cd.num_fall = m->num_fall_proxies;
   if (m->contact_stiffness > 0.0f) {
     if (!(m->contact_damping >= 0.0f)) return fail(-1, "orr_set_model: contact_damping must be >= 0");
@@ -789,6 +820,7 @@ static KParams make_params(const orr_handle* h) {
   P.ep_log = h->ep_log;
   P.ep_log_cap = h->ep_log_cap;
   P.simds = h->simds;
+  P.anchor_on = h->anchor_types != 0;
 #ifdef ORR_WAVE_TIMELINE
   P.wave_times = g_wave_times_dev;
 #endif
@@ -809,7 +841,11 @@ int32_t orr_step(orr_handle* h, const float* actions_dev, float* obs_dev, float*
   if (((uintptr_t)obs_dev & 15u) != 0) return fail(-1, "orr_step: the observation buffer must be 16-byte aligned (it is written in 16-byte pieces)");
   const int waves = (h->cfg.num_robots + kRPW - 1) / kRPW;
   const bool two = h->force_wpe ? h->force_wpe == 2 : waves > h->simds;
-  if (two) {
+  if (h->anchor_types) {   // some robot type has friction anchors: the ANCHOR variant (one wave per SIMD, any batch size)
+    hipLaunchKernelGGL((orr_step_kernel<0, ORR_WAVES_PER_EU, true>), dim3(waves), dim3(64), 0, (hipStream_t)stream, make_params(h), actions_dev, obs_dev,
+                       reward_dev, done_dev, 0, ReplayArgs{});
+    HIPCHK(hipGetLastError(), "orr_step: launch (friction anchors)");
+  } else if (two) {
     HIPCHK(launch_step_w2(make_params(h), waves, (hipStream_t)stream, actions_dev, obs_dev, reward_dev, done_dev), "orr_step: launch (two waves per SIMD)");
   } else {
     // <0> = <0, ORR_WAVES_PER_EU>: one wave per SIMD in the shipped build; development builds (-DORR_WAVES_PER_EU=2 with the timers of
@@ -825,6 +861,10 @@ int32_t orr_step(orr_handle* h, const float* actions_dev, float* obs_dev, float*
 // parity / debug entry point (not part of the drop-in surface): nsub physics sub-steps with fixed motor torques
 int32_t orr_debug_physics(orr_handle* h, const float* torques_dev, uint8_t* fall_dev, int32_t nsub, void* stream) {
   if (!h || !h->state || !torques_dev) return fail(-1, "orr_debug_physics: bad argument");
+  if (h->anchor_types)
+    hipLaunchKernelGGL((orr_step_kernel<1, ORR_WAVES_PER_EU, true>), dim3((h->cfg.num_robots + kRPW - 1) / kRPW), dim3(64), 0, (hipStream_t)stream, make_params(h),
+                       torques_dev, nullptr, nullptr, fall_dev, nsub, ReplayArgs{});
+  else
   hipLaunchKernelGGL(orr_step_kernel<1>, dim3((h->cfg.num_robots + kRPW - 1) / kRPW), dim3(64), 0, (hipStream_t)stream, make_params(h), torques_dev,
                      nullptr, nullptr, fall_dev, nsub, ReplayArgs{});
   HIPCHK(hipGetLastError(), "orr_debug_physics: launch");

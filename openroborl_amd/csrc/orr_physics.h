@@ -800,8 +800,14 @@ __device__ __forceinline__ void row_setup(const Shared& S, const orr_config& cfg
 #ifndef ORR_BRANCHFREE_ROWS
 #define ORR_BRANCHFREE_ROWS 1
 #endif
+// Bullet's friction anchor (orr_model::friction_anchor, ABI v5; the ANCHOR variant of the kernels): the cached contact point of the lane's
+// leg - the point on the toe in the lower-leg link frame, the point on the plane in world - carried in REGISTERS over the sub-steps of a
+// launch by each of the leg's three contact lanes (normal + two friction rows).  They make the same decisions from the same inputs
+// (link pose and last sub-step's impulses from LDS), so the copies stay equal; the normal-row lane loads / stores the record's words.
+struct AnchorState { float la[3], wb[3]; int valid; };
+template <bool ANCHOR = false>
 __device__ __forceinline__ void row_setup_bank_a(const Shared& S, const orr_config& cfg, int slot, bool enable, float dt, float inv_dt,
-                                                 float erp_dt, Row& R, ContactGeom& G) {
+                                                 float erp_dt, Row& R, ContactGeom& G, AnchorState* AS = nullptr, bool anchor_robot = false) {
   const bool knee = slot < 4;
   const int leg = knee ? slot : (slot < 20 ? slot - 16 : (slot - 20) >> 1);
   const int d = (knee || slot < 20) ? 0 : 1 + ((slot - 20) & 1);
@@ -817,7 +823,44 @@ __device__ __forceinline__ void row_setup_bank_a(const Shared& S, const orr_conf
   mv3(Lb.Rw, S.m.shank_pos[leg], cs);
   const float dist_t = cw[2] + Lb.ow[2] - S.m.toe_radius, dist_s = cs[2] + Lb.ow[2] - S.m.shank_radius;
   const bool shank = S.m.shank_radius > 0.0f && dist_s < dist_t;
-  const float dist = shank ? dist_s : dist_t;
+  float dist = shank ? dist_s : dist_t;
+  float Pw0 = (shank ? cs[0] : cw[0]) + Lb.ow[0], Pw1 = (shank ? cs[1] : cw[1]) + Lb.ow[1];
+  float drift_x = 0.0f, drift_y = 0.0f;
+  bool have = dist < cfg.contact_margin;
+  if constexpr (ANCHOR) {
+    // btManifoldResult::addContactPoint -> btPersistentManifold::replaceContactPoint -> refreshContactPoints, one cached point per toe
+    // (the oracle's physics_substep, same order of operations): the fresh sphere-plane point replaces the cached one only when the cached
+    // point's friction impulse of the last solve left the cone (or the point moved further than the breaking threshold over the toe's
+    // surface); the cached points are carried along by their bodies, distance and tangential offset are re-measured, and the point is
+    // dropped when either exceeds the threshold.  A leg on its shank sphere, or a robot whose model has no anchors, keeps the plain point.
+    AnchorState& A = *AS;
+    if (anchor_robot) {
+      int valid = A.valid;
+      if (shank) valid = 0;
+      else {
+        const float m2 = cfg.contact_margin * cfg.contact_margin;
+        if (have) {
+          // the fresh point on the toe, in the link frame: toe centre - r * (world z in link coordinates)
+          const float l0 = S.m.toe_pos[leg][0] - S.m.toe_radius * Lb.Rw[6], l1 = S.m.toe_pos[leg][1] - S.m.toe_radius * Lb.Rw[7];
+          const float l2 = S.m.toe_pos[leg][2] - S.m.toe_radius * Lb.Rw[8];
+          const float ln = S.s[O(LAMBDA) + 3 * leg], t1 = S.s[O(LAMBDA) + 3 * leg + 1], t2 = S.s[O(LAMBDA) + 3 * leg + 2];
+          const float b = mu_s * cfg.plane_friction * ln;
+          const float e0 = l0 - A.la[0], e1 = l1 - A.la[1], e2 = l2 - A.la[2];
+          const bool replace = !valid || (t1 * t1 + t2 * t2 > b * b) || (e0 * e0 + e1 * e1 + e2 * e2 >= m2);
+          if (replace) { A.la[0] = l0; A.la[1] = l1; A.la[2] = l2; A.wb[0] = Pw0; A.wb[1] = Pw1; A.wb[2] = 0.0f; valid = 1; }
+        }
+        if (valid) {
+          float pa[3];
+          mv3(Lb.Rw, A.la, pa);
+          pa[0] += Lb.ow[0]; pa[1] += Lb.ow[1]; pa[2] += Lb.ow[2];
+          const float dn = pa[2] - A.wb[2], dx = pa[0] - A.wb[0], dy = pa[1] - A.wb[1];
+          if (dn > cfg.contact_margin || dx * dx + dy * dy > m2) { valid = 0; have = false; }
+          else { have = true; dist = dn; Pw0 = pa[0]; Pw1 = pa[1]; drift_x = dx; drift_y = dy; }
+        } else have = false;
+      }
+      A.valid = valid;
+    }
+  }
   {   // instrumented build only (tools/dual_contact.py): normal-row lanes count the leg-sub-steps by which spheres touch
     const bool cnt = enable && normal, has_s = S.m.shank_radius > 0.0f;
     const bool t_in = dist_t < cfg.contact_margin, s_in = has_s && dist_s < cfg.contact_margin;
@@ -829,7 +872,7 @@ __device__ __forceinline__ void row_setup_bank_a(const Shared& S, const orr_conf
     ORR_DUAL_COUNT(5, cnt && shank && dist < cfg.contact_margin);
     (void)cnt; (void)has_s; (void)t_in; (void)s_in;
   }
-  const float Pw[3] = {(shank ? cs[0] : cw[0]) + Lb.ow[0], (shank ? cs[1] : cw[1]) + Lb.ow[1], dist};
+  const float Pw[3] = {Pw0, Pw1, dist};
   const float dir[3] = {d == 1 ? 1.0f : 0.0f, d == 2 ? 1.0f : 0.0f, d == 0 ? 1.0f : 0.0f};
   float rr[3] = {Pw[0] - S.s[O(POS)], Pw[1] - S.s[O(POS) + 1], Pw[2] - S.s[O(POS) + 2]};
   float Jb[6];
@@ -851,13 +894,15 @@ __device__ __forceinline__ void row_setup_bank_a(const Shared& S, const orr_conf
   }
   G.rr0 = rr[0]; G.rr1 = rr[1]; G.rr2 = rr[2];   // only the contact lanes' geometry is ever read (dpp_contact_triplet<4 + g>)
   // the row of this lane
-  const bool active = enable && (knee ? fr > 0.0f : dist < cfg.contact_margin);
+  const bool active = enable && (knee ? fr > 0.0f : have);
 #pragma unroll
   for (int i = 0; i < 6; i++) R.Jb[i] = knee ? 0.0f : Jb[i];
   R.jl[0] = knee ? 0.0f : jl[0]; R.jl[1] = knee ? 0.0f : jl[1]; R.jl[2] = knee ? 1.0f : jl[2];
   // right-hand side: knee motor -u*; friction -rel; normal -rel - dist / dt (open) or -rel - dist erp / dt (penetrating; a toe may be soft)
   const float kpen = normal ? (dist > 0.0f ? inv_dt : (shank ? erp_dt : erp_m)) : 0.0f;     // one multiply-add, as in the generic form
-  const float rhs = knee ? -uknee : -rel - dist * kpen;
+  float rhs = knee ? -uknee : -rel - dist * kpen;
+  // friction anchor: positionalError = -distance * frictionERP / dt along the friction direction (setupMultiBodyContactConstraint)
+  if constexpr (ANCHOR) rhs -= (d == 1 ? drift_x : (d == 2 ? drift_y : 0.0f)) * (cfg.friction_erp * inv_dt);
   R.rhs = active ? rhs : 0.0f;
   R.cfm = (normal && !shank) ? cfm_m : 0.0f;
   R.nrm_slot = fric ? 16 + leg : -1;
@@ -1331,8 +1376,9 @@ __device__ __forceinline__ void delassus_columns(const Shared& S, unsigned int m
 // wave can get a joint-limit row.  A joint coordinate moves by at most max_coord_velocity * dt per sub-step (the velocity clamp of the
 // integration), so a joint that is m away from the activation distance of its nearer bound stays rowless for floor(m / that) sub-steps;
 // the bank-B row setup (12 lanes x ~25 instructions + ballots, every sub-step) is skipped for that long - exactly, not approximately.
+template <bool ANCHOR = false>
 __device__ static int physics_substep(const KParams& P, Shared& S, const LegConst& K, int lane, int sub, bool want_fall, OwnCoord& X,
-                                      int& limit_idle) {
+                                      int& limit_idle, AnchorState* AS = nullptr, bool anchor_robot = false) {
   const orr_config& cfg = P.cfg;
   const float dt = cfg.sim_dt, inv_dt = 1.0f / cfg.sim_dt, erp_dt = cfg.contact_erp / cfg.sim_dt;
   // termination-only collision proxies (imitation_task.py:536-546): read once per env step, at its last sub-step, from the device table
@@ -1378,9 +1424,10 @@ __device__ static int physics_substep(const KParams& P, Shared& S, const LegCons
   const bool rowlane = lane < 16;
   ContactGeom G, Gunused;
 #if ORR_BRANCHFREE_ROWS
-  row_setup_bank_a(S, cfg, rowlane ? (lane < 4 ? lane : lane + 12) : 0, rowlane, dt, inv_dt, erp_dt, A, G);
+  row_setup_bank_a<ANCHOR>(S, cfg, rowlane ? (lane < 4 ? lane : lane + 12) : 0, rowlane, dt, inv_dt, erp_dt, A, G, AS, anchor_robot);
 #else
-  row_setup<0>(S, cfg, rowlane ? (lane < 4 ? lane : lane + 12) : 0, rowlane, dt, inv_dt, erp_dt, A, G);
+  if constexpr (ANCHOR) row_setup_bank_a<true>(S, cfg, rowlane ? (lane < 4 ? lane : lane + 12) : 0, rowlane, dt, inv_dt, erp_dt, A, G, AS, anchor_robot);   // the friction anchor lives in the branch-free row setup
+  else row_setup<0>(S, cfg, rowlane ? (lane < 4 ? lane : lane + 12) : 0, rowlane, dt, inv_dt, erp_dt, A, G);
 #endif
   unsigned long long balB = 0ull;
   if (limit_idle > 0) {

@@ -48,7 +48,8 @@ def _pa(m, d):
 def _build(name, init_pos, init_quat, init_motor_angles, motor_dir, motor_offset, joint_of_motor, kp, kd,
            base_mass, base_inertia, hip_xy, hip_z, coxa, femur, tibia, pitch_axis,
            hip_m, hip_com, hip_I, up_m, up_com, up_I, lo_m, lo_com, lo_I, toe_m, toe_r,
-           limits, chassis_half, hip_r, knee_r, foot_friction, shank_r=0.0, shank_at=0.0, contact_stiffness=0.0, contact_damping=0.0):
+           limits, chassis_half, hip_r, knee_r, foot_friction, shank_r=0.0, shank_at=0.0, contact_stiffness=0.0, contact_damping=0.0,
+           friction_anchor=0):
     m = {
         "name": name,
         "init_pos": np.array(init_pos, dtype=np.float64),
@@ -66,6 +67,7 @@ def _build(name, init_pos, init_quat, init_motor_angles, motor_dir, motor_offset
         "foot_friction": float(foot_friction),
         "contact_stiffness": float(contact_stiffness),
         "contact_damping": float(contact_damping),
+        "friction_anchor": int(friction_anchor),
     }
     link_mass = np.zeros(12)
     link_com = np.zeros((12, 3))

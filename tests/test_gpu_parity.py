@@ -73,21 +73,31 @@ RIGID = ["POS", "QUAT", "LINVEL", "ANGVEL", "Q", "QD"]
 SOFT_TOES = {"contact_stiffness": 30000.0, "contact_damping": 1000.0, "foot_friction": 3.0}
 
 
-@pytest.mark.parametrize("robot,soft", [("laikago", False), ("mini_cheetah", False), ("laikago", True), ("mini_cheetah", True)])
+ANCHOR_TOES = {"friction_anchor": 1}
+
+
+@pytest.mark.parametrize("robot,soft", [("laikago", False), ("mini_cheetah", False), ("laikago", True), ("mini_cheetah", True),
+                                        ("laikago", "anchor"), ("mini_cheetah", "anchor"), ("laikago", "anchor+soft")])
 def test_physics_substep_parity(robot, soft):
     """Row C in isolation: ABA + contact/limit/friction rows + PGS + integration, fixed torques.  soft: the toe's normal rows with
-    Bullet's contact stiffness / damping (cfm on the diagonal, own erp) and a friction coefficient of 3."""
+    Bullet's contact stiffness / damping (cfm on the diagonal, own erp) and a friction coefficient of 3.  anchor (ABI v5): Bullet's
+    friction anchors - the ANCHOR variant of the kernels against the oracle's cached contact points, over sub-step sequences long
+    enough for points to be kept, replaced (friction impulse outside the cone) and dropped (lift-off, tangential drift)."""
     import torch
     from tests.parity_inputs import substep_parity_inputs
     n = 64
-    env, orc = make_pair(robot, n=n, model_overrides={robot: SOFT_TOES} if soft else None)
+    anchor = isinstance(soft, str) and "anchor" in soft
+    over = dict(SOFT_TOES if soft is True or (isinstance(soft, str) and "soft" in soft) else {})
+    if anchor:
+        over.update(ANCHOR_TOES)
+    env, orc = make_pair(robot, n=n, model_overrides={robot: over} if over else None)
     env.reset(); orc.reset()
     _, _, _, st, tau = substep_parity_inputs(robot, n)       # the same seeded inputs tools/pybullet_ref.py feeds to PyBullet
     push_state(env, st); orc.state[:] = st
     tg = torch.tensor(tau, dtype=torch.float32, device=env.device)
     # one sub-step: positions agree to 2e-6 (they move by dt * velocity), velocities (up to ~20 rad/s, through the
     # articulated-body solve in float32) to 1.5e-4; after 8 sub-steps with contacts 1e-3
-    for nsub, ptol, vtol in ((1, 2e-6, 1.5e-4), (8, 1e-4, 1e-3)):
+    for nsub, ptol, vtol in ((1, 2e-6, 1.5e-4), (8, 1e-4, 1e-3)) + (((16, 4e-4, 6e-3),) if anchor else ()):
         fall_g = env.debug_physics(tg, nsub).cpu().numpy()
         fall_o = np.zeros(n, dtype=int)
         for i in range(n):
@@ -95,8 +105,24 @@ def test_physics_substep_parity(robot, soft):
                 fall_o[i] = orc.L.orc_physics_substep(orc.h, ol.P(orc.state[i]), ol.P(np.ascontiguousarray(tau[i])))
         compare_fields(env, orc, ["POS", "QUAT", "Q"], atol=ptol, rtol=ptol, what="nsub=%d" % nsub)
         compare_fields(env, orc, ["LINVEL", "ANGVEL", "QD"], atol=vtol, rtol=vtol, what="nsub=%d" % nsub)
-        compare_fields(env, orc, ["LAMBDA"], atol=5e-4 if nsub == 1 else 5e-3, what="nsub=%d" % nsub)
+        compare_fields(env, orc, ["LAMBDA"], atol=5e-4 if nsub == 1 else (5e-3 if nsub == 8 else 2e-2), what="nsub=%d" % nsub)
         assert (fall_g.astype(int) == fall_o).mean() > 0.95
+        if anchor:
+            g = gpu_state64(env)
+            lay = env.layout
+            vg, vo = g[:, lay.sl("ANCHOR_VALID")], orc.state[:, lay.sl("ANCHOR_VALID")]
+            np.testing.assert_array_equal(vg, vo, err_msg="cached contact points, nsub=%d" % nsub)
+            ag, ao = g[:, lay.sl("ANCHOR")].reshape(n, 4, 6), orc.state[:, lay.sl("ANCHOR")].reshape(n, 4, 6)
+            m = vo.astype(bool)
+            np.testing.assert_allclose(ag[m], ao[m], atol=max(ptol, 1e-6) * 4, err_msg="anchor points, nsub=%d" % nsub)
+            if nsub == 1:
+                assert m.mean() > 0.2                      # a good share of the toes holds a cached point
+    if anchor:
+        # the anchors did something: some toes kept a point that is NOT the fresh sphere-plane point any more (the link turned over it)
+        lay = env.layout
+        an = orc.state[:, lay.sl("ANCHOR")].reshape(n, 4, 6)
+        vo = orc.state[:, lay.sl("ANCHOR_VALID")].astype(bool)
+        assert vo.any()
     env.close(); orc.close()
 
 

@@ -59,7 +59,8 @@ def main():
         lines += open(out + "2").read().split("\n")
     meta = "\n".join(lines)
     # one report per variant of the step kernel (WPE 1: one wave per SIMD, WPE 2: two; see orr_kernels.hip)
-    for sym, title in (("_Z15orr_step_kernelILi0ELi1E", "step kernel, one wave per SIMD"), ("_Z15orr_step_kernelILi0ELi2E", "step kernel, two waves per SIMD")):
+    for sym, title in (("_Z15orr_step_kernelILi0ELi1ELb0E", "step kernel, one wave per SIMD"), ("_Z15orr_step_kernelILi0ELi2ELb0E", "step kernel, two waves per SIMD"),
+                       ("_Z15orr_step_kernelILi0ELi1ELb1E", "step kernel with friction anchors (one wave per SIMD)")):
         try:
             start = next(i for i, l in enumerate(lines) if re.match(r"^%s.*:" % sym, l))
         except StopIteration:
