@@ -12,10 +12,11 @@ from . import _abi
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(PKG_DIR, "csrc", "orr_kernels.hip")
+SRC_ANCHOR = os.path.join(PKG_DIR, "csrc", "orr_kernels_anchor.hip")   # the friction-anchor variants of the step kernel (ABI v5): their own translation unit
 SRC_W2 = os.path.join(PKG_DIR, "csrc", "orr_kernels_w2.hip")      # the two-waves-per-SIMD step kernel: its own translation unit + flags
 SRC_POLICY = os.path.join(PKG_DIR, "csrc", "orr_policy.hip")
 SRC_LEARNER = os.path.join(PKG_DIR, "csrc", "orr_learner.hip")    # the non-GEMM part of the PPO update (include/openroborl_learner.h)
-DEPS = [SRC, SRC_W2, SRC_POLICY, SRC_LEARNER] + [os.path.join(PKG_DIR, "csrc", h) for h in ("orr_device.h", "orr_robot_io.h", "orr_physics.h", "orr_task.h")] + [
+DEPS = [SRC, SRC_W2, SRC_ANCHOR, SRC_POLICY, SRC_LEARNER] + [os.path.join(PKG_DIR, "csrc", h) for h in ("orr_device.h", "orr_robot_io.h", "orr_physics.h", "orr_task.h")] + [
         os.path.join(os.path.dirname(PKG_DIR), "include", "openroborl_hip.h"),
         os.path.join(os.path.dirname(PKG_DIR), "include", "openroborl_policy.h"),
         os.path.join(os.path.dirname(PKG_DIR), "include", "openroborl_learner.h")]
@@ -133,15 +134,18 @@ def build(force=False, verbose=False, out_path=None, extra_flags=()):
             tag = ".%d" % os.getpid()
             obj_env = os.path.join(PKG_DIR, "csrc", "orr_kernels%s.o" % tag)
             obj_w2 = os.path.join(PKG_DIR, "csrc", "orr_kernels_w2%s.o" % tag)
+            obj_an = os.path.join(PKG_DIR, "csrc", "orr_kernels_anchor%s.o" % tag)
             obj_pol = os.path.join(PKG_DIR, "csrc", "orr_policy%s.o" % tag)
             obj_lrn = os.path.join(PKG_DIR, "csrc", "orr_learner%s.o" % tag)
             tmp_so = out_path + tag + ".tmp"
             cmds = [[HIPCC] + flags + ["-o", obj_env, SRC],
                     [HIPCC] + flags_w2 + ["-o", obj_w2, SRC_W2],
+                    # the friction-anchor variants of the step kernel (optional physics feature): the main unit's flags, their own unit
+                    [HIPCC] + [f for f in flags if not f.startswith("-DORR_SOURCE_HASH")] + ["-o", obj_an, SRC_ANCHOR],
                     # the policy forward pass (matrix cores) is its own translation unit with the compiler's default scheduling
                     [HIPCC, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-c", "-o", obj_pol, SRC_POLICY],
                     [HIPCC, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-c", "-o", obj_lrn, SRC_LEARNER],
-                    [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp_so, obj_env, obj_w2, obj_pol, obj_lrn]]
+                    [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp_so, obj_env, obj_w2, obj_an, obj_pol, obj_lrn]]
             try:
                 procs = []
                 for cmd in cmds[:-1]:           # the compiles are independent: run them side by side
@@ -156,7 +160,7 @@ def build(force=False, verbose=False, out_path=None, extra_flags=()):
                 subprocess.check_call(cmds[-1])
                 os.replace(tmp_so, out_path)
             finally:
-                for o in (obj_env, obj_w2, obj_pol, obj_lrn, tmp_so):
+                for o in (obj_env, obj_w2, obj_an, obj_pol, obj_lrn, tmp_so):
                     if os.path.exists(o):
                         os.remove(o)
         finally:

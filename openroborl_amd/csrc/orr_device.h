@@ -95,7 +95,6 @@ static_assert(sizeof(ModelHot) == 512, "LDS budget: 4 robots per wave, two waves
 struct ModelCold {
   float init_pos[3];
   float foot_friction;
-  int friction_anchor;        // orr_model::friction_anchor (read by the anchor variant of the step kernel only)
   float init_motor_angles[12], motor_dir[12], motor_offset[12];
   int joint_of_motor[12];
   float kp[12], kd[12];
@@ -112,6 +111,7 @@ struct ModelCold {
   float inertia[13][6];
   float inertia_pa[13][6];
   int group[13];
+  int friction_anchor;        // orr_model::friction_anchor (read by the anchor variant of the step kernel only; LAST: the fields above keep their offsets)
 };
 struct alignas(16) DevModel {   // 16-byte aligned in the device table: the hot part is copied to LDS in 16-byte pieces
   ModelHot hot;

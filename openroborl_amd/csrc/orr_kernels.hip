@@ -14,8 +14,9 @@
 // kernel and is compiled with an occupancy-minded scheduler (-O3 + iterative-maxocc since round 4, the compiler's default before): at
 // 256 registers that variant spills, and the ILP schedule's longer live ranges cost it 8 % (0.382 vs 0.352 ms at 8192 robots; the default
 // scheduler costs the one-wave variant 9 %).
-#ifdef ORR_TU_STEP_W2
+#if defined(ORR_TU_STEP_W2) || defined(ORR_TU_STEP_ANCHOR)
 #undef ORR_PHASE_TIMERS      // the development timers live in the main translation unit only
+#define ORR_TU_SECONDARY 1   // a unit that holds only instantiations of the step kernel and their launchers
 #endif
 #include <hip/hip_runtime.h>
 #include <type_traits>
@@ -67,7 +68,7 @@ __device__ long long g_wave_timeline[4 * 2048];   // per wave of the last launch
 // Development aid (tools/dual_contact.py): -DORR_COUNT_DUAL_CONTACT counts, per leg and sub-step, how often the toe sphere and the shank
 // sphere of a lower leg are within the contact margin / penetrating at the same time (the engine makes ONE contact point per leg, Bullet
 // one per touching shape: DESIGN.md section 9).  One-wave kernel only.
-#if defined(ORR_COUNT_DUAL_CONTACT) && !defined(ORR_TU_STEP_W2)
+#if defined(ORR_COUNT_DUAL_CONTACT) && !defined(ORR_TU_SECONDARY)
 __device__ unsigned long long g_dual_contact[8];
 // (called inside the contact branch of row_setup, where lanes 0..3 of every robot are inactive: the first ACTIVE lane adds the wave's count)
 #define ORR_DUAL_COUNT(k, cond) do { const unsigned long long b_ = __ballot(cond), act_ = __ballot(1); \
@@ -103,7 +104,7 @@ using namespace orr;
   const int robot = in_range ? robot_raw : 0; /* a padding lane group shadows robot 0 and never stores */ \
   float* rec = P.state + (size_t)robot * ORR_STATE_STRIDE
 
-#ifndef ORR_TU_STEP_W2
+#ifndef ORR_TU_SECONDARY
 __global__ __launch_bounds__(64) void orr_reset_kernel(KParams P, const uint8_t* mask, float* obs_out, const float* uniforms) {
   ORR_PROLOGUE();
   const bool valid = in_range && !(mask && !mask[robot]);
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(64) void orr_reset_kernel(KParams P, const uint8_t*
   if (obs_out && valid)
     for (int i = lane; i < ORR_OBS_DIM; i += kLanes) obs_out[(size_t)robot * ORR_OBS_DIM + i] = obs[i];
 }
-#endif  // !ORR_TU_STEP_W2
+#endif  // !ORR_TU_SECONDARY
 
 // mode 0: full env step.  mode 1 (debug / parity of row C): nsub physics sub-steps with the given
 // motor torques (actions = torques), no robot or task logic.  mode 2 (parity of everything BUT row C): a full env step in
@@ -207,7 +208,7 @@ __global__ __launch_bounds__((MODE == 0 && WPE == 1 ? 64 * ORR_WPB : 64)) __attr
     load_own_coord(S, lane, X);
     int limit_idle = 0;
     for (int s = 0; s < nsub; s++) {
-      fall = physics_substep<ANCHOR>(P, S, K, lane, sub, true, X, limit_idle, &AS, anchor_robot);
+      fall = physics_substep<ANCHOR>(P, S, K, lane, sub, true, X, limit_idle, ANCHOR ? &AS : nullptr, anchor_robot);
       float rel[4], Rb[9];
       base_rotation(S, lane, rel, Rb);
       WSYNC();
@@ -337,12 +338,12 @@ __global__ __launch_bounds__((MODE == 0 && WPE == 1 ? 64 * ORR_WPB : 64)) __attr
         WSYNC();
         fall = RP.fall[robot];
       } else
-      fall = physics_substep<ANCHOR>(P, S, K, lane, sub, sstep == c.action_repeat - 1, X, limit_idle, &AS, anchor_robot);
+      fall = physics_substep<ANCHOR>(P, S, K, lane, sub, sstep == c.action_repeat - 1, X, limit_idle, ANCHOR ? &AS : nullptr, anchor_robot);
       qm_c = (S.s[O(Q) + mj] - m_off) * m_dir;
       qdm_c = S.s[O(QD) + mj] * m_dir;
       ring_push_and_ctrl_obs(rec, S, lane, valid, F, ring, qm_c, &co_own);
     } else {
-      fall = physics_substep<ANCHOR>(P, S, K, lane, sub, sstep == c.action_repeat - 1, X, limit_idle, &AS, anchor_robot);
+      fall = physics_substep<ANCHOR>(P, S, K, lane, sub, sstep == c.action_repeat - 1, X, limit_idle, ANCHOR ? &AS : nullptr, anchor_robot);
       receive_obs(P, rec, S, lane, valid);
     }
     PT(10);
@@ -509,8 +510,24 @@ __global__ __launch_bounds__((MODE == 0 && WPE == 1 ? 64 * ORR_WPB : 64)) __attr
 namespace orr {
 // launcher of the two-waves-per-SIMD instantiation, defined in the second translation unit (see the top of this file)
 hipError_t launch_step_w2(const KParams& P, int waves, hipStream_t stream, const float* actions, float* obs, float* reward, uint8_t* done);
+// launchers of the friction-anchor instantiations (env step; debug physics), defined in the third translation unit
+// (orr_kernels_anchor.hip): kept out of the main unit, whose code generation for the DEFAULT kernels moves when further instantiations
+// share its functions (round 5: +6 instructions per sub-step, +0.7 % run time with the anchor variants compiled alongside)
+hipError_t launch_step_anchor(const KParams& P, int waves, hipStream_t stream, const float* actions, float* obs, float* reward, uint8_t* done);
+hipError_t launch_physics_anchor(const KParams& P, int waves, hipStream_t stream, const float* torques, uint8_t* fall, int nsub);
 }
-#ifdef ORR_TU_STEP_W2
+#ifdef ORR_TU_STEP_ANCHOR
+namespace orr {
+hipError_t launch_step_anchor(const KParams& P, int waves, hipStream_t stream, const float* actions, float* obs, float* reward, uint8_t* done) {
+  hipLaunchKernelGGL((orr_step_kernel<0, 1, true>), dim3(waves), dim3(64), 0, stream, P, actions, obs, reward, done, 0, ReplayArgs{});
+  return hipGetLastError();
+}
+hipError_t launch_physics_anchor(const KParams& P, int waves, hipStream_t stream, const float* torques, uint8_t* fall, int nsub) {
+  hipLaunchKernelGGL((orr_step_kernel<1, 1, true>), dim3(waves), dim3(64), 0, stream, P, torques, nullptr, nullptr, fall, nsub, ReplayArgs{});
+  return hipGetLastError();
+}
+}  // namespace orr
+#elif defined(ORR_TU_STEP_W2)
 namespace orr {
 hipError_t launch_step_w2(const KParams& P, int waves, hipStream_t stream, const float* actions, float* obs, float* reward, uint8_t* done) {
   hipLaunchKernelGGL((orr_step_kernel<0, 2>), dim3(waves), dim3(64), 0, stream, P, actions, obs, reward, done, 0, ReplayArgs{});
@@ -842,9 +859,7 @@ int32_t orr_step(orr_handle* h, const float* actions_dev, float* obs_dev, float*
   const int waves = (h->cfg.num_robots + kRPW - 1) / kRPW;
   const bool two = h->force_wpe ? h->force_wpe == 2 : waves > h->simds;
   if (h->anchor_types) {   // some robot type has friction anchors: the ANCHOR variant (one wave per SIMD, any batch size)
-    hipLaunchKernelGGL((orr_step_kernel<0, ORR_WAVES_PER_EU, true>), dim3(waves), dim3(64), 0, (hipStream_t)stream, make_params(h), actions_dev, obs_dev,
-                       reward_dev, done_dev, 0, ReplayArgs{});
-    HIPCHK(hipGetLastError(), "orr_step: launch (friction anchors)");
+    HIPCHK(launch_step_anchor(make_params(h), waves, (hipStream_t)stream, actions_dev, obs_dev, reward_dev, done_dev), "orr_step: launch (friction anchors)");
   } else if (two) {
     HIPCHK(launch_step_w2(make_params(h), waves, (hipStream_t)stream, actions_dev, obs_dev, reward_dev, done_dev), "orr_step: launch (two waves per SIMD)");
   } else {
@@ -861,10 +876,10 @@ int32_t orr_step(orr_handle* h, const float* actions_dev, float* obs_dev, float*
 // parity / debug entry point (not part of the drop-in surface): nsub physics sub-steps with fixed motor torques
 int32_t orr_debug_physics(orr_handle* h, const float* torques_dev, uint8_t* fall_dev, int32_t nsub, void* stream) {
   if (!h || !h->state || !torques_dev) return fail(-1, "orr_debug_physics: bad argument");
-  if (h->anchor_types)
-    hipLaunchKernelGGL((orr_step_kernel<1, ORR_WAVES_PER_EU, true>), dim3((h->cfg.num_robots + kRPW - 1) / kRPW), dim3(64), 0, (hipStream_t)stream, make_params(h),
-                       torques_dev, nullptr, nullptr, fall_dev, nsub, ReplayArgs{});
-  else
+  if (h->anchor_types) {
+    HIPCHK(launch_physics_anchor(make_params(h), (h->cfg.num_robots + kRPW - 1) / kRPW, (hipStream_t)stream, torques_dev, fall_dev, nsub), "orr_debug_physics: launch (friction anchors)");
+    return 0;
+  }
   hipLaunchKernelGGL(orr_step_kernel<1>, dim3((h->cfg.num_robots + kRPW - 1) / kRPW), dim3(64), 0, (hipStream_t)stream, make_params(h), torques_dev,
                      nullptr, nullptr, fall_dev, nsub, ReplayArgs{});
   HIPCHK(hipGetLastError(), "orr_debug_physics: launch");
@@ -983,4 +998,4 @@ int orr_debug_wave_timeline(long long* out, int waves) {
 #endif
 
 }  // extern "C"
-#endif  // !ORR_TU_STEP_W2
+#endif  // main translation unit

@@ -800,14 +800,89 @@ __device__ __forceinline__ void row_setup(const Shared& S, const orr_config& cfg
 #ifndef ORR_BRANCHFREE_ROWS
 #define ORR_BRANCHFREE_ROWS 1
 #endif
+__device__ __forceinline__ void row_setup_bank_a(const Shared& S, const orr_config& cfg, int slot, bool enable, float dt, float inv_dt,
+                                                 float erp_dt, Row& R, ContactGeom& G) {
+  const bool knee = slot < 4;
+  const int leg = knee ? slot : (slot < 20 ? slot - 16 : (slot - 20) >> 1);
+  const int d = (knee || slot < 20) ? 0 : 1 + ((slot - 20) & 1);
+  const bool normal = !knee && d == 0, fric = d != 0;
+  // everything that comes out of LDS, for every lane, before any use (opaque copies keep the loads here)
+  float fr = S.s[O(KNEE_FRICTION) + leg], uknee = S.ustar[6 + 3 * leg + 2], mu_s = S.s[O(FOOT_MU)];
+  float cfm_m = S.m.contact_cfm, erp_m = S.m.contact_erp_dt;
+  asm volatile("" : "+v"(fr), "+v"(uknee), "+v"(mu_s), "+v"(cfm_m), "+v"(erp_m));
+  R.leg = leg;
+  const LinkCache& Lb = S.ph.sub.dyn.lc[3 * leg + 2];
+  float cw[3], cs[3];
+  mv3(Lb.Rw, S.m.toe_pos[leg], cw);
+  mv3(Lb.Rw, S.m.shank_pos[leg], cs);
+  const float dist_t = cw[2] + Lb.ow[2] - S.m.toe_radius, dist_s = cs[2] + Lb.ow[2] - S.m.shank_radius;
+  const bool shank = S.m.shank_radius > 0.0f && dist_s < dist_t;
+  const float dist = shank ? dist_s : dist_t;
+  {   // instrumented build only (tools/dual_contact.py): normal-row lanes count the leg-sub-steps by which spheres touch
+    const bool cnt = enable && normal, has_s = S.m.shank_radius > 0.0f;
+    const bool t_in = dist_t < cfg.contact_margin, s_in = has_s && dist_s < cfg.contact_margin;
+    ORR_DUAL_COUNT(0, cnt);
+    ORR_DUAL_COUNT(1, cnt && (t_in || s_in));
+    ORR_DUAL_COUNT(2, cnt && t_in && s_in);
+    ORR_DUAL_COUNT(3, cnt && dist_t < 0.0f && has_s && dist_s < 0.0f);
+    ORR_DUAL_COUNT(4, cnt && s_in && !t_in);
+    ORR_DUAL_COUNT(5, cnt && shank && dist < cfg.contact_margin);
+    (void)cnt; (void)has_s; (void)t_in; (void)s_in;
+  }
+  const float Pw[3] = {(shank ? cs[0] : cw[0]) + Lb.ow[0], (shank ? cs[1] : cw[1]) + Lb.ow[1], dist};
+  const float dir[3] = {d == 1 ? 1.0f : 0.0f, d == 2 ? 1.0f : 0.0f, d == 0 ? 1.0f : 0.0f};
+  float rr[3] = {Pw[0] - S.s[O(POS)], Pw[1] - S.s[O(POS) + 1], Pw[2] - S.s[O(POS) + 2]};
+  float Jb[6];
+  cross3(rr, dir, &Jb[0]);
+  Jb[3] = dir[0]; Jb[4] = dir[1]; Jb[5] = dir[2];
+  float rel = Jb[0] * S.ustar[0] + Jb[1] * S.ustar[1] + Jb[2] * S.ustar[2] + Jb[3] * S.ustar[3] + Jb[4] * S.ustar[4] + Jb[5] * S.ustar[5];
+  float jl[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    // velocity of the contact point per unit joint rate: s x (P - o) = s x rr + (d x s), rr and d relative to the base COM
+    const LinkCache& L = S.ph.sub.dyn.lc[3 * leg + k];
+    const float cr[3] = {fmaf(L.s[1], rr[2], fmaf(-L.s[2], rr[1], L.sv[0])), fmaf(L.s[2], rr[0], fmaf(-L.s[0], rr[2], L.sv[1])),
+                         fmaf(L.s[0], rr[1], fmaf(-L.s[1], rr[0], L.sv[2]))};
+    if (k == 0) { G.c00 = cr[0]; G.c01 = cr[1]; G.c02 = cr[2]; }
+    else if (k == 1) { G.c10 = cr[0]; G.c11 = cr[1]; G.c12 = cr[2]; }
+    else { G.c20 = cr[0]; G.c21 = cr[1]; G.c22 = cr[2]; }
+    jl[k] = dir[0] * cr[0] + dir[1] * cr[1] + dir[2] * cr[2];
+    rel += jl[k] * S.ustar[6 + 3 * leg + k];
+  }
+  G.rr0 = rr[0]; G.rr1 = rr[1]; G.rr2 = rr[2];   // only the contact lanes' geometry is ever read (dpp_contact_triplet<4 + g>)
+  // the row of this lane
+  const bool active = enable && (knee ? fr > 0.0f : dist < cfg.contact_margin);
+#pragma unroll
+  for (int i = 0; i < 6; i++) R.Jb[i] = knee ? 0.0f : Jb[i];
+  R.jl[0] = knee ? 0.0f : jl[0]; R.jl[1] = knee ? 0.0f : jl[1]; R.jl[2] = knee ? 1.0f : jl[2];
+  // right-hand side: knee motor -u*; friction -rel; normal -rel - dist / dt (open) or -rel - dist erp / dt (penetrating; a toe may be soft)
+  const float kpen = normal ? (dist > 0.0f ? inv_dt : (shank ? erp_dt : erp_m)) : 0.0f;     // one multiply-add, as in the generic form
+  const float rhs = knee ? -uknee : -rel - dist * kpen;
+  R.rhs = active ? rhs : 0.0f;
+  R.cfm = (normal && !shank) ? cfm_m : 0.0f;
+  R.nrm_slot = fric ? 16 + leg : -1;
+  R.warm = knee ? -1 : 3 * leg + d;
+  R.active = active;
+  R.jdi = 0.0f; R.lam = 0.0f; R.w = 0.0f; R.lam_n = 0.0f;
+  // bounds as (constant part) + mu * lambda_normal: friction rows have a zero constant part, the others mu = 0; an inactive row is
+  // pinned to zero
+  const float hi = knee ? fr * dt : 1e30f, lo = knee ? -fr * dt : 0.0f;
+  R.mu_e = (active && fric) ? mu_s * cfg.plane_friction : 0.0f;
+  R.hi_c = (active && !fric) ? hi : 0.0f;
+  R.lo_c = (active && !fric) ? lo : 0.0f;
+}
+
+// The same row setup with Bullet's friction anchors: a COPY of the function above with the cached contact point worked in (the default
+// kernels keep the function above token for token: a semantically neutral rewrite of it moved the one-wave kernel by six instructions
+// per sub-step and 0.7 % of run time, round 5).
 // Bullet's friction anchor (orr_model::friction_anchor, ABI v5; the ANCHOR variant of the kernels): the cached contact point of the lane's
 // leg - the point on the toe in the lower-leg link frame, the point on the plane in world - carried in REGISTERS over the sub-steps of a
 // launch by each of the leg's three contact lanes (normal + two friction rows).  They make the same decisions from the same inputs
 // (link pose and last sub-step's impulses from LDS), so the copies stay equal; the normal-row lane loads / stores the record's words.
 struct AnchorState { float la[3], wb[3]; int valid; };
-template <bool ANCHOR = false>
-__device__ __forceinline__ void row_setup_bank_a(const Shared& S, const orr_config& cfg, int slot, bool enable, float dt, float inv_dt,
-                                                 float erp_dt, Row& R, ContactGeom& G, AnchorState* AS = nullptr, bool anchor_robot = false) {
+__device__ __forceinline__ void row_setup_bank_a_anchor(const Shared& S, const orr_config& cfg, int slot, bool enable, float dt, float inv_dt,
+                                                 float erp_dt, Row& R, ContactGeom& G, AnchorState* AS, bool anchor_robot) {
+  constexpr bool ANCHOR = true;
   const bool knee = slot < 4;
   const int leg = knee ? slot : (slot < 20 ? slot - 16 : (slot - 20) >> 1);
   const int d = (knee || slot < 20) ? 0 : 1 + ((slot - 20) & 1);
@@ -1423,12 +1498,14 @@ __device__ static int physics_substep(const KParams& P, Shared& S, const LegCons
   Row A, B;
   const bool rowlane = lane < 16;
   ContactGeom G, Gunused;
+  if constexpr (ANCHOR) row_setup_bank_a_anchor(S, cfg, rowlane ? (lane < 4 ? lane : lane + 12) : 0, rowlane, dt, inv_dt, erp_dt, A, G, AS, anchor_robot);
+  else {
 #if ORR_BRANCHFREE_ROWS
-  row_setup_bank_a<ANCHOR>(S, cfg, rowlane ? (lane < 4 ? lane : lane + 12) : 0, rowlane, dt, inv_dt, erp_dt, A, G, AS, anchor_robot);
+  row_setup_bank_a(S, cfg, rowlane ? (lane < 4 ? lane : lane + 12) : 0, rowlane, dt, inv_dt, erp_dt, A, G);
 #else
-  if constexpr (ANCHOR) row_setup_bank_a<true>(S, cfg, rowlane ? (lane < 4 ? lane : lane + 12) : 0, rowlane, dt, inv_dt, erp_dt, A, G, AS, anchor_robot);   // the friction anchor lives in the branch-free row setup
-  else row_setup<0>(S, cfg, rowlane ? (lane < 4 ? lane : lane + 12) : 0, rowlane, dt, inv_dt, erp_dt, A, G);
+  row_setup<0>(S, cfg, rowlane ? (lane < 4 ? lane : lane + 12) : 0, rowlane, dt, inv_dt, erp_dt, A, G);
 #endif
+  }
   unsigned long long balB = 0ull;
   if (limit_idle > 0) {
     limit_idle--;

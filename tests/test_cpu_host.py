@@ -157,7 +157,7 @@ def test_the_kernel_tuning_knobs_still_compile(defs):
     import subprocess
     base = [f for f in _lib.HIPCC_FLAGS if f not in ("-shared", "-fPIC")] + ["--cuda-device-only", "-fsyntax-only", "-Wno-unused-command-line-argument"]
     csrc = os.path.dirname(_lib.SRC)
-    for src in (_lib.SRC, os.path.join(csrc, "orr_kernels_w2.hip")):
+    for src in (_lib.SRC, os.path.join(csrc, "orr_kernels_w2.hip"), os.path.join(csrc, "orr_kernels_anchor.hip")):
         r = subprocess.run([_lib.HIPCC] + base + defs + [src], capture_output=True, text=True)
         assert r.returncode == 0, "%s %s:\n%s" % (os.path.basename(src), " ".join(defs), r.stderr[-1500:])
 

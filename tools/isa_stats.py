@@ -57,6 +57,10 @@ def main():
         flags_w2 = [f for f in _lib.HIPCC_FLAGS_W2 if f not in ("-shared", "-fPIC")] + sys.argv[1:]
         subprocess.check_call([_lib.HIPCC] + flags_w2 + ["-S", "--cuda-device-only", "-o", out + "2", src_w2], stderr=subprocess.DEVNULL)
         lines += open(out + "2").read().split("\n")
+    src_an = os.path.join(os.path.dirname(src), "orr_kernels_anchor.hip")
+    if os.path.exists(src_an):       # the friction-anchor variants: third translation unit, the main unit's flags
+        subprocess.check_call([_lib.HIPCC] + flags + ["-S", "--cuda-device-only", "-o", out + "3", src_an], stderr=subprocess.DEVNULL)
+        lines += open(out + "3").read().split("\n")
     meta = "\n".join(lines)
     # one report per variant of the step kernel (WPE 1: one wave per SIMD, WPE 2: two; see orr_kernels.hip)
     for sym, title in (("_Z15orr_step_kernelILi0ELi1ELb0E", "step kernel, one wave per SIMD"), ("_Z15orr_step_kernelILi0ELi2ELb0E", "step kernel, two waves per SIMD"),
