@@ -58,6 +58,11 @@ B_ALG = 693 + 2456 + 2640 + 2660
 # PMC traffic says what that costs)
 B_ALG_FIXED_LATENCY = 693 + 2456 + 320 + 228
 HBM_PEAK_GBS = 8000.0
+# SURVEY.md section 8(d)'s own per-unit figures (the survey session's estimate of the algorithmic traffic, made before there was a layout):
+# 6.4 KB per robot-step with the randomiser on, 2.6 KB with the fixed 2 ms latency.  Reported BESIDE the built layout's figure (B_ALG
+# above: what the records of this implementation really move) so that a reader can check either convention.
+B_ALG_SURVEY = 6400
+B_ALG_SURVEY_FIXED_LATENCY = 2600
 
 CONFIGS = {
     # name: (VecQuadrupedEnv keyword arguments, robots per GPU, description for config.workload)
@@ -130,8 +135,10 @@ def cpu_baseline(env):
     share = min(16, avail)
     wide = min(avail, int(quota)) if quota and quota >= 1.0 else avail
     f64, f32 = "f64 -O2 -ffp-contract=off", "f32 -O3 -march=native"
-    plan = [(f64, False, 1, 1, 3.0), (f64, False, 512, 1, 3.0), (f64, False, 32 * share, share, 4.0),
-            (f32, True, 1, 1, 3.0), (f32, True, 512, 1, 3.0), (f32, True, 32 * share, share, 4.0)]
+    # BASELINE.md section 3.1 asks for N = 1 and N = 4096: the 4096-robot rows run the WHOLE batch of the GPU workload on the box's core
+    # share for a bounded number of env steps (~4 s each: a dozen steps of the float64 build, a few dozen of the float32 build)
+    plan = [(f64, False, 1, 1, 3.0), (f64, False, 512, 1, 3.0), (f64, False, 32 * share, share, 4.0), (f64, False, 4096, share, 4.0),
+            (f32, True, 1, 1, 3.0), (f32, True, 512, 1, 3.0), (f32, True, 32 * share, share, 4.0), (f32, True, 4096, share, 4.0)]
     if wide > share:
         plan += [(f64, False, 16 * wide, wide, 4.0), (f32, True, 16 * wide, wide, 4.0)]
     for build, f32, n, threads, secs in plan:
@@ -156,7 +163,13 @@ def cpu_baseline(env):
     except Exception as e:          # noqa: BLE001
         pyb = "probe failed: %r" % (e,)
     best = max((r for r in rows if "value" in r and r.get("kind", "port") == "port"), key=lambda r: r["value"])
-    return {"value": best["value"], "unit": "env steps/s", "cores": best["cores"], "kind": "port",
+    at = {}
+    for nr in (1, 4096):          # the N = 1 and the N = 4096 row, fastest build / thread count of each
+        cand = [r for r in rows if r.get("robots") == nr and "value" in r and r.get("kind", "port") == "port"]
+        if cand:
+            b = max(cand, key=lambda r: r["value"])
+            at["robots_%d" % nr] = {"value": b["value"], "unit": "env steps/s", "cores": b["cores"], "build": b["build"], "sample": b["sample"]}
+    return {"value": best["value"], "unit": "env steps/s", "cores": best["cores"], "kind": "port", "by_batch": at,
             "sample": "%s of the same workload, oracle/orr_oracle.c (%s), %d OpenMP threads; the fastest of the rows below"
                       % (best["sample"], best["build"], best["cores"]),
             "host_cpu_count": os.cpu_count(), "host_cores_available": avail, "cgroup_cpu_quota_cores": quota, "pybullet": pyb,
@@ -326,7 +339,9 @@ def main():
     torch.cuda.synchronize(dev)
     kern_b2b_ms = env.time_steps(act, 50) / 50.0
     b_alg = B_ALG_FIXED_LATENCY if args.no_randomizer else B_ALG
+    b_survey = B_ALG_SURVEY_FIXED_LATENCY if args.no_randomizer else B_ALG_SURVEY
     achieved = b_alg * n / (kern_ms * 1e-3) / 1e9
+    achieved_survey = b_survey * n / (kern_ms * 1e-3) / 1e9
 
     if rank == 0:
         # PMC numbers come from separate rocprofv3 --pmc passes over this same command (tools/profile_gpu.sh), committed under
@@ -340,7 +355,7 @@ def main():
             tag += "_wpe2"          # the reverse (a small batch forced onto the two-wave kernel): the committed counters of this config are another kernel's
         lib_hash = env.L.orr_source_hash().decode()
         pmc_stale, pmc_seen = None, []
-        for rnd in ("r04", "r03", "r02"):
+        for rnd in ("r05", "r04", "r03", "r02"):
             name = "%s_%s_pmc_summary.json" % (rnd, tag)
             pmc = os.path.join(ROOT, "profiles", name)
             if not os.path.exists(pmc) or n != CONFIGS[args.config][1]:
@@ -381,7 +396,7 @@ def main():
                          "frac_of_lone_wave_ceiling": (ipw * per_simd * 4.0 / kcyc) if resident == 1 else None,
                          "frac_of_simd_peak": ipw * per_simd * 2.0 / kcyc,
                          "tail_frac": None}
-                for rnd2 in ("r04", "r03", "r02"):
+                for rnd2 in ("r05", "r04", "r03", "r02"):
                     tl = os.path.join(ROOT, "profiles", "%s_wave_timeline.txt" % rnd2)
                     if args.config == "laikago4096" and not args.no_randomizer and os.path.exists(tl):
                         rows = {m.group(1).strip(): float(m.group(2)) for m in (re.match(r"^(.*\S)\s+([0-9.]+)$", ln.rstrip()) for ln in open(tl)) if m}
@@ -419,6 +434,12 @@ def main():
             "dist": dist_info,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         # the same with SURVEY.md section 8(d)'s per-unit figure instead of the built layout's
+                         "alg_bytes_survey": b_survey, "achieved_survey": achieved_survey, "frac_survey": achieved_survey / HBM_PEAK_GBS,
+                         # THE BOUND THAT BINDS (valu_issue below, hoisted): share of a lone wave's VALU issue ceiling (one instruction per
+                         # 4 cycles; one-wave kernel only) and of the SIMD's peak (one per 2 cycles) that the launch sustains
+                         "frac_of_lone_wave_ceiling": issue["frac_of_lone_wave_ceiling"] if issue else None,
+                         "frac_of_simd_peak": issue["frac_of_simd_peak"] if issue else None,
                          "pmc_stale": pmc_stale, "pmc_source_hash": lib_hash, "pmc_summaries_seen": pmc_seen,
                         "kernel": "orr_step_kernel<0, %d>" % kernel_wpe, "kernel_ms": kern_ms, "kernel_ms_mean": mid["kern_ms_mean"],
                          "kernel_ms_min": mid["kern_ms_min"], "kernel_ms_max": mid["kern_ms_max"], "kernel_ms_back_to_back": kern_b2b_ms,

@@ -251,3 +251,54 @@ def test_shank_contact_carries_the_robot(robot):
     assert (z0 - s[:, lay.sl("POS")][:, 2] < 0.012).all(), z0 - s[:, lay.sl("POS")][:, 2]
     assert (np.abs(s[:, lay.sl("LINVEL")][:, 2]) < 0.35).all()
     env.close()
+
+
+def _stand(env, model, s, nsub):
+    lay = env.lay
+    kp, kd = np.array(model["kp"]), np.array(model["kd"])
+    for _ in range(nsub):
+        qm = (s[lay.sl("Q")][model["joint_of_motor"]] - model["motor_offset"]) * model["motor_dir"]
+        qdm = s[lay.sl("QD")][model["joint_of_motor"]] * model["motor_dir"]
+        tau = -kp * (qm - model["init_motor_angles"]) - kd * qdm
+        env.L.orc_physics_substep(env.h, P(s), P(np.ascontiguousarray(tau)))
+
+
+def test_friction_anchor_caches_the_toe_contact_points():
+    """Bullet's friction anchor (orr_model::friction_anchor, ABI v5): a toe's contact point is CACHED while its
+    friction impulse stays inside the cone.  A robot standing still: every toe holds a cached point, the point on the plane does not
+    move any more although the stance keeps rocking on its PD legs, the toes' tangential offsets from their anchors stay far below the
+    threshold; lifting the robot by 3 cm drops all four points at the next sub-step; a reset clears them; without the flag nothing is cached."""
+    for anchor in (1, 0):
+        env, model = _make_env_model("laikago", friction_anchor=anchor)
+        lay = env.lay
+        s = env.state[0]
+        dirj, offj, moj = pr.joint_maps(model)
+        s[lay.sl("Q")] = np.array(model["init_motor_angles"])[moj] * dirj + offj
+        s[lay.sl("QUAT")] = model["init_quat"]
+        s[lay.sl("POS")] = model["init_pos"]
+        s[lay.sl("QD")] = 0; s[lay.sl("LINVEL")] = 0; s[lay.sl("ANGVEL")] = 0
+        _stand(env, model, s, 600)
+        valid = s[lay.sl("ANCHOR_VALID")].copy()
+        if not anchor:
+            assert not valid.any() and not s[lay.sl("ANCHOR")].any()
+            env.close()
+            continue
+        assert valid.all()
+        a0 = s[lay.sl("ANCHOR")].reshape(4, 6).copy()
+        _stand(env, model, s, 400)
+        a1 = s[lay.sl("ANCHOR")].reshape(4, 6)
+        np.testing.assert_array_equal(a0, a1)                       # kept, not replaced: the friction impulses of a quiet stance are inside the cone
+        assert np.all(a1[:, 5] == 0.0)                              # the points on the plane lie ON the plane
+        # the cached toe points sit where the toes are: world position of the local point = the plane point to well under a millimetre
+        out, masses = np.zeros(34 * 3), np.zeros(13)
+        env.L.orc_fk_probe(env.h, P(s), P(out), P(masses))
+        toes = out[26 * 3:].reshape(8, 3)[1::2]
+        assert np.all(np.abs(toes[:, :2] - a1[:, 3:5]) < 2e-3)
+        s[lay.sl("POS")][2] += 0.03                                 # lift: distance > contact breaking threshold
+        _stand(env, model, s, 1)
+        assert not s[lay.sl("ANCHOR_VALID")].any()
+        _stand(env, model, s, 300)
+        assert s[lay.sl("ANCHOR_VALID")].all()                      # landed again: fresh points
+        env.reset()
+        assert not env.state[0][lay.sl("ANCHOR_VALID")].any()       # a new episode starts without cached points
+        env.close()

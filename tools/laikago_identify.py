@@ -306,6 +306,93 @@ def score(r, policies):
     return (f, ln)
 
 
+def evaluate_exact(probe, thetas, policies, steps=600):
+    """Like evaluate(), but every candidate runs under ITS OWN orr_config constants: candidates are grouped by equal constants."""
+    keyf = lambda th: tuple(th[k] for k in NAMES if PARAMS[k][3] == "c")
+    order = sorted(range(len(thetas)), key=lambda i: keyf(thetas[i]))
+    res = [None] * len(thetas)
+    i = 0
+    while i < len(order):
+        j = i
+        while j < len(order) and j - i < probe.SLOTS and keyf(thetas[order[j]]) == keyf(thetas[order[i]]):
+            j += 1
+        grp = [thetas[k] for k in order[i:j]]
+        out = [dict() for _ in grp]
+        for pol, clip in policies:
+            for q, o in enumerate(probe.run_group(pol, clip, grp, config_overrides(grp[0]), steps)):
+                out[q][pol] = o
+        for q, k in enumerate(order[i:j]):
+            res[k] = out[q]
+        i = j
+    return res
+
+
+def ablate(args, probe):
+    """FIT-SET-ONLY follow-up of a finished identification (the hold-out policies are never run here): which of the chosen candidate's
+    deviations from the shipped table does the acceptance hang on?
+      single  : the chosen candidate with ONE entry put back to its shipped value, for every entry
+      apply   : the shipped table with ONE entry moved to the chosen value
+      defaults: the chosen TABLE under the shipped orr_config constants (contact_erp, warmstart_factor, contact_margin)
+      greedy  : put back, one at a time, the entry whose reversion hurts the fit score least, while both fit policies stay >= 0.8"""
+    rec = json.load(open(args.ablate))
+    th = rec["chosen"]["theta"]
+    base = shipped_theta()
+    keys = [k for k in list(NAMES) + list(SWITCHES) if th[k] != base[k] and not (k == "friction_erp" and not th["anchor"])]
+    out = {"of": args.ablate, "robots": args.robots, "fit": [p for p, _ in FIT], "keys": keys}
+    t0 = time.time()
+
+    def reverted(theta, ks):
+        t2 = dict(theta)
+        for k in ks:
+            t2[k] = base[k]
+            if k == "soft":
+                t2["soft_k"], t2["soft_d"] = base["soft_k"], base["soft_d"]
+        return t2
+
+    def applied(ks):
+        t2 = dict(base)
+        for k in ks:
+            t2[k] = th[k]
+            if k == "soft":
+                t2["soft_k"], t2["soft_d"] = th["soft_k"], th["soft_d"]
+        return t2
+    cfgk = [k for k in NAMES if PARAMS[k][3] == "c"]
+    cands = [th] + [reverted(th, [k]) for k in keys] + [applied([k]) for k in keys] + [reverted(th, cfgk)]
+    rs = evaluate_exact(probe, cands, FIT, args.steps)
+    sc = [score(r, FIT) for r in rs]
+    out["chosen"] = {"fit": rs[0], "score": sc[0]}
+    out["single_reverted"] = {k: {"fit": rs[1 + i], "score": sc[1 + i]} for i, k in enumerate(keys)}
+    out["single_applied"] = {k: {"fit": rs[1 + len(keys) + i], "score": sc[1 + len(keys) + i]} for i, k in enumerate(keys)}
+    out["table_with_shipped_config"] = {"fit": rs[-1], "score": sc[-1]}
+    print("chosen: %.3f / %.3f" % sc[0])
+    print("chosen table under the shipped solver constants: %.3f / %.3f   %s" % (sc[-1][0], sc[-1][1], json.dumps({p: rs[-1][p]["F"] for p, _ in FIT})))
+    for i, k in enumerate(keys):
+        print("  %-18s reverted: %.3f / %.3f     applied alone to the shipped table: %.3f / %.3f" % (
+            k, sc[1 + i][0], sc[1 + i][1], sc[1 + len(keys) + i][0], sc[1 + len(keys) + i][1]), flush=True)
+    # greedy reversion from the chosen table under the SHIPPED solver constants if that keeps the acceptance, else from the chosen candidate
+    cur = reverted(th, cfgk) if sc[-1][0] >= 0.8 else dict(th)
+    left = [k for k in keys if cur[k] != base[k]]
+    path = []
+    while left:
+        trial = [reverted(cur, [k]) for k in left]
+        rs2 = evaluate_exact(probe, trial, FIT, args.steps)
+        sc2 = [score(r, FIT) for r in rs2]
+        b = int(np.argmax([x[0] + 1e-3 * x[1] for x in sc2]))
+        if sc2[b][0] < 0.8:
+            break
+        cur = trial[b]
+        path.append({"reverted": left[b], "score": sc2[b], "fit": {p: rs2[b][p]["F"] for p, _ in FIT}})
+        print("  greedy: %-18s back to shipped -> %.3f / %.3f (%d entries still moved)" % (left[b], sc2[b][0], sc2[b][1], len(left) - 1), flush=True)
+        left.pop(b)
+    out["greedy"] = {"path": path, "still_moved": left, "theta": cur, "dist": distance(cur)}
+    fin = evaluate_exact(probe, [cur], FIT, args.steps)[0]
+    out["greedy"]["fit"] = fin
+    print("greedy end: %d entries still differ from the shipped table: %s; distance %.2f; fit %s" % (len(left), left, distance(cur), json.dumps({p: fin[p]["F"] for p, _ in FIT})))
+    out["elapsed_s"] = time.time() - t0
+    with open(args.out, "w") as f:
+        json.dump(out, f, indent=1)
+
+
 def share_config(group):
     """The candidates of a group run under ONE handle: they take the group's first candidate's orr_config constants."""
     for th in group[1:]:
@@ -323,8 +410,11 @@ def main():
     ap.add_argument("--backend", default="hip", choices=["hip", "oracle"])
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "laikago_identify.json"))
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--ablate", default=None, help="result file of a finished run: FIT-set-only ablation of its chosen candidate (see ablate())")
     args = ap.parse_args()
     probe = (HipProbe if args.backend == "hip" else OracleProbe)(args.robots)
+    if args.ablate:
+        return ablate(args, probe)
     rng = np.random.RandomState(args.seed)
     t0 = time.time()
     budget = args.minutes * 60.0
