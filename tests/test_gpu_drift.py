@@ -46,6 +46,20 @@ def _three(robot, n, seed, randomizer=True, mode="train"):
     return env, o64, o32, dev_step, dev_state
 
 
+def _warn_if_factors_are_of_other_sources(env):
+    """The factor table is derived on the GPU box from one build of the kernel, one state of the oracle and one pair of robot tables
+    (tools/drift_floor_spread.py records their hashes).  Other sources do not invalidate the float32 floor's SPREAD, but they are not what
+    it was measured on: say so."""
+    import hashlib
+    import warnings
+    rec = drift.factors("laikago") and drift._FACTORS
+    have = {"source_hash": env.L.orr_source_hash().decode(),
+            "oracle_hash": hashlib.sha256(open(os.path.join(ROOT, "oracle", "orr_oracle.c"), "rb").read()).hexdigest()[:32]}
+    for k, v in have.items():
+        if rec.get(k) != v:
+            warnings.warn("tests/golden/drift_factors.json was derived at %s = %s, this run has %s: regenerate with tools/drift_floor_spread.py" % (k, rec.get(k), v))
+
+
 @pytest.mark.parametrize("robot", ["laikago", "mini_cheetah"])
 def test_hip_drift_is_float32_drift(robot):
     n = 1024
@@ -60,6 +74,7 @@ def test_hip_drift_is_float32_drift(robot):
     # factors = the float32 floor's OWN spread on this very sample (K runs from start states one ulp apart + the -O3 -march=native build),
     # x 1.25: tests/golden/drift_factors.json, derived by tools/drift_floor_spread.py, table in profiles/r04_drift_floor_spread_<robot>.txt
     fac_tab = drift.factors(robot)["factors"]
+    _warn_if_factors_are_of_other_sources(env)
     bad = []
     for h in drift.HORIZONS:
         assert tab[h]["alive"] >= 100, "too few robots survive to horizon %d" % h
@@ -68,10 +83,13 @@ def test_hip_drift_is_float32_drift(robot):
             for q, _ in drift.QUANTS:
                 if q == "max" and name in drift.TASK_LEVEL:
                     continue            # discrete events: bounded by COUNT below, not as a quantile of noise
-                fac = row[q]["factor"]
+                # bound: (1 + margin) x the LARGEST value of this quantile over the recorded float32 runs of this very sample -
+                # not "ratio x run 0", which is as loose as max^2 / min when run 0 happens to be the largest of them - or 1.5 x this
+                # run's float32 value where the runs agree to a few per cent
                 d, f = tab[h][name]["dev"][q], tab[h][name]["f32"][q]
-                if d > fac * f + FLOOR:
-                    bad.append("%s h=%d %s: HIP %.3g > %.2f x f32 %.3g" % (name, h, q, d, fac, f))
+                lim = max(drift.FACTOR_MIN * f, (1.0 + drift.MARGIN) * row[q]["max"])
+                if d > lim + FLOOR:
+                    bad.append("%s h=%d %s: HIP %.3g > %.3g (float32 runs: %.3g .. %.3g, this run's %.3g)" % (name, h, q, d, lim, row[q]["min"], row[q]["max"], f))
             if name in drift.TASK_LEVEL:
                 m = alive[h]
                 ed, e32 = out[h][name]

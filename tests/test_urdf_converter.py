@@ -52,11 +52,12 @@ def test_parser_reads_plain_urdf_elements():
 def test_toe_contact_block_fills_the_soft_contact_entries():
     """URDF <contact><stiffness/><damping/><lateral_friction/> on the toe links -> contact_stiffness / contact_damping / foot_friction
     of the table (Bullet's BT_CONTACT_FLAG_CONTACT_STIFFNESS_DAMPING)."""
-    model = robots.laikago()
+    model = robots.laikago(contact_stiffness=0.0, contact_damping=0.0)       # rigid toes (the shipped table's are soft since round 5)
     soft = dict(model, contact_stiffness=30000.0, contact_damping=1000.0, foot_friction=3.0, toe_radius=0.03)
     text = urdf.model_to_urdf(soft, urdf.LAIKAGO_JOINTS, np.random.RandomState(2))
     assert "<stiffness" in text and text.count("<contact>") == 4
     got = urdf.model_from_urdf(text, robots.laikago(), urdf.LAIKAGO_JOINTS)
     assert (got["contact_stiffness"], got["contact_damping"], got["foot_friction"], got["toe_radius"]) == (30000.0, 1000.0, 3.0, 0.03)
-    rigid = urdf.model_from_urdf(urdf.model_to_urdf(model, urdf.LAIKAGO_JOINTS), robots.laikago(), urdf.LAIKAGO_JOINTS)
+    rigid = urdf.model_from_urdf(urdf.model_to_urdf(model, urdf.LAIKAGO_JOINTS), robots.laikago(contact_stiffness=0.0, contact_damping=0.0),
+                                 urdf.LAIKAGO_JOINTS)
     assert rigid["contact_stiffness"] == 0.0 and "<stiffness" not in urdf.model_to_urdf(model, urdf.LAIKAGO_JOINTS)

@@ -12,7 +12,7 @@ quantile.  factor = max(1.5, 1.25 x that ratio).  For the task-level fields (ref
 replaced by a COUNT of discrete-event outliers (tests/drift.py).  The HIP path's own numbers are printed beside the floor's.
 
 Writes tests/golden/drift_factors.json (what the test asserts against) and gpurun_out/drift_floor_spread_<robot>.txt (copied to
-profiles/r04_drift_floor_spread_<robot>.txt).
+profiles/r05_drift_floor_spread_<robot>.txt).
 
 usage: python tools/drift_floor_spread.py [--runs 12] [--out-dir gpurun_out]
 """
@@ -38,7 +38,8 @@ def main():
     from tests.test_gpu_drift import _three
     os.makedirs(args.out_dir, exist_ok=True)
     result = {"_about": "derived by tools/drift_floor_spread.py on the GPU box; see its docstring and tests/drift.py", "runs_perturbed": args.runs,
-              "margin": drift.MARGIN, "factor_min": drift.FACTOR_MIN, "outlier_x": drift.OUTLIER_X, "source_hash": _lib.library_hash()}
+              "margin": drift.MARGIN, "factor_min": drift.FACTOR_MIN, "outlier_x": drift.OUTLIER_X, "source_hash": _lib.library_hash(),
+              "oracle_hash": __import__("hashlib").sha256(open(os.path.join(ROOT, "oracle", "orr_oracle.c"), "rb").read()).hexdigest()[:32]}
     for robot in ("laikago", "mini_cheetah"):
         n = 1024
         env, o64, o32, dev_step, dev_state = _three(robot, n, seed=31)

@@ -88,6 +88,8 @@ NAMES = list(PARAMS)
 
 
 def shipped_theta():
+    """The ROUND-4 table (robots.LAIKAGO_R04) and solver constants: the reference point of the intervals and of the distance.  (Since the
+    run recorded in profiles/r05_laikago_identify.json, robots.laikago() IS that run's chosen candidate.)"""
     th = {k: PARAMS[k][0] for k in NAMES}
     th.update({k: SWITCHES[k][0] for k in SWITCHES})
     th.update(soft_k=30000.0, soft_d=1000.0)
@@ -138,8 +140,8 @@ def build_model(th):
     """theta -> robot model table (robots.laikago with the varied entries replaced)."""
     from openroborl_amd import robots
     kw = {k: th[k] for k in NAMES if PARAMS[k][3] == "b"}
-    # base COM in front of the hips' centre = all hips shifted back by com_x: per-leg x positions are not a _build argument, patched below
     kw["hip_xy"] = [th["hip_x"], th["hip_y"]]
+    kw["com_x"] = th["com_x"]            # base COM in front of the hips' centre: hips and chassis box shifted back by com_x (robots._build)
     kw["base_inertia"] = [th["base_I"] * x for x in (0.073348887, 0.250684593, 0.254469458)]
     s = th["leg_I"]
     kw["hip_I"] = [s * x for x in (0.00100, 0.00120, 0.00100)]
@@ -151,19 +153,12 @@ def build_model(th):
     kw["chassis_half"] = [th["chassis"] * x for x in (0.27, 0.09, 0.055)]
     if not th["limits"]:
         kw["limits"] = [(-1e9, 1e9)] * 3
-    if th["soft"]:
-        kw["contact_stiffness"], kw["contact_damping"] = th["soft_k"], th["soft_d"]
+    kw["contact_stiffness"], kw["contact_damping"] = (th["soft_k"], th["soft_d"]) if th["soft"] else (0.0, 0.0)
     kw["friction_anchor"] = int(th["anchor"])
     m = robots.laikago(**kw)
     ref = robots.laikago()
     for key in ("kp", "kd", "init_motor_angles", "motor_dir", "motor_offset", "joint_of_motor", "init_pos", "init_quat"):
         assert np.array_equal(np.asarray(m[key]), np.asarray(ref[key])), key          # the reference's constants are untouched
-    m["joint_pos"] = np.array(m["joint_pos"], dtype=np.float64)
-    for leg in range(4):
-        m["joint_pos"][3 * leg][0] -= th["com_x"]
-    fp = np.array(m["fall_pos"], dtype=np.float64)
-    fp[:8, 0] -= th["com_x"]                                                          # the chassis box moves with the hips
-    m["fall_pos"] = fp
     return m
 
 
