@@ -184,7 +184,11 @@ typedef struct orr_model {
   float contact_stiffness;              /* URDF <contact><stiffness/><damping/> of the TOE link (Bullet's BT_CONTACT_FLAG_CONTACT_STIFFNESS_DAMPING): */
   float contact_damping;                /* the toe's normal row gets cfm = 1 / (dt k + d), erp = dt k / (dt k + d) instead of the global
                                            contact_erp and cfm 0 (btMultiBodyConstraintSolver::setupMultiBodyContactConstraint).
-                                           stiffness <= 0 = rigid contact (the global pair); ABI v4 */
+                                           stiffness <= 0 = rigid contact (the global pair); ABI v4.  These are the values of the PAIR: Bullet combines
+                                           the two bodies' entries (btManifoldResult: k = 1 / (1 / k_toe + 1 / k_plane), d = d_toe + d_plane; the
+                                           plane's defaults - a huge stiffness and a damping of 0.1 - change (30000, 1000) by 0.01 %), the caller folds
+                                           them in if it has them.  orr_config (sim_dt, contact_erp) must be final before orr_set_model: the
+                                           row's cfm / erp are folded when the model is set */
   int32_t friction_anchor;              /* URDF <contact><friction_anchor/> of the TOE link (ABI v5): the toe's contact point is CACHED while its
                                            friction impulse stays inside the cone (btPersistentManifold::replaceContactPoint), and the friction
                                            rows pull the cached pair of points together (orr_config::friction_erp).  0 = off */

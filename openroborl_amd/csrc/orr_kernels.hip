@@ -8,10 +8,10 @@
 // Device code by phase: orr_device.h (LDS image, math, DPP helpers), orr_robot_io.h (record load / store, latency
 // ring), orr_physics.h (one physics sub-step), orr_task.h (motion clips, reward, observation, reset); this file holds
 // the two kernels and the C-ABI.
-// Two translation units are built from this file.  The main one (everything) is compiled with the instruction-level-parallelism
+// Three translation units are built from this file (the third, orr_kernels_anchor.hip, holds the friction-anchor variants: see launch_step_anchor).  The main one (everything) is compiled with the instruction-level-parallelism
 // scheduler: one wave per SIMD, ~300 registers, nothing to hide latency but the wave's own independent instructions.  The second
 // one (orr_kernels_w2.hip: #define ORR_TU_STEP_W2 + #include of this file) holds ONLY the two-waves-per-SIMD instantiation of the step
-// kernel and is compiled with an occupancy-minded scheduler (-O3 + iterative-maxocc since round 4, the compiler's default before): at
+// kernel and is compiled with an occupancy-minded scheduler (-Os + iterative-maxocc since the end of round 4: openroborl_amd/_lib.py HIPCC_FLAGS_W2; the compiler's default before): at
 // 256 registers that variant spills, and the ILP schedule's longer live ranges cost it 8 % (0.382 vs 0.352 ms at 8192 robots; the default
 // scheduler costs the one-wave variant 9 %).
 #if defined(ORR_TU_STEP_W2) || defined(ORR_TU_STEP_ANCHOR)

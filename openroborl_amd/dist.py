@@ -30,7 +30,7 @@ def init_from_env(backend=None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     # ORR_FORCE_DIST=1: build the process group even for one rank (a one-GPU smoke test of the RCCL code path)
-    if (world > 1 or os.environ.get("ORR_FORCE_DIST")) and not dist.is_initialized():
+    if (world > 1 or os.environ.get("ORR_FORCE_DIST", "0") == "1") and not dist.is_initialized():
         if backend is None:
             backend = os.environ.get("ORR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -145,7 +145,7 @@ def allgather_packed(buf, capacity, group=None):
     """all_gather of one packed payload per rank (pack_episode_stats layout) + unpack."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not os.environ.get("ORR_FORCE_DIST")):
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and os.environ.get("ORR_FORCE_DIST", "0") != "1"):
         return unpack_episode_stats([buf], capacity)
     if dist.get_backend(group) == "gloo" and buf.is_cuda:   # rehearsal on a one-GPU box: stage through the host
         buf = buf.cpu()

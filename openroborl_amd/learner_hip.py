@@ -81,7 +81,7 @@ class FusedPPO(object):
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()):
             return False
-        return dist.get_world_size(self.group) > 1 or bool(os.environ.get("ORR_FORCE_DIST"))
+        return dist.get_world_size(self.group) > 1 or (os.environ.get("ORR_FORCE_DIST", "0") == "1")
 
     def _graph_key(self, several):
         return (self.lr, self.b1, self.b2, self.eps, self.clip, self.vf_coef, float(self.model.std), self.adam_flags, self._world(), several)

@@ -56,7 +56,7 @@ class ActorCritic(object):
         import torch
         self.torch = torch
         self.device = torch.device(device)
-        self.std = float(std)
+        self._std = float(std)
         g = torch.Generator().manual_seed(seed)
         self.p = {}
         dims = [obs_dim] + list(hidden)
@@ -75,6 +75,19 @@ class ActorCritic(object):
             v.requires_grad_(True)
         self.fused = None          # policy_hip.FusedActorCritic once enable_fused() was called
         self._fused_dirty = True
+
+    @property
+    def std(self):
+        return self._std
+
+    @std.setter
+    def std(self, value):
+        """One number for the sampler AND the log-probabilities: the fused forward pass takes std by value at every launch, so a policy
+        whose std is changed after enable_fused() must hand it on (a re-captured rollout graph sampled with the old std while
+        the log-probabilities used the new one)."""
+        self._std = float(value)
+        if getattr(self, "fused", None) is not None:
+            self.fused.std = self._std
 
     def enable_fused(self):
         """Route act() through the fused matrix-core forward pass (csrc/orr_policy.hip).  The packed weight copy is

@@ -1,10 +1,16 @@
-"""All five PyBullet-trained policies the reference ships (task/policies/*.zip), on the HIP path, with their levels pinned BOTH ways.
+"""All five PyBullet-trained policies the reference ships (task/policies/*.zip), on the HIP path.
 
 They are the only PyBullet-derived artefacts in the reference tree, i.e. the only behavioural evidence about SURVEY 8a row C that exists
-here.  `laikago_pace` and `minicheetah_trot` walk the 600-step episode; the three that no table entry was ever
-tuned against - `laikago_spin`, `laikago_trot`, `laikago_trot0` - fall on this engine.  That is a finding, not something to hide or to
-fit away: the test asserts the measured level of each, so that any change of the engine or of a table that moves one of them - in either
-direction - fails here and has to be looked at (and written up)."""
+here.  STATUS OF EACH ANCHOR - read this before taking a green run for physics parity:
+
+  laikago_trot, laikago_spin   IN SAMPLE: the Laikago table was identified against these two (tools/laikago_identify.py, round 5)
+  laikago_trot0, laikago_pace  HELD OUT by that identification's protocol: run once on the chosen candidate (0.55 / 1.00 finish); what is
+                               pinned here is the level of the SHIPPED configuration (the chosen table under the unchanged solver constants)
+  minicheetah_trot             IN SAMPLE: the mini-cheetah table was identified against it (tools/mc_identify.py, round 3); there is no
+                               second mini-cheetah policy to hold out
+
+Bounds: two-sided only for the policies that walk the whole episode; a policy that partly fails is bounded from BELOW only
+and its level is printed, so that a change that brings the engine closer to Bullet never turns this file red."""
 import json
 import os
 import sys
@@ -27,13 +33,15 @@ def test_every_shipped_zip_is_matched_to_exactly_one_clip_pair():
         assert m["clip"] == pol.rstrip("0") and 1 <= len(m["clips_with_equal_bounds"]) <= 2
 
 
-# policy: (clip, robot, robots, finished lo, finished hi, mean survival lo, hi [steps])   measured: DESIGN.md section 7c
+# policy: (clip, robot, robots, finished lo, finished hi, mean survival lo, hi [steps])   hi = None: no upper bound.   measured (1024 robots,
+# seeds 1 / 2, profiles/r05_policy_probe.txt) in the comments
 LEVELS = {
-    "laikago_pace": ("laikago_pace", "laikago", 256, 0.97, 1.0, 590, 600),          # 1.000, 600
-    "laikago_spin": ("laikago_spin", "laikago", 256, 0.0, 0.05, 30, 120),           # 0.000, 52
-    "laikago_trot": ("laikago_trot", "laikago", 256, 0.0, 0.05, 80, 260),           # 0.000-0.003, 138-143
-    "laikago_trot0": ("laikago_trot", "laikago", 256, 0.0, 0.05, 60, 230),          # 0.000-0.001, 110-117
-    "minicheetah_trot": ("minicheetah_trot", "mini_cheetah", 1024, 0.84, 0.95, 490, 580),   # 0.883-0.901, 531-542
+    "laikago_pace": ("laikago_pace", "laikago", 256, 0.97, 1.0, 590, 600),          # held out: 1.000 / 1.000, 600
+    "laikago_spin": ("laikago_spin", "laikago", 256, 0.75, None, 470, None),        # fit:      0.883 / 0.888, 539-545 (round-4 table: 0.000, 52)
+    "laikago_trot": ("laikago_trot", "laikago", 256, 0.85, None, 520, None),        # fit:      0.931 / 0.949, 563-573 (round-4 table: 0.000, 138-143)
+    "laikago_trot0": ("laikago_trot", "laikago", 256, 0.40, None, 380, None),       # held out: 0.532 / 0.500, 420-434 (round-4 table: 0.001, 110-117);
+                                                                                    # what fails lags > 1 m behind the reference (475 of 479), it does not fall
+    "minicheetah_trot": ("minicheetah_trot", "mini_cheetah", 1024, 0.84, 0.95, 490, 580),   # in sample: 0.902 / 0.883, 531-543
 }
 
 
@@ -43,13 +51,15 @@ def test_all_five_shipped_policies(pol):
     clip, robot, n, f_lo, f_hi, l_lo, l_hi = LEVELS[pol]
     o = policy_probe.run(pol, clip, robot, n, seed=1, raw=True)
     print("POLICY_PROBE " + policy_probe.fmt(o))
-    assert f_lo <= o["finished"] <= f_hi, (pol, o["finished"])
-    assert l_lo <= o["len"] <= l_hi, (pol, o["len"])
+    assert f_lo <= o["finished"] and (f_hi is None or o["finished"] <= f_hi), (pol, o["finished"])
+    assert l_lo <= o["len"] and (l_hi is None or o["len"] <= l_hi), (pol, o["len"])
     assert o["reasons"]["non_finite"] == 0
     t = o["terms"]
     assert all(0.0 <= t[k] <= 1.0 + 1e-3 for k in t), t        # the five terms recomputed from the state record are consistent with the reward
     if pol == "laikago_pace":
-        assert o["reward_per_step"] > 0.6
+        assert o["reward_per_step"] > 0.65                                                     # 0.73 (round-4 table: 0.68)
+    if pol == "laikago_trot0":
+        assert o["reasons"]["fall"] <= 0.1 * max(o["reasons"]["root_pos"], 1)                  # it lags, it does not fall
     if pol == "minicheetah_trot":
         # where the ~10 % fall: not the warm-up starts (VERDICT r3's hypothesis) but two windows of the trot cycle,
         # half a cycle apart, and early in the episode

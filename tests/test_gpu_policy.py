@@ -176,6 +176,25 @@ def test_graph_rollout_equals_the_eager_collector():
                     m.p[k2].mul_(1.0 + 0.01 * (seg + 1))
                 m.mark_updated()
     assert collector.graph is not None and ended >= n                  # episodes ended and restarted inside the replayed segments
+    # by-value launch arguments frozen into the captured graph: a new exploration std and a new env seed after the capture -
+    # the collector must capture again, and the new graph must SAMPLE with the new std (it is handed on to the fused forward pass by
+    # ActorCritic.std's setter), not only compute the log-probabilities with it
+    for seg, change in ((4, "std"), (5, "seed"), (6, None)):
+        if change == "std":
+            for m in models:
+                m.std = 0.25
+        elif change == "seed":
+            for e in envs:
+                e.seed(12345)
+        noise = torch.randn(T, n, 12, device=dev, generator=gen)
+        a = rollout.collect_rollout(envs[0], models[0], T, obs=obs[0], noise=noise)
+        b = collector.collect(obs[1], noise=noise)
+        for k in ("obs", "actions", "rewards", "dones", "vpred", "last_obs"):
+            assert torch.equal(a[k], b[k]), (seg, change, k)
+        np.testing.assert_allclose(b["logp"].cpu().numpy(), a["logp"].cpu().numpy(), rtol=1e-6, atol=1e-5)
+        if change == "std":      # the sampled actions really moved with the std: raw action - mean = std * noise
+            assert float((b["actions"][0] - a["actions"][0]).abs().max()) == 0.0 and models[1].fused.std == 0.25
+        obs = [a["last_obs"], b["last_obs"]]
     stats = [e.stats() for e in envs]
     assert stats[0] == stats[1]
     for e in envs:

@@ -56,3 +56,42 @@ def test_drift_statistics_on_synthetic_errors():
         pass
     else:
         raise AssertionError("a 4x larger median was accepted")
+
+
+def test_shipped_laikago_table_is_the_identified_candidate_and_the_record_follows_its_protocol():
+    """robots.laikago() IS the chosen candidate of tools/laikago_identify.py's recorded run (profiles/r05_laikago_identify.json), the run
+    followed the protocol stated in the tool's docstring (fit on trot + spin, hold-out run once on the chosen candidate), and what the
+    search did NOT vary is what the reference fixes."""
+    import laikago_identify as li
+    from openroborl_amd import robots
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r05_laikago_identify.json")))
+    assert rec["fit"] == ["laikago_trot", "laikago_spin"] and rec["holdout"] == ["laikago_trot0", "laikago_pace"]
+    assert "BEFORE the sweep was run" in li.__doc__ and rec["criterion"].split()[:8] == li.__doc__.split("PROTOCOL AND CRITERION")[1].split()[:8]
+    ch = rec["chosen"]
+    assert rec["verdict"] == "accepted" and all(ch["fit"][p]["F"] >= 0.8 for p in rec["fit"])            # rule 2
+    assert ch["robustness"]["mean_score"] >= 0.6                                                         # rule 3: not a knife edge
+    assert all(rec["shipped_table_fit"][p]["F"] <= 0.01 for p in rec["fit"])                             # where the search started: nobody walks
+    assert rec["row_c_pinned_by_holdout"] == all(ch["holdout"][p]["F"] >= 0.5 for p in rec["holdout"])   # rule 5, whatever it came to
+    for k, (v0, lo, hi) in rec["params"].items():
+        assert lo - 1e-12 <= ch["theta"][k] <= hi + 1e-12, k                                             # inside the stated box
+        assert (v0, lo, hi) == tuple(li.PARAMS[k][:3]), k                                                # the box in the tool is the box of the run
+    m_tool, m_ship = li.build_model(ch["theta"]), robots.laikago()
+    for key, val in m_ship.items():
+        if isinstance(val, str):
+            continue
+        b = np.asarray(m_tool[key], dtype=float)
+        np.testing.assert_allclose(np.asarray(val, dtype=float), b, rtol=3e-5, atol=3e-5 * max(1.0, float(np.abs(b).max())), err_msg=key)   # 5 digits
+    # the reference point of the search = round 4's table, reproduced by robots.LAIKAGO_R04
+    r4, t4 = robots.laikago(**robots.LAIKAGO_R04), li.build_model(li.shipped_theta())
+    for key, val in r4.items():
+        if not isinstance(val, str):
+            np.testing.assert_allclose(np.asarray(val, dtype=float), np.asarray(t4[key], dtype=float), atol=1e-9, err_msg=key)
+    for key in ("kp", "kd", "init_motor_angles", "motor_dir", "motor_offset", "joint_of_motor", "init_pos", "init_quat", "joint_axis"):
+        np.testing.assert_array_equal(np.asarray(m_ship[key]), np.asarray(r4[key]), err_msg=key)          # control constants, conventions
+    # link lengths (trans2minicheetah.m:3-5): knee below the hip pitch axis, toe below the knee
+    assert np.allclose(m_ship["joint_pos"][2], [0, 0, -0.25223]) and np.allclose(m_ship["toe_pos"][0], [0, 0, -0.251])
+    # the solver constants that ship are the library defaults, not the candidate's: the candidate's table is accepted under them too
+    ab = json.load(open(os.path.join(ROOT, "profiles", "r05_laikago_identify_ablation.json")))
+    assert all(ab["table_with_shipped_config"]["fit"][p]["F"] >= 0.8 for p in rec["fit"])
+    assert ab["single_reverted"]["soft"]["score"][0] < 0.5 and ab["single_reverted"]["foot_friction"]["score"][0] < 0.5    # what it hangs on
+    assert min(ab["single_reverted"][k]["score"][0] for k in ("chassis", "hip_r", "knee_r")) >= 0.8                      # not the fall proxies

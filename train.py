@@ -104,7 +104,7 @@ def main():
                                   epochs=args.epochs, generator=gen)
         samples += T * n * world
         # (> 1 rank, or ORR_FORCE_DIST=1: the one-rank rehearsal of the several-ranks path on RCCL runs the check too)
-        if (world > 1 or os.environ.get("ORR_FORCE_DIST")) and it % args.sync_check_every == args.sync_check_every - 1 and hasattr(learner, "check_synced"):
+        if (world > 1 or os.environ.get("ORR_FORCE_DIST", "0") == "1") and args.sync_check_every > 0 and it % args.sync_check_every == args.sync_check_every - 1 and hasattr(learner, "check_synced"):
             learner.check_synced()                            # like MpiAdam every 100 updates (mpi_adam.py:47-48)
         stats = odist.gather_env_episodes(env, args.horizon)   # means come from the exact per-rank sums, not the truncated list
         if rank == 0 and (it % 10 == 0 or it == args.iters - 1):
