@@ -187,7 +187,7 @@ typedef struct orr_model {
                                            stiffness <= 0 = rigid contact (the global pair); ABI v4.  These are the values of the PAIR: Bullet combines
                                            the two bodies' entries (btManifoldResult: k = 1 / (1 / k_toe + 1 / k_plane), d = d_toe + d_plane; the
                                            plane's defaults - a huge stiffness and a damping of 0.1 - change (30000, 1000) by 0.01 %), the caller folds
-                                           them in if it has them.  orr_config (sim_dt, contact_erp) must be final before orr_set_model: the
+                                           them in if it has them.  The configuration's sim_dt and contact_erp must be final before the model is set: the
                                            row's cfm / erp are folded when the model is set */
   int32_t friction_anchor;              /* URDF <contact><friction_anchor/> of the TOE link (ABI v5): the toe's contact point is CACHED while its
                                            friction impulse stays inside the cone (btPersistentManifold::replaceContactPoint), and the friction
