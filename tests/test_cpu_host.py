@@ -257,3 +257,15 @@ def test_null_handles_are_reported_not_dereferenced():
     L = _lib.load()
     assert L.orr_bind(None, C.c_void_p(16), C.c_void_p(16), None, 0) < 0 and b"orr_bind" in L.orr_last_error()
     assert L.orr_step(None, None, None, None, None, None) < 0
+
+
+def test_graft_entry_build_checks_the_current_abi_version():
+    """__graft_entry__.build() is the driver's "does it build" check: it must assert the ABI version the header declares (round 5 bumped the
+    header to v5 while build() still asserted 4 - caught before the driver ran it)."""
+    import re
+    hdr = open(os.path.join(ROOT, "include", "openroborl_hip.h")).read()
+    ver = int(re.search(r"#define ORR_ABI_VERSION (\d+)", hdr).group(1))
+    from openroborl_amd import _abi
+    assert _abi.ABI_VERSION == ver
+    src = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    assert "_abi.ABI_VERSION == %d" % ver in src
