@@ -37,7 +37,7 @@ def split_overrides(over):
     return build, cfg
 
 
-def run(policy, clip_name, n, steps, seed, over, threads=8):
+def run(policy, clip_name, n, steps, seed, over, threads=8, table="shipped"):
     W = np.load(os.path.join(ol.GOLDEN, "policy_%s.npz" % policy))
     w = {k: W[k].astype(np.float64) for k in W.files}
     clip = motion.MotionClip(clip_name)
@@ -47,7 +47,7 @@ def run(policy, clip_name, n, steps, seed, over, threads=8):
                              auto_reset=False, legacy_grid=False)
     for k, v in cfg_over.items():
         setattr(cfg, k, type(getattr(cfg, k))(v))
-    model = robots.laikago(**build)
+    model = robots.laikago(**dict(robots.LAIKAGO_R04 if table == "r04" else {}, **build))
     orc = ol.OracleEnv(cfg, [model, None, None, None], [clip], n, robot_type=np.zeros(n, dtype=np.int32), clip_id=np.zeros(n, dtype=np.int32),
                        threads=threads)
     if spin:
@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--set", nargs="*", default=[])
     ap.add_argument("--holdout", action="store_true", help="ALSO run the two held-out policies (only once a candidate is chosen)")
+    ap.add_argument("--table", default="shipped", choices=["shipped", "r04"], help="r04: start from round 4's hand-authored table (robots.LAIKAGO_R04)")
     args = ap.parse_args()
     over = {}
     for kv in args.set:
@@ -103,10 +104,10 @@ def main():
     t0 = time.time()
     out = []
     for pol, clip in rows:
-        o = run(pol, clip, args.robots, args.steps, args.seed, over)
+        o = run(pol, clip, args.robots, args.steps, args.seed, over, table=args.table)
         out.append(o)
         print("%-14s finished %.2f  len %5.1f  r/step %.3f  fall %d pos %d rot %d" % (pol, o["finished"], o["len"], o["r"], o["fall"], o["pos"], o["rot"]), flush=True)
-    print("# %s  (%.0f s)" % (json.dumps(over), time.time() - t0))
+    print("# table %s + %s  (%.0f s)" % (args.table, json.dumps(over), time.time() - t0))
 
 
 if __name__ == "__main__":
