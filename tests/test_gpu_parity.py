@@ -177,6 +177,56 @@ def test_step_parity(robot, randomizer):
     env.close(); orc.close(); o32.close()
 
 
+def test_env_step_with_friction_anchors_matches_the_oracle_and_resets_clear_them():
+    """The ANCHOR variant of the ENV STEP kernel (orr_step_kernel<0, 1, true>: its own translation unit; load of the cached contact
+    points at the start of a launch, the carry over 33 sub-steps in registers, the store by the normal-row lanes, the clearing by an inline
+    reset) against the oracle: a full env step from an identical start (float32-floor bounds like test_step_parity), the same toes holding a
+    cached point on both sides, the same points; then train mode until the 20-step time limit: a robot reset inside the launch has no
+    cached point left, as on the oracle; and the standalone reset kernel clears them too."""
+    import torch
+    n = 256
+    env, orc = make_pair("laikago", n=n, model_overrides={"laikago": ANCHOR_TOES})
+    env.reset(); orc.reset()
+    st = gpu_state64(env)
+    orc.state[:] = st
+    o32 = f32_twin(env, orc)
+    rng = np.random.RandomState(5)
+    act = torch.tensor(rng.uniform(-0.3, 0.3, (n, 12)), dtype=torch.float32, device=env.device)
+    og, rg, dg, _ = env.step(act)
+    oo, ro, do = orc.step(act.cpu().numpy().astype(np.float64))
+    o32.step(act.cpu().numpy())
+    compare_to_floor(env, orc, o32, RIGID, "anchor step")
+    g = gpu_state64(env)
+    lay = env.layout
+    vg, vo = g[:, lay.sl("ANCHOR_VALID")], orc.state[:, lay.sl("ANCHOR_VALID")]
+    assert (vg == vo).mean() > 0.97 and vo.mean() > 0.2            # 33 un-synced sub-steps of contact chaos: a toe or two may differ
+    same = (vg == vo) & (vo > 0)
+    ag, ao = g[:, lay.sl("ANCHOR")].reshape(n, 4, 6), orc.state[:, lay.sl("ANCHOR")].reshape(n, 4, 6)
+    assert np.median(np.abs(ag[same] - ao[same])) < 1e-5
+    env.close(); orc.close(); o32.close()
+    # inline reset and reset kernel clear the cached points
+    env, orc = make_pair("laikago", n=64, randomizer=True, auto_reset=True, mode="train", seed=17, model_overrides={"laikago": ANCHOR_TOES})
+    env.reset(); orc.reset()
+    orc.state[:] = gpu_state64(env)
+    limit = int(env.field_int("MAX_EP_STEPS").max())
+    rng = np.random.RandomState(1)
+    for k in range(limit):
+        a = rng.uniform(-0.05, 0.05, (64, 12)).astype(np.float32)
+        og, rg, dg, _ = env.step(torch.from_numpy(a).to(env.device))
+        oo, ro, do = orc.step(a.astype(np.float64))
+        if k == limit - 2:
+            assert env.field_int("ANCHOR_VALID").any()              # standing robots hold cached points right up to the reset
+    done = dg.cpu().numpy().astype(bool)
+    assert done.sum() > 32
+    g = gpu_state64(env)
+    assert not g[done][:, env.layout.sl("ANCHOR_VALID")].any() and not g[done][:, env.layout.sl("ANCHOR")].any()
+    assert not orc.state[done & do][:, env.layout.sl("ANCHOR_VALID")].any()
+    env.step(torch.zeros(64, 12, device=env.device))
+    env.reset()
+    assert not env.field_int("ANCHOR_VALID").any() and not env.field("ANCHOR").any()
+    env.close(); orc.close()
+
+
 def test_short_rollout_tracks_oracle():
     """10 env steps from an identical start: trajectories stay close (loose: contact dynamics amplify rounding)."""
     import torch
