@@ -24,6 +24,16 @@ ACTION_REPEAT = 33          # laikago.py:26, mini_cheetah.py:26 NUM_ACTION_REPEA
 CTRL_LATENCY = 0.002        # laikago.py:27
 
 
+# Solver constants PyBullet is REMEMBERED to set in place of the Bullet library's defaults (PhysicsServerCommandProcessor::
+# createEmptyDynamicsWorld: m_erp2 = 0.08, m_warmstartingFactor = 0.1, m_frictionERP = 0.2; btCollisionDispatcher's default
+# CD_USE_RELATIVE_CONTACT_BREAKING_THRESHOLD: 0.02 x the shape's bounding radius, i.e. ~1 mm for a toe sphere and a few mm for a link).
+# A recollection of Bullet's public source, not verifiable in this environment: NOT the shipped defaults (make_config keeps the library
+# values), offered as a named set of orr_config overrides - VecQuadrupedEnv(config_overrides=config.PYBULLET_REMEMBERED) - for whoever can
+# check them.  What is known here: the Laikago policies do not care (round 4's sweep, round 5's ablation); the mini-cheetah's termination
+# does care about the margin.
+PYBULLET_REMEMBERED = {"contact_erp": 0.08, "warmstart_factor": 0.1, "friction_erp": 0.2, "contact_margin": 0.004}
+
+
 def load_training_params(task_name, path=None):
     """run.py:194-200: section lookup by --task; ValueError when missing."""
     path = path or DEFAULT_TRAINING_YAML

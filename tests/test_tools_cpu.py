@@ -95,3 +95,34 @@ def test_shipped_laikago_table_is_the_identified_candidate_and_the_record_follow
     assert all(ab["table_with_shipped_config"]["fit"][p]["F"] >= 0.8 for p in rec["fit"])
     assert ab["single_reverted"]["soft"]["score"][0] < 0.5 and ab["single_reverted"]["foot_friction"]["score"][0] < 0.5    # what it hangs on
     assert min(ab["single_reverted"][k]["score"][0] for k in ("chassis", "hip_r", "knee_r")) >= 0.8                      # not the fall proxies
+
+
+def test_laikago_identify_runs_end_to_end_on_the_oracle_backend(tmp_path):
+    """The identification tool's whole flow - random stage, local stage, acceptance, closest-accepted choice with its cloud, the fit-alone
+    and the once-only hold-out evaluation, the JSON record, and the fit-only ablation of that record - at toy size on the CPU oracle
+    (2 robots, 12 steps: the numbers mean nothing, the plumbing is what is tested; the GPU run is profiles/r05_laikago_identify.json)."""
+    import subprocess
+    out = str(tmp_path / "li.json")
+    tool = os.path.join(ROOT, "tools", "laikago_identify.py")
+    r = subprocess.run([sys.executable, tool, "--backend", "oracle", "--robots", "2", "--steps", "12", "--minutes", "0.12", "--out", out],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.load(open(out))
+    assert rec["fit"] == ["laikago_trot", "laikago_spin"] and rec["holdout"] == ["laikago_trot0", "laikago_pace"]
+    assert rec["search"]["candidates"] >= 32 and set(rec["chosen"]["holdout"]) == set(rec["holdout"]) and set(rec["chosen"]["fit_alone"]) == set(rec["fit"])
+    assert all(set(c["fit"]) == set(rec["fit"]) for c in rec["search"]["top_by_score"])          # no candidate of the search saw a hold-out policy
+    ab = str(tmp_path / "ab.json")
+    r = subprocess.run([sys.executable, tool, "--backend", "oracle", "--robots", "2", "--steps", "12", "--ablate", out, "--out", ab],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    a = json.load(open(ab))
+    assert a["fit"] == rec["fit"] and "table_with_shipped_config" in a and "greedy" in a
+
+
+def test_pybullet_remembered_constants_are_config_fields_and_not_the_defaults():
+    from openroborl_amd import config
+    c = config.make_config(4)
+    for k, v in config.PYBULLET_REMEMBERED.items():
+        assert hasattr(c, k)
+    assert (c.contact_erp, c.warmstart_factor, c.contact_margin) != tuple(config.PYBULLET_REMEMBERED[k] for k in ("contact_erp", "warmstart_factor", "contact_margin"))
+    assert abs(c.contact_erp - 0.2) < 1e-7 and abs(c.warmstart_factor - 0.85) < 1e-7 and abs(c.contact_margin - 0.02) < 1e-7 and abs(c.friction_erp - 0.2) < 1e-7
