@@ -251,13 +251,20 @@ def test_short_rollout_tracks_oracle():
     env.close(); orc.close(); o32.close()
 
 
-@pytest.mark.parametrize("soft_type", [None, "mini_cheetah"])
+@pytest.mark.parametrize("soft_type", [None, "mini_cheetah", "anchor:mini_cheetah"])
 def test_mixed_batch_parity(soft_type):
     """BASELINE config 5: interleaved Laikago / mini-cheetah robots in one launch (divergent wavefronts).  soft_type: that robot type's
-    toes with Bullet's contact stiffness / damping, the other type rigid - the two contact models side by side in every wavefront."""
+    toes with Bullet's contact stiffness / damping (the Laikago table's are soft since round 5), the other type as shipped - two contact
+    models side by side in every wavefront; "anchor:<type>": that type's toes with friction anchors, i.e. the ANCHOR variant of the step
+    kernel serving robots with and without cached contact points in the same wavefront."""
     import torch
     n = 64
-    env, orc = make_pair(n=n, mixed=["laikago", "mini_cheetah"], model_overrides={soft_type: SOFT_TOES} if soft_type else None)
+    over = None
+    if soft_type and soft_type.startswith("anchor:"):
+        over = {soft_type.split(":")[1]: ANCHOR_TOES}
+    elif soft_type:
+        over = {soft_type: SOFT_TOES}
+    env, orc = make_pair(n=n, mixed=["laikago", "mini_cheetah"], model_overrides=over)
     og = env.reset().cpu().numpy()
     oo = orc.reset()
     np.testing.assert_allclose(og, oo, atol=2e-6)
@@ -267,6 +274,13 @@ def test_mixed_batch_parity(soft_type):
     oo, ro, do = orc.step(a.astype(np.float64))
     np.testing.assert_allclose(rg.cpu().numpy(), ro, atol=3e-3)
     np.testing.assert_allclose(og.cpu().numpy()[:, 84:], oo[:, 84:], atol=5e-4)
+    if soft_type and soft_type.startswith("anchor:"):
+        g = gpu_state64(env)
+        v = g[:, env.layout.sl("ANCHOR_VALID")]
+        t = env.robot_type
+        anchored = t == robots.ROBOT_TYPE_ID[soft_type.split(":")[1]]
+        assert v[anchored].any() and not v[~anchored].any()                       # only the type with anchors ever caches a point
+        assert (v == orc.state[:, env.layout.sl("ANCHOR_VALID")]).mean() > 0.97
     env.close(); orc.close()
 
 
