@@ -23,8 +23,18 @@ assert "asan" in ol.lib()._name
 seen = tg._replay("task_laikago.npz")
 assert seen["wrap"] >= 3 and seen["done_fall"] >= 2, seen
 from tests.test_oracle_env import make
-for robot in ("laikago", "mini_cheetah"):
+import ctypes as C
+from openroborl_amd import robots
+for robot, anchor in (("laikago", 0), ("mini_cheetah", 0), ("laikago", 1)):      # 1: friction anchors + the sub-step trace + the spinning-friction experiment
     env, model, clip = make(robot, n=8, randomizer=True, auto_reset=True, mode="train", seed=3)
+    if anchor:
+        model["friction_anchor"] = 1
+        env.L.orc_set_model(env.h, robots.ROBOT_TYPE_ID[robot], C.byref(robots.to_struct(model)))
+        trace = np.zeros((8, env.cfg.action_repeat, env.L.orc_trace_words()))
+        env.L.orc_set_substep_trace.argtypes = [C.c_void_p, ol.dp]
+        env.L.orc_set_substep_trace(env.h, ol.P(trace))
+        env.L.orc_set_experimental.argtypes = [C.c_void_p, C.c_int, C.c_double]
+        env.L.orc_set_experimental(env.h, 0, 0.05)
     env.reset()
     _, _, _, st, tau = substep_parity_inputs(robot, 8)
     keep = env.state.copy()
@@ -38,6 +48,8 @@ for robot in ("laikago", "mini_cheetah"):
     for k in range(25):                       # crosses the 20-step time limit: auto-reset inside orc_step
         obs, rew, done = env.step(rng.uniform(-0.3, 0.3, (8, 12)))
     assert np.isfinite(obs).all() and np.isfinite(rew).all()
+    if anchor:
+        assert env.state[:, env.lay.sl("ANCHOR_VALID")].any() and np.isfinite(trace).all() and trace.any()
     env.close()
 print("SANITIZED_OK")
 """
