@@ -61,7 +61,7 @@ def test_all_five_shipped_policies(pol):
     if pol == "laikago_trot0":
         assert o["reasons"]["fall"] <= 0.1 * max(o["reasons"]["root_pos"], 1)                  # it lags, it does not fall
     if pol == "minicheetah_trot":
-        # where the ~10 % fall: not the warm-up starts (VERDICT r3's hypothesis) but two windows of the trot cycle,
+        # where the ~10 % fall (round 4: HISTORY.md section 7c): not the warm-up starts (VERDICT r3's hypothesis) but two windows of the trot cycle,
         # half a cycle apart, and early in the episode
         r = o["_raw"]
         fell = ~r["finished"]

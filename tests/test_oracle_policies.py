@@ -78,7 +78,7 @@ def _minicheetah_run(n, steps, margin=None, seed=1):
 
 
 def test_minicheetah_phase_020_fallers_are_ended_by_the_contact_margin_not_by_a_fall():
-    """DESIGN.md section 7c / VERDICT r4 item 2.  The shipped mini-cheetah policy loses ~10 % of its episodes, every one of them started in
+    """DESIGN.md section 7.3 (round 4: HISTORY.md section 7c) / VERDICT r4 item 2.  The shipped mini-cheetah policy loses ~10 % of its episodes, every one of them started in
     one of two windows of the trot cycle.  The window around phase 0.20, on the oracle: the teleported reference state is the flight phase
     just before the FL / RR touchdown (one toe < 1 mm above the ground, the others 2-8 cm up; NO toe penetrates, so the erp push-out of a
     teleport into the ground - the round-4 reviewer's hypothesis - never happens: the first normal impulse comes ~40 sub-steps later).

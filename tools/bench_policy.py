@@ -1,7 +1,7 @@
 """Time the fused actor / critic forward pass (csrc/orr_policy.hip) against the plain PyTorch path it replaces.
 
 usage (GPU box):  python tools/bench_policy.py [robots]
-DESIGN.md section 3a quotes these numbers; `rocprofv3 --kernel-trace --stats -- python3 tools/bench_policy.py` gives the
+HISTORY.md section 3a quotes these numbers; `rocprofv3 --kernel-trace --stats -- python3 tools/bench_policy.py` gives the
 per-kernel view stored in profiles/r01_policy_kernel_stats.csv.
 """
 import os

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The shipped Laikago policies on the float64 CPU ORACLE under variations of the contact model / table (no GPU).
 
-Exploration aid for SURVEY 8a row C: which of Bullet's toe-contact features - friction anchor, spinning friction,
+Exploration aid for SURVEY 8a row C (round 4: HISTORY.md section 7c): which of Bullet's toe-contact features - friction anchor, spinning friction,
 contact stiffness / damping, the URDF's lateral friction, PyBullet's solver constants - change the fate of the PyBullet-trained policies
 on this engine.  HOLD-OUT RULE (fixed in round 5 before anything was run): only `laikago_trot` and `laikago_spin` may be looked at while
 features or table entries are chosen; `laikago_trot0` and `laikago_pace` are evaluated once, at the end, on the chosen candidate
