@@ -2,9 +2,11 @@
 """All five PyBullet-trained policies the reference ships, run on this engine (runs on the GPU box).
 
 The reference's task/policies/*.zip were trained in PyBullet on the real URDFs: they are the only PyBullet-derived artefacts in the
-tree, i.e. the only behavioural evidence about SURVEY 8a row C (the physics engine) that exists here.  `laikago_pace` was looked at
-while the Laikago table was written and `minicheetah_trot` is what the mini-cheetah table was identified against (round 3); the other
-three (`laikago_spin`, `laikago_trot`, `laikago_trot0`) were never used for anything: OUT OF SAMPLE.  Each zip is matched to its clip
+tree, i.e. the only behavioural evidence about SURVEY 8a row C (the physics engine) that exists here.  Status of the five anchors since
+round 5: `laikago_trot` and `laikago_spin` are IN SAMPLE (the Laikago table was identified against them,
+tools/laikago_identify.py), `laikago_trot0` and `laikago_pace` were HELD OUT by that protocol, `minicheetah_trot` is in sample (round 3).
+(Round 4, whose --sensitivity sweep and LAIKAGO_SHIPPED values below refer to robots.LAIKAGO_R04: pace looked at while the table was
+written, the other three Laikago policies out of sample - and falling.)  Each zip is matched to its clip
 by the 76 target-observation bounds pickled inside it (tests/golden/policy_clips.json, written by tests/golden/make_golden.py); a clip
 and its time reversal have equal bounds, so both are run.
 
