@@ -405,6 +405,9 @@ def main():
     ap.add_argument("--backend", default="hip", choices=["hip", "oracle"])
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "laikago_identify.json"))
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-holdout", action="store_true", help="FIT-SET-ONLY survey run: never evaluates the hold-out policies (the record says so); "
+                    "with --dump-all it is what the accepted-set statistics of DESIGN.md section 7.2 come from")
+    ap.add_argument("--dump-all", default=None, help="write every candidate (parameters, fit results, stage) as JSON lines to this file")
     ap.add_argument("--ablate", default=None, help="result file of a finished run: FIT-set-only ablation of its chosen candidate (see ablate())")
     args = ap.parse_args()
     probe = (HipProbe if args.backend == "hip" else OracleProbe)(args.robots)
@@ -477,7 +480,19 @@ def main():
     if chosen is None:
         chosen = max(cands, key=lambda c: c["score"])
     # re-evaluate the chosen candidate alone (its own config constants, not a group's) on the fit set, THEN - once - on the hold-out
+    if args.dump_all:
+        with open(args.dump_all, "w") as f:
+            for c in cands:
+                f.write(json.dumps({"theta": c["theta"], "F": {p: c["fit"][p]["F"] for p, _ in FIT}, "len": {p: c["fit"][p]["len"] for p, _ in FIT},
+                                    "dist": c["dist"], "stage": c["stage"]}) + "\n")
     chosen["fit_alone"] = evaluate(probe, [chosen["theta"]], FIT, args.steps)[0]
+    if args.no_holdout:
+        chosen["holdout"] = None
+        res.update(chosen=chosen, verdict=verdict, row_c_pinned_by_holdout=None, holdout_evaluated=False, elapsed_s=time.time() - t0)
+        with open(args.out, "w") as f:
+            json.dump(res, f, indent=1)
+        print("fit-set-only survey: %d candidates, %d accepted; the hold-out policies were NOT run" % (len(cands), len(accepted)))
+        return
     chosen["holdout"] = evaluate(probe, [chosen["theta"]], HOLDOUT, args.steps)[0]
     pinned = verdict == "accepted" and all(chosen["holdout"][p]["F"] >= 0.5 for p, _ in HOLDOUT)
     res["chosen"] = chosen
