@@ -42,7 +42,8 @@ def run(policy, clip_name, n, steps, seed, over, threads=8, table="shipped"):
     w = {k: W[k].astype(np.float64) for k in W.files}
     clip = motion.MotionClip(clip_name)
     build, cfg_over = split_overrides(over)
-    spin = build.pop("spinning_friction", 0.0)          # oracle-only experiment (orc_set_experimental)
+    spin = build.pop("spinning_friction", 0.0)          # oracle-only experiments (orc_set_experimental)
+    nofw = build.pop("no_friction_warmstart", 0)
     cfg = config.make_config(n, sim_params=config.load_sim_params(None), mode="test", enable_randomizer=False, seed=seed, num_procs=1,
                              auto_reset=False, legacy_grid=False)
     for k, v in cfg_over.items():
@@ -50,10 +51,11 @@ def run(policy, clip_name, n, steps, seed, over, threads=8, table="shipped"):
     model = robots.laikago(**dict(robots.LAIKAGO_R04 if table == "r04" else {}, **build))
     orc = ol.OracleEnv(cfg, [model, None, None, None], [clip], n, robot_type=np.zeros(n, dtype=np.int32), clip_id=np.zeros(n, dtype=np.int32),
                        threads=threads)
-    if spin:
+    if spin or nofw:
         import ctypes as C
         orc.L.orc_set_experimental.argtypes = [C.c_void_p, C.c_int, C.c_double]
         orc.L.orc_set_experimental(orc.h, 0, float(spin))
+        orc.L.orc_set_experimental(orc.h, 1, float(nofw))
     orc.field("FOOT_MU")[:] = model["foot_friction"]
     obs = orc.reset()
     orc.field("FOOT_MU")[:] = model["foot_friction"]
