@@ -95,3 +95,69 @@ def test_bench_self_launch_runs_ranks_and_propagates_failure():
     assert out.returncode != 0
     assert out.stdout.strip() == ""                    # no result line
     assert "ChildFailedError" in out.stderr or "exitcode" in out.stderr, out.stderr[-2000:]
+
+
+SHARD_WORKER = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, %r)
+from openroborl_amd import _abi, config, dist as odist, motion, robots
+from tests import oracle_lib as ol
+rank, world, local = odist.init_from_env(backend="gloo")
+TOTAL, STEPS, CAP = 32, 22, 64
+
+
+def run(n, offset, num_procs):
+    cfg = config.make_config(n, mode="train", enable_randomizer=True, auto_reset=True, seed=9, num_procs=num_procs)
+    env = ol.OracleEnv(cfg, [robots.laikago(), None, None, None], [motion.MotionClip("laikago_pace")], n, robot_type=0, clip_id=0,
+                       robot_index=np.arange(offset, offset + n), threads=2, ep_log_capacity=256)
+    obs = env.reset()
+    noise = np.random.RandomState(5).randn(STEPS, TOTAL, 12)[:, offset:offset + n] * 0.125      # robot-local: one global table
+    m = env.models[0]
+    outs = []
+    for k in range(STEPS):
+        tar = obs[:, 84 + 7:84 + 19][:, m["joint_of_motor"]]
+        a = np.clip((tar - m["motor_offset"]) * m["motor_dir"] - m["init_motor_angles"] + noise[k], -2 * np.pi, 2 * np.pi)
+        obs, rew, done = env.step(a)
+        outs.append((obs.copy(), rew.copy(), done.copy()))
+    cnt = int(env.counters[_abi.CNT_EPISODES])
+    log = env.ep_log[:cnt].copy()
+    env.close()
+    return outs, log
+
+
+lo, hi = odist.shard_range(TOTAL, rank, world)
+outs, log = run(hi - lo, lo, world)
+stats = odist.allgather_episode_stats(torch.from_numpy(log[:, 0]).float(), torch.from_numpy(log[:, 1]).float(), STEPS * (hi - lo), 0, capacity=CAP)
+if rank == 0:
+    big, biglog = run(TOTAL, 0, 1)
+    for k in range(STEPS):                      # this rank's shard IS rows lo..hi of the one big env, bit for bit (float64 on both sides)
+        for a, b in zip(outs[k], big[k]):
+            assert np.array_equal(a, b[lo:hi]), k
+    rs, ls = stats[0].numpy().astype(np.float64), stats[1].numpy()
+    rb, lb = biglog[:, 0].astype(np.float32).astype(np.float64), biglog[:, 1].astype(np.float32)
+    assert len(rs) == len(rb) >= TOTAL and stats[2] == STEPS * TOTAL
+    o1, o2 = np.lexsort((rs, ls)), np.lexsort((rb, lb))
+    assert np.array_equal(ls[o1], lb[o2]) and np.array_equal(rs[o1], rb[o2])     # the gathered payload = the big env's episode log (as a multiset)
+torch.distributed.barrier()
+torch.distributed.destroy_process_group()
+print("rank", rank, "ok")
+""" % (ROOT,)
+
+
+def test_two_oracle_shards_gathered_over_gloo_are_the_one_big_env(tmp_path):
+    """The N > 1 path end to end on CPU: two processes, each stepping its shard of the robots (global indices by
+    shard_range, per-rank curriculum counter with num_procs = 2) on the oracle, ONE all_gather of the episode payload over gloo -
+    and rank 0 checks that its shard is, bit for bit, its rows of the single 32-robot env and that the gathered payload is that env's
+    episode log.  The device counterpart (one GPU, eight shards one after another): tests/test_gpu_shards.py."""
+    script = tmp_path / "shard_worker.py"
+    script.write_text(SHARD_WORKER)
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+        assert "ok" in o
