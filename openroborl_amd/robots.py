@@ -176,7 +176,12 @@ def laikago(**over):
         pitch_axis=[0.0, 1.0, 0.0],                                          # FK sign: trans_data.py:55-69
         # ---- identified entries (round-4 values in LAIKAGO_R04) ----
         base_mass=13.841, base_inertia=[1.2126 * x for x in (0.073348887, 0.250684593, 0.254469458)],
-        hip_xy=[0.22686, 0.097958], hip_z=-0.068136, com_x=0.021374,
+        # hip_z: the search's winner had -0.068136, but the hip plane's height is pinned by in-tree DATA, not by a policy: with -0.044 the stance
+        # toes of every Laikago clip touch the ground (lowest toe clearance per frame: median +0.2 .. +5 mm over five clips) and the default pose
+        # stands at INIT_POSITION's height; with the winner's value they sit 2 cm UNDER the ground (tools/diag/clip_toe_clearance.py).  The search
+        # box should never have contained this entry; the fit-set ablation shows the fit does not care (0.90 with it put back), so the
+        # calibrated value ships.  This is the ONE entry in which the shipped table differs from the recorded candidate.
+        hip_xy=[0.22686, 0.097958], hip_z=-0.044, com_x=0.021374,
         hip_m=0.97061, hip_com=[0.0, 0.00082832, 0.0], hip_I=[1.5115 * x for x in (0.00100, 0.00120, 0.00100)],
         up_m=1.7255, up_com=[0.0085448, 0.03206, -0.044706], up_I=[1.5115 * x for x in (0.0078, 0.0081, 0.0012)],
         lo_m=0.36971, lo_com=[0.0082597, 0.0, -0.12418], lo_I=[1.5115 * x for x in (0.0013, 0.0013, 0.00005)],

@@ -75,7 +75,10 @@ def test_shipped_laikago_table_is_the_identified_candidate_and_the_record_follow
     for k, (v0, lo, hi) in rec["params"].items():
         assert lo - 1e-12 <= ch["theta"][k] <= hi + 1e-12, k                                             # inside the stated box
         assert (v0, lo, hi) == tuple(li.PARAMS[k][:3]), k                                                # the box in the tool is the box of the run
-    m_tool, m_ship = li.build_model(ch["theta"]), robots.laikago()
+    # ONE entry differs, on purpose: the hip plane's height is pinned by the clips (stance toes on the ground: tools/diag/clip_toe_clearance.py),
+    # not by a policy; the search's winner had put it 2.4 cm lower, the fit-set ablation shows the fit does not care, the calibrated value ships
+    assert abs(ch["theta"]["hip_z"] - (-0.068136)) < 1e-5
+    m_tool, m_ship = li.build_model(dict(ch["theta"], hip_z=-0.044)), robots.laikago()
     for key, val in m_ship.items():
         if isinstance(val, str):
             continue
@@ -95,6 +98,7 @@ def test_shipped_laikago_table_is_the_identified_candidate_and_the_record_follow
     assert all(ab["table_with_shipped_config"]["fit"][p]["F"] >= 0.8 for p in rec["fit"])
     assert ab["single_reverted"]["soft"]["score"][0] < 0.5 and ab["single_reverted"]["foot_friction"]["score"][0] < 0.5    # what it hangs on
     assert min(ab["single_reverted"][k]["score"][0] for k in ("chassis", "hip_r", "knee_r")) >= 0.8                      # not the fall proxies
+    assert ab["single_reverted"]["hip_z"]["score"][0] >= 0.85                                                          # nor the hip height (see above)
 
 
 def test_laikago_identify_runs_end_to_end_on_the_oracle_backend(tmp_path):
