@@ -5,7 +5,9 @@ here.  STATUS OF EACH ANCHOR - read this before taking a g
 
   laikago_trot, laikago_spin   IN SAMPLE: the Laikago table was identified against these two (tools/laikago_identify.py, round 5)
   laikago_trot0, laikago_pace  HELD OUT by that identification's protocol: run once on the chosen candidate (0.55 / 1.00 finish); what is
-                               pinned here is the level of the SHIPPED configuration (the chosen table under the unchanged solver constants)
+                               pinned here is the level of the SHIPPED configuration: the chosen table under the unchanged solver constants
+                               and with the hip height put back to its clip-calibrated value (a correction decided on in-tree data and the
+                               fit policies alone, robots.py): 0.93 / 1.00
   minicheetah_trot             IN SAMPLE: the mini-cheetah table was identified against it (tools/mc_identify.py, round 3); there is no
                                second mini-cheetah policy to hold out
 
@@ -34,13 +36,13 @@ def test_every_shipped_zip_is_matched_to_exactly_one_clip_pair():
 
 
 # policy: (clip, robot, robots, finished lo, finished hi, mean survival lo, hi [steps])   hi = None: no upper bound.   measured (1024 robots,
-# seeds 1 / 2, profiles/r05_policy_probe.txt) in the comments
+# seeds 1 / 2, profiles/r05_policy_probe.txt: the SHIPPED table = the identified candidate with the clip-calibrated hip height) in the comments;
+# in brackets the candidate's own table (profiles/r05_policy_probe_candidate_table.txt) and round 4's
 LEVELS = {
-    "laikago_pace": ("laikago_pace", "laikago", 256, 0.97, 1.0, 590, 600),          # held out: 1.000 / 1.000, 600
-    "laikago_spin": ("laikago_spin", "laikago", 256, 0.75, None, 470, None),        # fit:      0.883 / 0.888, 539-545 (round-4 table: 0.000, 52)
-    "laikago_trot": ("laikago_trot", "laikago", 256, 0.85, None, 520, None),        # fit:      0.931 / 0.949, 563-573 (round-4 table: 0.000, 138-143)
-    "laikago_trot0": ("laikago_trot", "laikago", 256, 0.40, None, 380, None),       # held out: 0.532 / 0.500, 420-434 (round-4 table: 0.001, 110-117);
-                                                                                    # what fails lags > 1 m behind the reference (475 of 479), it does not fall
+    "laikago_pace": ("laikago_pace", "laikago", 256, 0.97, 1.0, 590, 600),          # held out: 1.000 / 1.000, 600  [1.000; 1.000]
+    "laikago_spin": ("laikago_spin", "laikago", 256, 0.75, None, 470, None),        # fit:      0.879 / 0.889, 533-540  [0.883 / 0.888; round 4: 0.000, 52 steps]
+    "laikago_trot": ("laikago_trot", "laikago", 256, 0.80, None, 500, None),        # fit:      0.898 / 0.898, 549-552  [0.931 / 0.949; round 4: 0.000, 138-143]
+    "laikago_trot0": ("laikago_trot", "laikago", 256, 0.80, None, 500, None),       # held out: 0.931 / 0.927, 563-564  [0.532 / 0.500; round 4: 0.001, 110-117]
     "minicheetah_trot": ("minicheetah_trot", "mini_cheetah", 1024, 0.84, 0.95, 490, 580),   # in sample: 0.902 / 0.883, 531-543
 }
 
@@ -57,9 +59,7 @@ def test_all_five_shipped_policies(pol):
     t = o["terms"]
     assert all(0.0 <= t[k] <= 1.0 + 1e-3 for k in t), t        # the five terms recomputed from the state record are consistent with the reward
     if pol == "laikago_pace":
-        assert o["reward_per_step"] > 0.65                                                     # 0.73 (round-4 table: 0.68)
-    if pol == "laikago_trot0":
-        assert o["reasons"]["fall"] <= 0.1 * max(o["reasons"]["root_pos"], 1)                  # it lags, it does not fall
+        assert o["reward_per_step"] > 0.62                                                     # 0.69 (round-4 table: 0.68)
     if pol == "minicheetah_trot":
         # where the ~10 % fall (round 4: HISTORY.md section 7c): not the warm-up starts (VERDICT r3's hypothesis) but two windows of the trot cycle,
         # half a cycle apart, and early in the episode
