@@ -49,7 +49,9 @@ HOLDOUT = [("laikago_trot0", "laikago_trot"), ("laikago_pace", "laikago_pace")]
 PARAMS = {
     "toe_m":        (0.06, 0.005, 0.15, "b"),     # toe link mass [kg]
     "toe_r":        (0.0265, 0.018, 0.035, "b"),  # toe sphere radius [m]
-    "hip_z":        (-0.044, -0.07, 0.0, "b"),    # hip axis plane relative to the base COM [m]
+    "hip_z":        (-0.044, -0.07, 0.0, "b"),    # hip axis plane relative to the base COM [m].  HINDSIGHT: this entry is pinned by the clips (stance toes on
+                                                  # the ground, tools/diag/clip_toe_clearance.py) and should not have been in the box; the recorded runs varied it,
+                                                  # the shipped table carries the calibrated -0.044 (robots.py), the fit does not care (ablation)
     "hip_x":        (0.21, 0.19, 0.25, "x"),      # hip joints in front of / behind the base COM [m] (laikago.py:54-59: 0.21; URDF (mem): 0.2429)
     "hip_y":        (0.082825, 0.07, 0.10, "x"),  # hip joints left / right of the base COM [m]
     "com_x":        (0.0, -0.03, 0.03, "x"),      # base COM in front of the geometric centre of the four hips [m]
