@@ -5,7 +5,7 @@ sys.path.insert(0, '.')
 from openroborl_amd import _abi, config, motion, robots
 from tests import oracle_lib as ol
 P = ol.P
-for name, table in (("round-4 table", robots.LAIKAGO_R04), ("identified table (shipped)", {})):
+for name, table in (("round-4 table", robots.LAIKAGO_R04), ("search winner (hip plane at -0.068)", {"hip_z": -0.068136}), ("shipped table", {})):
     print(name)
     for clipn in ("laikago_pace", "laikago_trot", "laikago_spin", "laikago_inplace_steps", "laikago_turn"):
         clip = motion.MotionClip(clipn)
