@@ -302,3 +302,33 @@ def test_friction_anchor_caches_the_toe_contact_points():
         env.reset()
         assert not env.state[0][lay.sl("ANCHOR_VALID")].any()       # a new episode starts without cached points
         env.close()
+
+
+def test_clip_stance_toes_touch_the_ground_on_the_shipped_tables():
+    """Geometry pinned by in-tree DATA (no physics, no policy): the clips were made by inverse kinematics on the real URDFs, so in every
+    frame the lowest toe of a correct table touches the ground.  The shipped tables do (median clearance of the lowest toe within a few
+    millimetres); the Laikago hip height the policy search of round 5 preferred (-0.068 m) does not - it puts the stance toes 2 cm under
+    the ground - which is why that ONE entry of the identified candidate was put back to this calibration (robots.py)."""
+    def lowest_toe(robot, clip_name, **over):
+        clip = motion.MotionClip(clip_name)
+        cfg = config.make_config(1, mode="test", enable_randomizer=False, auto_reset=False)
+        m = robots.ROBOTS[robot](**over)
+        models = [None, None]
+        t = robots.ROBOT_TYPE_ID[robot]
+        models[t] = m
+        env = ol.OracleEnv(cfg, models, [clip], 1, robot_type=t)
+        lay = env.lay
+        lows = []
+        for f in clip.frames:
+            s = env.state[0].copy()
+            s[lay.sl("POS")] = f[:3]; s[lay.sl("QUAT")] = f[3:7]; s[lay.sl("Q")] = f[7:]
+            out, masses = np.zeros(34 * 3), np.zeros(13)
+            env.L.orc_fk_probe(env.h, P(s), P(out), P(masses))
+            lows.append((out[26 * 3:].reshape(8, 3)[1::2, 2] - m["toe_radius"]).min())
+        env.close()
+        return float(np.median(lows))
+    for clip_name in ("laikago_pace", "laikago_trot", "laikago_spin", "laikago_inplace_steps", "laikago_turn"):
+        assert -0.003 < lowest_toe("laikago", clip_name) < 0.008, clip_name
+    assert lowest_toe("laikago", "laikago_trot", hip_z=-0.068136) < -0.015          # the search's winner: toes under the ground
+    assert -0.003 < lowest_toe("mini_cheetah", "minicheetah_trot") < 0.006
+    assert lowest_toe("mini_cheetah", "minicheetah_trot", hip_z=0.0) < -0.006        # round 2's table, before the policy-based identification
