@@ -277,6 +277,14 @@ def sensitivity(args):
     for name, (kind, key), values in LAIKAGO_SWEEP:
         for v in values:
             mo, co = laikago_variation(kind, key, v)
+            # the sweep is ONE-AT-A-TIME AROUND ROUND 4's TABLE (that is what LAIKAGO_SHIPPED / the "*" marks and the recorded
+            # profiles/r04_laikago_sensitivity.* refer to): the round-4 entries go in first, the variation on top
+            from openroborl_amd import robots as _robots
+            mo = dict(mo)
+            mo["_build"] = dict(_robots.LAIKAGO_R04, **mo.get("_build", {}))
+            for k_ in ("foot_friction", "contact_stiffness", "contact_damping"):      # table entries that are also _build arguments
+                if k_ in mo:
+                    mo["_build"][k_] = mo.pop(k_)
             cells = []
             for pol, clip, robot, _ in rows:
                 o = run(pol, clip, robot, args.robots, args.seeds[0], model_over=mo, config_over=co)
