@@ -31,6 +31,7 @@ CTRL_LATENCY = 0.002        # laikago.py:27
 # values), offered as a named set of orr_config overrides - VecQuadrupedEnv(config_overrides=config.PYBULLET_REMEMBERED) - for whoever can
 # check them.  What is known here: the Laikago policies do not care (round 4's sweep, round 5's ablation); the mini-cheetah's termination
 # does care about the margin.
+BULLET_LIBRARY_DEFAULTS = {"contact_erp": 0.2, "warmstart_factor": 0.85, "friction_erp": 0.2, "contact_margin": 0.02}
 PYBULLET_REMEMBERED = {"contact_erp": 0.08, "warmstart_factor": 0.1, "friction_erp": 0.2, "contact_margin": 0.004}
 
 

@@ -197,6 +197,12 @@ def laikago(**over):
         limits=[(-1.0471975512, 1.0471975512), (-0.5235987756, 3.9269908170), (-2.7750735107, -0.6108652382)]), **over))
 
 
+# Round 2's mini-cheetah entries (published MIT figures from memory) that round 3's identification moved: the reference point of the
+# identification tools' intervals and distances (tools/mc_identify.py, tools/identify_r6.py).
+MINI_CHEETAH_R02 = dict(toe_m=0.15, lo_m=0.064, lo_com=[0.0, 0.0, -0.061], lo_I=[0.000245, 0.000248, 0.000006], hip_z=0.0,
+                        up_com=[0.0, 0.016, -0.02], shank_r=0.012, shank_at=0.02)
+
+
 def mini_cheetah(**over):
     """robots/mini_cheetah.py constants + MIT mini-cheetah published inertial figures.  over: as in laikago()."""
     return _build(**dict(dict(

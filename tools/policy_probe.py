@@ -143,6 +143,8 @@ def run(pol, clip, robot, n, seed, steps=600, ref_state_init_prob=None, model_ov
     out = {"policy": pol, "clip": clip, "robot": robot, "robots": n, "seed": seed,
            "ref_state_init_prob": float(env.cfg.ref_state_init_prob),
            "finished": float(al.mean()), "len": float(ln.mean()), "reward_per_step": float((ret / L).mean()),
+           # J of tools/identify_r6.py: the episode return (rewards until the first failure) per NOMINAL step - what PPO maximised
+           "return_per_nominal_step": float((ret / float(steps)).mean()),
            "terms": {k: float(tm[:, i].mean()) for i, k in enumerate(("pose", "velocity", "end_effector", "root_pose", "root_velocity"))},
            "terms_finishers": {k: (float(tm[al, i].mean()) if al.any() else None)
                                for i, k in enumerate(("pose", "velocity", "end_effector", "root_pose", "root_velocity"))},
