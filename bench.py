@@ -355,7 +355,7 @@ def main():
             tag += "_wpe2"          # the reverse (a small batch forced onto the two-wave kernel): the committed counters of this config are another kernel's
         lib_hash = env.L.orr_source_hash().decode()
         pmc_stale, pmc_seen = None, []
-        for rnd in ("r05", "r04", "r03", "r02"):
+        for rnd in ("r06", "r05", "r04", "r03", "r02"):
             name = "%s_%s_pmc_summary.json" % (rnd, tag)
             pmc = os.path.join(ROOT, "profiles", name)
             if not os.path.exists(pmc) or n != CONFIGS[args.config][1]:
@@ -396,7 +396,7 @@ def main():
                          "frac_of_lone_wave_ceiling": (ipw * per_simd * 4.0 / kcyc) if resident == 1 else None,
                          "frac_of_simd_peak": ipw * per_simd * 2.0 / kcyc,
                          "tail_frac": None}
-                for rnd2 in ("r05", "r04", "r03", "r02"):
+                for rnd2 in ("r06", "r05", "r04", "r03", "r02"):
                     tl = os.path.join(ROOT, "profiles", "%s_wave_timeline.txt" % rnd2)
                     if args.config == "laikago4096" and not args.no_randomizer and os.path.exists(tl):
                         rows = {m.group(1).strip(): float(m.group(2)) for m in (re.match(r"^(.*\S)\s+([0-9.]+)$", ln.rstrip()) for ln in open(tl)) if m}
@@ -434,6 +434,11 @@ def main():
             "dist": dist_info,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         # the waste ratios, hoisted: counter traffic over the algorithmic bytes of the built layout / of SURVEY 8(d)'s figure
+                         # (> 1 = re-reads and spills), and the share of wave cycles spent waiting (SQ_WAIT_ANY / SQ_WAVE_CYCLES)
+                         "traffic_over_alg": (traffic / (b_alg * n)) if traffic else None,
+                         "traffic_over_alg_survey": (traffic / (b_survey * n)) if traffic else None,
+                         "wait_any_frac": valu.get("wait_any_frac_of_wave_cycles") if valu else None,
                          # the same with SURVEY.md section 8(d)'s per-unit figure instead of the built layout's
                          "alg_bytes_survey": b_survey, "achieved_survey": achieved_survey, "frac_survey": achieved_survey / HBM_PEAK_GBS,
                          # THE BOUND THAT BINDS (valu_issue below, hoisted): share of a lone wave's VALU issue ceiling (one instruction per

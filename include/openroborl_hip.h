@@ -35,7 +35,7 @@ extern "C" {
 #define ORR_NUM_TAR_FRAMES 4
 #define ORR_TARGET_DIM (ORR_NUM_TAR_FRAMES * ORR_POSE_DIM) /* imitation_task.py:254-301 */
 #define ORR_OBS_DIM (ORR_PROPRIO_DIM + ORR_TARGET_DIM)     /* 160, wrapper_env.py:109-125 */
-#define ORR_MAX_ROBOT_TYPES 4
+#define ORR_MAX_ROBOT_TYPES 32 /* slots of the device model table (a batch may mix that many tables: heterogeneous batches, table sweeps) */
 #define ORR_MAX_CLIPS 16
 #define ORR_MAX_FALL_PROXIES 16
 #define ORR_RING_DEPTH 44   /* latency <= 0.04 s -> int(0.04/0.001)+1 = 41 entries needed      */
@@ -43,8 +43,9 @@ extern "C" {
 
 /* ---------------------------------------------------------------------------------------
  * Per-robot state record: ORR_STATE_STRIDE 32-bit words, one record per robot, records
- * contiguous ([N, ORR_STATE_STRIDE] tensor).  One wavefront owns one record: lane k loads
- * word k, k+64, ... (coalesced).  X(name, words, kind) with kind F = float32, I = int32.
+ * contiguous ([N, ORR_STATE_STRIDE] tensor).  A 16-lane group (a quarter of a wavefront: four
+ * robots per wave) owns one record: lane k moves words k, k+16, ... in 16-byte pieces
+ * (coalesced).  X(name, words, kind) with kind F = float32, I = int32.
  * Reference provenance of every group: SURVEY.md Appendix A.1.
  * ------------------------------------------------------------------------------------- */
 #define ORR_STATE_FIELDS(X)                                                                   \
@@ -95,6 +96,7 @@ enum orr_state_offset_e {
       ORR_STATE_WORDS
 };
 #define ORR_STATE_STRIDE 1216 /* ORR_STATE_WORDS rounded up to a multiple of 64 (19 x 64) */
+typedef char orr_state_words_fit_the_stride[(ORR_STATE_WORDS <= ORR_STATE_STRIDE) ? 1 : -1]; /* C99 static assertion */
 
 /* done reasons (bit mask) */
 #define ORR_DONE_CONTACT_FALL 1 /* imitation_task.py:536-546 */

@@ -8,7 +8,7 @@ VEL_DIM = 18
 PROPRIO_DIM = 84
 TARGET_DIM = 76
 OBS_DIM = 160
-MAX_ROBOT_TYPES = 4
+MAX_ROBOT_TYPES = 32
 MAX_CLIPS = 16
 MAX_FALL_PROXIES = 16
 RING_DEPTH = 44

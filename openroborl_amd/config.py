@@ -24,13 +24,14 @@ ACTION_REPEAT = 33          # laikago.py:26, mini_cheetah.py:26 NUM_ACTION_REPEA
 CTRL_LATENCY = 0.002        # laikago.py:27
 
 
-# Solver constants PyBullet is REMEMBERED to set in place of the Bullet library's defaults (PhysicsServerCommandProcessor::
-# createEmptyDynamicsWorld: m_erp2 = 0.08, m_warmstartingFactor = 0.1, m_frictionERP = 0.2; btCollisionDispatcher's default
-# CD_USE_RELATIVE_CONTACT_BREAKING_THRESHOLD: 0.02 x the shape's bounding radius, i.e. ~1 mm for a toe sphere and a few mm for a link).
-# A recollection of Bullet's public source, not verifiable in this environment: NOT the shipped defaults (make_config keeps the library
-# values), offered as a named set of orr_config overrides - VecQuadrupedEnv(config_overrides=config.PYBULLET_REMEMBERED) - for whoever can
-# check them.  What is known here: the Laikago policies do not care (round 4's sweep, round 5's ablation); the mini-cheetah's termination
-# does care about the margin.
+# Solver constants.  PYBULLET_REMEMBERED = what PyBullet is REMEMBERED to set in place of the Bullet library's defaults
+# (PhysicsServerCommandProcessor::createEmptyDynamicsWorld: m_erp2 = 0.08, m_warmstartingFactor = 0.1, m_frictionERP = 0.2; the contact
+# breaking threshold is 0.02 x the shape's bounding radius, btCollisionShape::getContactBreakingThreshold, i.e. ~0.5 mm for a toe sphere and a few mm
+# for a link: one 4 mm margin stands for both here).  A recollection of Bullet's public source, not verifiable in this environment.
+# Rounds 1-5 shipped BULLET_LIBRARY_DEFAULTS.  Round 6 ADOPTED the remembered set as make_config's defaults by a cross-robot rule fixed
+# before the run (tools/identify_r6.py P5; profiles/r06_constants_rule.json): preferred on each robot's policies (Laikago mean J 0.565 vs
+# 0.560, minicheetah_trot J 0.648 vs 0.611 and F 0.947 vs 0.893) and costing the OTHER robot's policies nothing (no policy loses 0.02 in F or
+# J).  The library set stays available: VecQuadrupedEnv(config_overrides=config.BULLET_LIBRARY_DEFAULTS).
 BULLET_LIBRARY_DEFAULTS = {"contact_erp": 0.2, "warmstart_factor": 0.85, "friction_erp": 0.2, "contact_margin": 0.02}
 PYBULLET_REMEMBERED = {"contact_erp": 0.08, "warmstart_factor": 0.1, "friction_erp": 0.2, "contact_margin": 0.004}
 
@@ -84,14 +85,14 @@ def make_config(num_robots, sim_params=None, mode="train", enable_randomizer=Non
     c.flags = ((_abi.FLAG_AUTO_RESET if auto_reset else 0) | (_abi.FLAG_RANDOMIZER if enable_randomizer else 0) |
                _abi.FLAG_CYCLE_SYNC | (_abi.FLAG_LEGACY_GRID if legacy_grid else 0) |
                (_abi.FLAG_CURRICULUM if curriculum else 0))
-    c.contact_erp = 0.2
-    c.contact_margin = 0.02
-    c.warmstart_factor = 0.85
+    c.contact_erp = PYBULLET_REMEMBERED["contact_erp"]
+    c.contact_margin = PYBULLET_REMEMBERED["contact_margin"]
+    c.warmstart_factor = PYBULLET_REMEMBERED["warmstart_factor"]
     c.max_coord_velocity = 100.0
     c.plane_friction = 1.0
     c.limit_activation = 0.1
     c.max_angle_change = 0.2                                          # laikago.py:71
     c.dist_fail_threshold = 1.0                                       # imitation_task.py:518
     c.rot_fail_threshold = 0.5 * math.pi
-    c.friction_erp = 0.2
+    c.friction_erp = PYBULLET_REMEMBERED["friction_erp"]
     return c

@@ -22,26 +22,13 @@
 // by another lane's ds_read of the same word needs no s_waitcnt and no s_barrier -- only the COMPILER must not move
 // memory operations across the hand-off.  (A workgroup-scope release/acquire fence also works but makes the wave
 // drain vmcnt, i.e. wait for the latency-ring store to reach memory, ten times per sub-step.)
-#ifdef ORR_FENCE_SYNC
-#define WSYNC()                                           \
-  do {                                                    \
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); \
-    __builtin_amdgcn_wave_barrier();                      \
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); \
-  } while (0)
-#else
 #define WSYNC()                             \
   do {                                      \
     asm volatile("" ::: "memory");          \
     __builtin_amdgcn_wave_barrier();        \
     asm volatile("" ::: "memory");          \
   } while (0)
-#endif
-#ifdef ORR_SCHED_FENCE
-#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-#else
 #define SCHED_FENCE()  // measured: fencing the scheduler RAISES spills (104 vs 0 at 256 VGPRs); kept for experiments
-#endif
 
 namespace orr {
 
@@ -222,12 +209,6 @@ union PhaseBuf {
   StepEndBuf end;
 };
 
-#ifndef ORR_ROW_SOLVE
-#define ORR_ROW_SOLVE 0
-#endif
-#ifndef ORR_LDS_PAD_WORDS
-#define ORR_LDS_PAD_WORDS 0     // multiple of 4
-#endif
 struct alignas(16) Shared {
   alignas(16) float s[kHead];  // state head (float / int bit patterns)
   alignas(16) ModelHot m;      // robot model (hot part)
@@ -235,16 +216,10 @@ struct alignas(16) Shared {
   LegSolve leg[4];
   alignas(16) float tdump[8];  // where the part-3 lanes (which own no joint) put their "column of T" (leg_dynamics)
   alignas(16) float Rb[9];     // kinematic base frame -> world
-#if !ORR_ROW_SOLVE
-  alignas(16) float IA0inv[36];  // inverse of the base's effective 6x6 inertia (world axes, about the base COM)
-#endif
   alignas(16) float tau[16];   // joint torques (internal sign convention), joint order; 12..15: dump slots of the lanes that own no motor
   alignas(16) float ustar[24];
   alignas(16) float co[20];    // control (latency-delayed) observation
   alignas(16) PhaseBuf ph;
-#if ORR_LDS_PAD_WORDS > 0
-  alignas(16) float lds_pad_[ORR_LDS_PAD_WORDS];   // bank phase between the images of neighbouring robots (see the note at ORR_LDS_PAD_WORDS)
-#endif
 #ifdef ORR_PHASE_TIMERS
   long long pt_acc[kPhaseSlots], pt_last, pt_t0, pt_r0;  // development aid, see PT() in orr_kernels.hip
 #endif
@@ -415,16 +390,9 @@ __device__ __forceinline__ float bcast_lane(float x, int sub) {
     const int a = __builtin_amdgcn_readlane(v, R), b = __builtin_amdgcn_readlane(v, R + 32);
     return __int_as_float(sub ? b : a);
   }
-#ifndef ORR_READLANE_BCAST
   // old = 0 with bound_ctrl (every source lane of a row_newbcast is valid, so neither matters): the form the compiler's DPP
   // combiner folds into the consuming VOP2 (v_mul_f32_dpp / v_fmac_f32_dpp / v_max_f32_dpp ...) instead of a separate v_mov_b32_dpp
   return __int_as_float(__builtin_amdgcn_update_dpp(0, v, 0x150 + R, 0xF, 0xF, true));
-#else
-  const int a0 = __builtin_amdgcn_readlane(v, R), a1 = __builtin_amdgcn_readlane(v, R + 16);
-  const int a2 = __builtin_amdgcn_readlane(v, R + 32), a3 = __builtin_amdgcn_readlane(v, R + 48);
-  const int lo = (sub & 1) ? a1 : a0, hi = (sub & 1) ? a3 : a2;
-  return __int_as_float((sub & 2) ? hi : lo);
-#endif
 }
 // sum_k x_k(lane R of this robot) * w_k(own lane), k < 9: the broadcast rides as the DPP operand of the multiply-adds
 // (v_fmac_f32_dpp ... row_newbcast:R; the compiler's DPP combiner only folds v_mov_b32_dpp into v_mul, not into v_fmac).
@@ -511,11 +479,8 @@ __device__ __forceinline__ float bcast_row(float x, int r, int sub) {
 
 // sine / cosine of a joint angle (|a| is a few radians at most).  Cody-Waite reduction to [-pi/4, pi/4] with a
 // two-part pi/2 and minimax polynomials (~25 instructions, error < 1e-7, no large-argument branch): +2.3 % env steps/s
-// over libm's sincosf (-DORR_LIBM_TRIG) at unchanged parity tolerances.
+// over libm's sincosf at unchanged parity tolerances.
 __device__ __forceinline__ void joint_sincos(float a, float* sn, float* cs) {
-#ifdef ORR_LIBM_TRIG
-  sincosf(a, sn, cs);
-#else
   const float k = rintf(a * 0.63661977236758134f);       // a * 2/pi
   float r = fmaf(-k, 1.57079625129699707031f, a);         // pi/2 high part (exact in float)
   r = fmaf(-k, 7.54978941586159635335e-08f, r);           // pi/2 low part
@@ -532,20 +497,16 @@ __device__ __forceinline__ void joint_sincos(float a, float* sn, float* cs) {
   const float ss = (q & 1) ? c : s, cc = (q & 1) ? s : c;
   *sn = (q & 2) ? -ss : ss;
   *cs = ((q + 1) & 2) ? -cc : cc;
-#endif
 }
 
 // Inverse trigonometric functions without branches (libm's atan2f / asinf / acosf cost a lone wave several taken or skipped
 // branches each, 13-30 ticks apiece: profiles/r02_issue_costs.txt).  atan2: octant reduction to t = min / max in [0, 1], then the
 // Cephes atanf kernel on [0, tan(pi/8)] (t -> (t - 1) / (t + 1) above it); absolute error < 3e-7 (checked against float64 on 2 M
-// random arguments).  -DORR_LIBM_TRIG switches back to libm.
+// random arguments).
 // NaN arguments come out FINITE (fmax / fmin and the selects drop NaNs): non-finite numbers
 // are detected in ONE place, the |state| < 1e30 sweep + reward check at the end of the step (ORR_DONE_NAN, orr_kernels.hip), never through
 // these functions (tests/test_gpu_parity.py::test_non_finite_state_is_caught_by_the_state_guard).
 __device__ __forceinline__ float atan2_bf(float y, float x) {
-#ifdef ORR_LIBM_TRIG
-  return atan2f(y, x);
-#else
   const float ax = fabsf(x), ay = fabsf(y);
   const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
   const float t = mx > 0.0f ? mn * __builtin_amdgcn_rcpf(mx) : 0.0f;
@@ -561,21 +522,12 @@ __device__ __forceinline__ float atan2_bf(float y, float x) {
   // quadrant by the SIGN BITS, like libm: atan2(0, -0.0) = pi and atan2(-0.0, -1) = -pi (a comparison with 0.0f treats -0.0 as positive)
   r = __float_as_int(x) < 0 ? 3.14159265358979324f - r : r;
   return __float_as_int(y) < 0 ? -r : r;
-#endif
 }
 __device__ __forceinline__ float asin_bf(float x) {   // |x| <= 1
-#ifdef ORR_LIBM_TRIG
-  return asinf(x);
-#else
   return atan2_bf(x, __builtin_amdgcn_sqrtf(fmaxf((1.0f - x) * (1.0f + x), 0.0f)));
-#endif
 }
 __device__ __forceinline__ float acos_bf(float x) {   // |x| <= 1
-#ifdef ORR_LIBM_TRIG
-  return acosf(x);
-#else
   return atan2_bf(__builtin_amdgcn_sqrtf(fmaxf((1.0f - x) * (1.0f + x), 0.0f)), x);
-#endif
 }
 
 // transformations.quaternion_multiply(a, b): Hamilton product (pose3d.py:228-230)

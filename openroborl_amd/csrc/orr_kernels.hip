@@ -29,10 +29,7 @@
 // The constraint rows need A0^-1 (Jb - T_L jl): every row lane solves with the Cholesky factor of A0, which stays in registers (15 entries + 6 reciprocal pivots, Chol6Pk) from
 // the leg dynamics on (-54 instructions per sub-step there: no unit-column solve, no A0^-1 through LDS; +15 per bank in the row
 // response).  4096 robots 0.2338 -> 0.2295 ms; the two-wave unit (256 registers, spilling) is neutral (8192 robots 0.3265 vs 0.3255 ms)
-// and takes it too, so that both variants of the kernel keep giving the same bits.  ORR_ROW_SOLVE=0: the explicit inverse in LDS.
-#ifndef ORR_ROW_SOLVE
-#define ORR_ROW_SOLVE 1
-#endif
+// and takes it too, so that both variants of the kernel keep giving the same bits.
 #include "orr_device.h"
 
 // Development aid (tools/phase_cycles.py): -DORR_PHASE_TIMERS makes lane 0 of one wave accumulate shader-clock cycles
@@ -113,7 +110,9 @@ __global__ __launch_bounds__(64) void orr_reset_kernel(KParams P, const uint8_t*
   reset_robot(P, rec, S, lane, valid, total, obs, uniforms ? uniforms + (size_t)robot * 28 : nullptr);
   WSYNC();
   store_robot(rec, S, lane, valid);
-  if (P.anchor_on && valid)   // a new episode: no cached contact points (ANCHOR, ANCHOR_VALID: 28 words behind the ring)
+  // a new episode: no cached contact points (ANCHOR, ANCHOR_VALID: 28 words behind the ring).  Unconditional: friction anchors may be switched
+  // on (orr_set_model) after this reset, and a caller-bound record need not have been zeroed
+  if (valid)
     for (int i = lane; i < ORR_OFFEND_ANCHOR_VALID - ORR_OFF_ANCHOR + 1; i += kLanes) rec[O(ANCHOR) + i] = 0.0f;
   if (obs_out && valid)
     for (int i = lane; i < ORR_OBS_DIM; i += kLanes) obs_out[(size_t)robot * ORR_OBS_DIM + i] = obs[i];
@@ -180,6 +179,7 @@ __global__ __launch_bounds__((MODE == 0 && WPE == 1 ? 64 * ORR_WPB : 64)) __attr
   bool anchor_robot = false;
   const int aleg = lane < 4 ? lane : (lane < 8 ? lane - 4 : (lane - 8) >> 1);   // leg of the lane's bank-A row (knee, normal, friction)
   if constexpr (ANCHOR) {
+    static_assert(kLanes == 16, "ANCHOR: aleg indexes the record's four cached points by the 16-lane row layout");
     anchor_robot = model_cold(P, geti(S, O(ROBOT_TYPE)))->friction_anchor != 0;
     const float* an = rec + O(ANCHOR) + 6 * aleg;
     AS.la[0] = an[0]; AS.la[1] = an[1]; AS.la[2] = an[2]; AS.wb[0] = an[3]; AS.wb[1] = an[4]; AS.wb[2] = an[5];
@@ -265,14 +265,13 @@ __global__ __launch_bounds__((MODE == 0 && WPE == 1 ? 64 * ORR_WPB : 64)) __attr
   OwnCoord X;
   load_own_coord(S, lane, X);
   int limit_idle = 0;      // see physics_substep
-#ifndef ORR_NO_PRIO_ALTERNATION
   // Two waves per SIMD: VALU issue is arbitrated by priority, then AGE - the older wave of a SIMD runs nearly unimpeded, the younger on
   // the leftover slots, and when the older one has finished the younger runs on alone at a lone wave's pace (half the SIMD idle).  The
   // two waves of a SIMD come from consecutive dispatch rounds (workgroup b: round b / #SIMDs), so raising the priority of the even rounds
   // in even sub-steps and of the odd rounds in odd sub-steps lets them take turns at being the favoured one and finish together.
   // 8192 robots: 0.349 -> 0.331 ms (-5.3 %, round 3; turns of 2 or 4 sub-steps or a second flip in the middle of a sub-step were no
   // better then: 0.332 / 0.332 / 0.335).  Round 4, final code: turns of FOUR sub-steps 0.3015 -> 0.2991 ms (2: 0.2995, 8 / 16: 0.3032 /
-  // 0.3027; without the alternation 0.317; tools/build_variants.py: -DORR_PRIO_TURN=n, -DORR_NO_PRIO_ALTERNATION).
+  // 0.3027; without the alternation 0.317; profiles/r04_ab25..28_8192.log).
   const int prio_phase = WPE == 2 ? (int)(((unsigned)wave_id / (unsigned)(P.simds > 0 ? P.simds : 1)) & 1u) : 0;
   // Taking turns pairs the dispatch rounds (0, 1), (2, 3) ...: with an ODD number of rounds the last one has no partner of its own, and the
   // plain age order - the oldest wave of a SIMD runs at nearly a lone wave's pace, the next one moves up when it ends - is the better
@@ -280,10 +279,9 @@ __global__ __launch_bounds__((MODE == 0 && WPE == 1 ? 64 * ORR_WPB : 64)) __attr
   // them against 0.5847 / 1.109 without; profiles/r04_ab34_large.log)
   const bool prio_turns = WPE == 2 && ((((unsigned)gridDim.x * (unsigned)step_wpb<MODE, WPE>() + (unsigned)(P.simds > 0 ? P.simds : 1) - 1u) /
                                         (unsigned)(P.simds > 0 ? P.simds : 1)) & 1u) == 0u;
-#endif
   // What the PD law of a sub-step reads - the delayed angle of the lane's motor (control observation), the joint's true angle and rate -
   // is produced at the END of the previous sub-step: the control-observation word by this very lane, angle and rate by the integration
-  // (read from LDS there anyway, for the ring entry).  Carried over in registers (ORR_CARRY_PD), the top of the loop has no LDS round
+  // (read from LDS there anyway, for the ring entry).  Carried over in registers, the top of the loop has no LDS round
   // trip of its own: a lone wave has nothing to overlap one with there.  Same values, bit for bit.  4096 robots 0.2235 -> 0.2205 ms.
   // The two-wave build lost 1 % with it when it was introduced (8192 robots 0.3130 -> 0.3160 ms: three more registers across the sub-step)
   // and takes it since the end of round 4: a wave pair runs 1.33 x the LONE time of its build whatever the scheduling (DESIGN.md section
@@ -291,30 +289,19 @@ __global__ __launch_bounds__((MODE == 0 && WPE == 1 ? 64 * ORR_WPB : 64)) __attr
   // carrying the base rotation the same way (nine words that leg_dynamics reads back from LDS: 0.2206, neutral), and issuing the loads
   // of the leg dynamics' first reads (base rotation / velocity, own joint angle, the leg's joint rates: 19 registers) in front of the
   // PD law (0.2208 -> 0.2223: worse).
-#ifndef ORR_CARRY_PD
-#define ORR_CARRY_PD 1
-#endif
   float co_own = S.co[ml], qm_c = (S.s[O(Q) + mj] - m_off) * m_dir, qdm_c = S.s[O(QD) + mj] * m_dir;
   for (int sstep = 0; sstep < c.action_repeat; sstep++) {
-#ifndef ORR_NO_PRIO_ALTERNATION
-#ifndef ORR_PRIO_TURN
-#define ORR_PRIO_TURN 4       // favoured for ORR_PRIO_TURN sub-steps at a time (measured: tools/ab_variants.sh, profiles/r04_ab25..28_8192.log)
-#endif
-#ifndef ORR_PRIO_HI
-#define ORR_PRIO_HI 1
-#endif
-#ifndef ORR_PRIO_OFFSET
-#define ORR_PRIO_OFFSET 1     // the turns start one sub-step early: the younger wave of a SIMD leads with a turn of three and has the last two sub-steps
-#endif                        // (8192 robots 0.3012 -> 0.2998 ms; offsets 2 / 3 / 4 (= the older wave leads): 0.3030 / 0.3042 / 0.3046; equal priority for the
-#ifndef ORR_PRIO_EQUAL_FROM   // last 4 / 8 sub-steps: 0.3026 / 0.3014; profiles/r04_ab30_8192.log)
-#define ORR_PRIO_EQUAL_FROM 1000
-#endif
-    if (WPE == 2 && prio_turns) { if (sstep < ORR_PRIO_EQUAL_FROM && ((((sstep + ORR_PRIO_OFFSET) / ORR_PRIO_TURN) ^ prio_phase) & 1)) __builtin_amdgcn_s_setprio(ORR_PRIO_HI); else __builtin_amdgcn_s_setprio(0); }
-#endif
+    // priority turns of the two-wave variant (measured: profiles/r04_ab25..30_8192.log): a wave is favoured for kPrioTurn sub-steps at a time; the turns
+    // start kPrioOffset sub-steps early, i.e. the younger wave of a SIMD leads with a turn of three and has the last two sub-steps (8192 robots
+    // 0.3012 -> 0.2998 ms; offsets 2 / 3 / 4 (= the older wave leads): 0.3030 / 0.3042 / 0.3046; equal priority for the last 4 / 8 sub-steps:
+    // 0.3026 / 0.3014, not kept).  kPrioEqualFrom: equal priority from that sub-step on; 1000 = never (action_repeat is 33), the comparison
+    // stays so that the unit's code is the measured one
+    constexpr int kPrioTurn = 4, kPrioHi = 1, kPrioOffset = 1, kPrioEqualFrom = 1000;
+    if (WPE == 2 && prio_turns) { if (sstep < kPrioEqualFrom && ((((sstep + kPrioOffset) / kPrioTurn) ^ prio_phase) & 1)) __builtin_amdgcn_s_setprio(kPrioHi); else __builtin_amdgcn_s_setprio(0); }
     if (kLanes != 16 && sstep > 0) ctrl_obs(P, rec, S, lane);
     {  // every lane (no divergent `if`: it would cost more than it skips); lanes 12..15 repeat motor 0 and store into dump slots
       const float lerp = (float)(sstep + 1) * inv_repeat;  // process_action (minitaur.py:438-460)
-      const bool carry = ORR_CARRY_PD && kLanes == 16;
+      const bool carry = kLanes == 16;
       const float cur = map_pi(carry ? co_own : S.co[ml]);
       const float prev = m_has_prev ? m_prev : cur;
       float cmd = prev + lerp * (m_target - prev);
@@ -348,10 +335,9 @@ __global__ __launch_bounds__((MODE == 0 && WPE == 1 ? 64 * ORR_WPB : 64)) __attr
     }
     PT(10);
   }
-#ifndef ORR_PRIO_TAIL
-#define ORR_PRIO_TAIL 3       // past its sub-step loop (reward, observation, reset, store: few vector instructions between long memory waits) a wave
-#endif                        // issues ahead of its partner: it costs the partner next to nothing and shortens the tail (8192 robots: -0.1 %;
-  if (WPE == 2 && ORR_PRIO_TAIL >= 0) __builtin_amdgcn_s_setprio(ORR_PRIO_TAIL);   // with -Os for this unit -0.4 %, profiles/r04_ab29_8192.log)
+  // past its sub-step loop (reward, observation, reset, store: few vector instructions between long memory waits) a wave issues ahead of its
+  // partner: it costs the partner next to nothing and shortens the tail (8192 robots: -0.1 %; with -Os for this unit -0.4 %, profiles/r04_ab29_8192.log)
+  if (WPE == 2) __builtin_amdgcn_s_setprio(3);
   if (lane == 0) {  // end of robot_step (minitaur.py:287-293)
     if (kLanes == 16) { seti(S, O(RING_HEAD), ring.head); seti(S, O(RING_LEN), ring.len); }
     seti(S, O(STATE_ACTION_COUNTER), action_counter);
@@ -598,7 +584,7 @@ struct orr_handle {
   orr_config cfg;
   int simds;          // SIMDs of the device (4 per CU): a batch of more waves than that runs the two-waves-per-SIMD variant of the step kernel
   int force_wpe;      // ORR_STEP_WAVES_PER_EU (0 = automatic)
-  int anchor_types;   // bit t = robot type t has orr_model::friction_anchor: launches run the ANCHOR variant of the step kernel
+  uint32_t anchor_types;   // bit t = robot type t has orr_model::friction_anchor: launches run the ANCHOR variant of the step kernel
   DevTables* tab_dev;
   DevTables tab_host;
   float fb[3], fa[3];
@@ -723,7 +709,8 @@ int32_t orr_set_model(orr_handle* h, int32_t robot_type, const orr_model* m) {
   for (int i = 0; i < m->num_fall_proxies; i++)
     if (m->fall_body[i] < 0 || m->fall_body[i] > 12) return fail(-1, "orr_set_model: fall_body out of range");
   // every joint must turn about a coordinate axis of the kinematic frame: hip about +-x, upper / lower leg about +-y
-  DevModel& d = h->tab_host.model[robot_type];
+  // built in a local entry: a rejected model leaves the handle (host table, device table, anchor bit) exactly as it was
+  DevModel d;
   memset(&d, 0, sizeof(d));
   float axsgn[12];
   for (int j = 0; j < 12; j++) {
@@ -768,7 +755,6 @@ int32_t orr_set_model(orr_handle* h, int32_t robot_type, const orr_model* m) {
   H.shank_radius = m->shank_radius;
   Cd.foot_friction = m->foot_friction;
   Cd.friction_anchor = m->friction_anchor != 0;
-  if (m->friction_anchor) h->anchor_types |= 1 << robot_type; else h->anchor_types &= ~(1 << robot_type);
   if (m->friction_anchor && !(h->cfg.friction_erp >= 0.0f && h->cfg.friction_erp <= 1.0f)) return fail(-1, "orr_set_model: friction_anchor needs 0 <= orr_config::friction_erp <= 1");
   Cd.num_fall = m->num_fall_proxies;
   if (m->contact_stiffness > 0.0f) {
@@ -795,6 +781,8 @@ int32_t orr_set_model(orr_handle* h, int32_t robot_type, const orr_model* m) {
     for (int k = 0; k < 6; k++) { Cd.inertia[j + 1][k] = m->link_inertia[j][k]; Cd.inertia_pa[j + 1][k] = m->link_inertia_pa[j][k]; }
   }
   HIPCHK(hipMemcpy(&h->tab_dev->model[robot_type], &d, sizeof(DevModel), hipMemcpyHostToDevice), "orr_set_model: hipMemcpy");
+  h->tab_host.model[robot_type] = d;
+  if (m->friction_anchor) h->anchor_types |= 1u << robot_type; else h->anchor_types &= ~(1u << robot_type);
   return 0;
 }
 

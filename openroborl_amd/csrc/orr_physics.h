@@ -47,12 +47,9 @@ __device__ __forceinline__ void chol6_solve(const float L[21], const float invdi
 // The factor is kept by COLUMNS with the rows below the diagonal paired (2,3) and (4,5): a rank-1 update of the trailing columns and a
 // forward substitution step then work on whole pairs with the scalar factor as an op_sel broadcast.  Every entry sees the operations of
 // chol6 / chol6_solve in the same order (the sums run over k ascending either way; the backward substitution stays scalar: by columns it
-// would subtract in descending order), each step ONE fused multiply-add.  ORR_CHOL_PK: 0 = scalar code above, 1 = packed factorisation
-// and solves, 2 = also the column of T, the elimination terms -T_k F_k^T / T_k b_k and the 16-lane sums in that layout (leg_dynamics).
+// would subtract in descending order), each step ONE fused multiply-add.  Packed: the factorisation
+// and the solves, and also the column of T, the elimination terms -T_k F_k^T / T_k b_k and the 16-lane sums in that layout (leg_dynamics).
 // 4096 robots 0.2187 -> 0.2164 ms, 8192 robots 0.3033 -> 0.3005 ms (interleaved A/B, profiles/r04_ab17_*.log).
-#ifndef ORR_CHOL_PK
-#define ORR_CHOL_PK 2
-#endif
 typedef float pk2 __attribute__((ext_vector_type(2)));
 // c - a * s and c - a * b as ONE fused operation per component (v_pk_fma_f32; the scalar rides as an op_sel broadcast).  Spelled out, not
 // left to the compiler's contraction of `c - a * s`: in the row solves it kept some of those as v_pk_mul + v_pk_add, i.e. other bits
@@ -136,16 +133,18 @@ __device__ __forceinline__ void chol6_solve_pk(const Chol6Pk& F, float b0, float
 // hide the LDS round trips of re-reading them every sub-step).  Lane (leg = lane & 3, part = (lane >> 2) & 3) walks the
 // joints 0..min(part, 2) of its leg and owns link `part` (part 3: an idle copy with zero inertia): the chain constants of
 // the joints beyond its own are zeroed, so that walking "through" them is the identity.
+// Two choices differ between the translation units (orr_kernels.hip: why there are several); they are properties of the unit, not -D knobs:
+//   kCarrySubtreeMass  the subtree mass lives in a register across the launch in the one-wave build only: the 256-register build pays more
+//                      for the live register than for the two adds that rebuild it every sub-step
+//   kOwnLegFactor      row_response's variant (b), see there: four more live registers cost the two-wave unit 30 spilled ones
+#ifdef ORR_TU_STEP_W2
+constexpr bool kCarrySubtreeMass = false, kOwnLegFactor = false;
+#else
+constexpr bool kCarrySubtreeMass = true, kOwnLegFactor = true;
+#endif
 struct LegConst {
   float r[3][3], jdir[3], joff[3];  // chain: joint origin in the parent frame, internal angle = jdir * (q - joff)
   float com[3], m, Ic[6];           // own link: COM in the link frame, mass, inertia about the COM (xx yy zz xy xz yz)
-#ifndef ORR_MSUB          // carried in a register by the one-wave build only: the 256-register build pays more for the live register than for the two adds
-#ifdef ORR_TU_STEP_W2
-#define ORR_MSUB 0
-#else
-#define ORR_MSUB 1
-#endif
-#endif
   float msub;                       // mass of the subtree behind the own joint (own + later links of the leg): constant over a launch
   float damp_l, damp_a;             // Bullet base damping coefficients in the lane that owns the base body, 0 elsewhere
   float jdir_own, joff_own;         // the lane's own joint (part < 3; jdir 0 for part 3): scalars, NOT selects over jdir[] / joff[] --
@@ -192,9 +191,7 @@ __device__ static void load_leg_const(const KParams& P, const Shared& S, int lan
 #pragma unroll
     for (int i = 0; i < 6; i++) K.Ic[i] = (real || base) ? mc->inertia[body][i] * ir + mc->inertia_pa[body][i] * mr : 0.0f;
     K.m = (real || base) ? mass : 0.0f;
-#if ORR_MSUB
-    K.msub = part_suffix_sum(K.m);
-#endif
+    if (kCarrySubtreeMass) K.msub = part_suffix_sum(K.m);
   }
   K.jdir_own = real ? S.m.jdir[own] : 0.0f;
   K.joff_own = S.m.joff[own];
@@ -258,12 +255,6 @@ __device__ __forceinline__ void spatial_inertia_mul(const float I[6], const floa
 // one joint on the way down the leg: pose of the link behind it, its motion axis S = (s; d x s) about O, spatial
 // velocity and velocity-product acceleration.  For a joint beyond the lane's own link the constants are zero and the
 // step is the identity (angle 0, rate 0, offset 0).
-#ifndef ORR_JOINT_DOWN_V2
-#define ORR_JOINT_DOWN_V2 1
-#endif
-#ifndef ORR_LD_V3
-#define ORR_LD_V3 1   // round 4, v39: leg dynamics with fewer selects / repeated products (see the spots)
-#endif
 template <int AX, bool SAME_AXIS = false>
 __device__ __forceinline__ void joint_down(const Shared& S, const LegConst& K, int k, int j, float sn, float cs, float Rw[9], float d[3],
                                            float Vw[3], float Vv[3], float Aa[3], float Al[3], float s[3], float sv[3], float& ad_out,
@@ -282,7 +273,6 @@ __device__ __forceinline__ void joint_down(const Shared& S, const LegConst& K, i
   }
   s[0] = Rw[AX]; s[1] = Rw[3 + AX]; s[2] = Rw[6 + AX];
   cross3(d, s, sv);
-#if ORR_JOINT_DOWN_V2
   // A += V x (S ad) = ad (Vw x s ; Vw x sv + Vv x s) with the velocity of the PARENT (the joint's own S ad drops out of the cross
   // products: s x s = 0 and (s ad) x (sv ad) + (sv ad) x (s ad) = 0), then V += S ad: 30 instructions instead of 39 per joint step.
   // 4096 robots 0.2256 -> 0.2236 ms, 8192 robots 0.3158 -> 0.3136 ms (round 4, interleaved A/B).
@@ -290,7 +280,7 @@ __device__ __forceinline__ void joint_down(const Shared& S, const LegConst& K, i
     // SAME_AXIS: the joint's axis is the previous joint's (hip pitch -> knee: both about the link's y, a pure translation between them),
     // so Vw x s = (Vw_prev + qd_prev s) x s = Vw_prev x s: the previous joint's product is taken over (-6 instructions)
     float c0x, c0y, c0z;
-    if (SAME_AXIS && ORR_LD_V3) { c0x = c0[0]; c0y = c0[1]; c0z = c0[2]; }
+    if (SAME_AXIS) { c0x = c0[0]; c0y = c0[1]; c0z = c0[2]; }
     else { c0x = Vw[1] * s[2] - Vw[2] * s[1]; c0y = Vw[2] * s[0] - Vw[0] * s[2]; c0z = Vw[0] * s[1] - Vw[1] * s[0]; }
     if (c0) { c0[0] = c0x; c0[1] = c0y; c0[2] = c0z; }
     const float c1x = fmaf(Vv[1], s[2], fmaf(-Vv[2], s[1], Vw[1] * sv[2] - Vw[2] * sv[1]));
@@ -301,18 +291,6 @@ __device__ __forceinline__ void joint_down(const Shared& S, const LegConst& K, i
 #pragma unroll
     for (int i = 0; i < 3; i++) { Vw[i] = fmaf(ad, s[i], Vw[i]); Vv[i] = fmaf(ad, sv[i], Vv[i]); }
   }
-#else
-  // V += S ad;  A += V x (S ad)
-  const float ga[3] = {s[0] * ad, s[1] * ad, s[2] * ad}, gl[3] = {sv[0] * ad, sv[1] * ad, sv[2] * ad};
-#pragma unroll
-  for (int i = 0; i < 3; i++) { Vw[i] += ga[i]; Vv[i] += gl[i]; }
-  float t0[3], t1[3], t2[3];
-  cross3(Vw, ga, t0);
-  cross3(Vw, gl, t1);
-  cross3(Vv, ga, t2);
-#pragma unroll
-  for (int i = 0; i < 3; i++) { Aa[i] += t0[i]; Al[i] += t1[i] + t2[i]; }
-#endif
 }
 
 // sum of x over the own and the later LINK parts (q..2) of one leg (lane = leg + 4 q): two DPP row shifts, zero beyond the
@@ -325,14 +303,7 @@ __device__ __forceinline__ float part_suffix_sum(float x) {
   return x + a + b;
 }
 
-#ifndef ORR_ROW_SOLVE
-#define ORR_ROW_SOLVE 0     // 1: the rows solve with the Cholesky factor of A0 (kept in registers) instead of multiplying by an explicit A0^-1
-#endif
-#if ORR_CHOL_PK
 struct BaseFactor { Chol6Pk F; };
-#else
-struct BaseFactor { float L[21], idg[6]; };
-#endif
 __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst& K, int lane, BaseFactor& BF) {
   const int leg = lane & 3, part = (lane >> 2) & 3;
   float Rb[9];  // kinematic base frame -> world: kept current by base_rotation() (after every change of the quaternion)
@@ -358,7 +329,6 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
     const float cA = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(cso), 0x114, 0xF, 0xF, true));
     const float sB = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sno), 0x118, 0xF, 0xF, true));  // row_shr:8
     const float cB = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(cso), 0x118, 0xF, 0xF, true));
-#if ORR_LD_V3
     // the selects over `part` as bank-masked DPP moves (a bank = the four lanes of one part): a lane keeps its own value where the mask
     // is off, and a shift from beyond the row writes 0 (bound_ctrl) -- the own values of the part-3 lanes are sin 0 = 0, cos 0 = 1
     //   sn0 / cs0 = [own, shr4, shr8, own]   sn1 = [0 (from beyond the row), own, shr4, own = 0]   cs1 = [1, own, shr4, own = 1]
@@ -370,12 +340,6 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
     cs1 = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(cso), __float_as_int(cso), 0x114, 0xF, 0x4, false));
     cs1 = part == 0 ? 1.0f : cs1;
     (void)sA; (void)cA; (void)sB; (void)cB;
-#else
-    sn0 = part == 0 ? sno : (part == 1 ? sA : (part == 2 ? sB : 0.0f));
-    cs0 = part == 0 ? cso : (part == 1 ? cA : (part == 2 ? cB : 1.0f));
-    sn1 = part == 1 ? sno : (part == 2 ? sA : 0.0f);
-    cs1 = part == 1 ? cso : (part == 2 ? cA : 1.0f);
-#endif
     sn2 = part == 2 ? sno : 0.0f;
     cs2 = part == 2 ? cso : 1.0f;
   }
@@ -387,14 +351,9 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
   float so[3], svo[3];
 #pragma unroll
   for (int i = 0; i < 3; i++) {
-#if ORR_LD_V3
     // the joints behind a lane's own link are identity steps with zero offsets: for a part-1 lane (s2, sv2) ARE (s1, sv1), bit for bit
     so[i] = part == 0 ? s0[i] : (part == 3 ? 0.0f : s2[i]);        // part 3 owns no joint: F, T columns = 0
     svo[i] = part == 0 ? sv0[i] : (part == 3 ? 0.0f : sv2[i]);
-#else
-    so[i] = part == 0 ? s0[i] : (part == 1 ? s1[i] : (part == 2 ? s2[i] : 0.0f));       // part 3 owns no joint: F, T columns = 0
-    svo[i] = part == 0 ? sv0[i] : (part == 1 ? sv1[i] : (part == 2 ? sv2[i] : 0.0f));
-#endif
   }
   const float ado = part == 0 ? ad0 : (part == 1 ? ad1 : ad2);
   {  // pose and joint axis of the own link for the constraint rows (part-3 lanes: dump slot)
@@ -412,10 +371,6 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
     for (int i = 0; i < 3; i++) c[i] = fmaf(Rw[3 * i], K.com[0], fmaf(Rw[3 * i + 1], K.com[1], fmaf(Rw[3 * i + 2], K.com[2], d[i])));
     h[0] = m * c[0]; h[1] = m * c[1]; h[2] = m * c[2];
     rot_sym_full(Rw, K.Ic, I);
-#ifndef ORR_BIAS_COM
-#define ORR_BIAS_COM 1
-#endif
-#if ORR_BIAS_COM
     // Bias force f = I A + V x* (I V) evaluated at the link's COM and shifted to O (round 4: 54 instead of ~80 instructions; the same
     // vector - with L = (Ic w + c x p; p), p = m (v_O + w x c): the cross terms of the spatial form collapse to c x (m a_c + w x p)):
     //   f_lin = m (Al + Aa x c) + w x p,    f_ang = Ic Aa + w x (Ic w) + c x f_lin      (Ic = inertia about the COM, world axes)
@@ -442,19 +397,6 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
     const float hc = h[0] * c[0] + h[1] * c[1] + h[2] * c[2];
     I[0] += hc - h[0] * c[0]; I[1] += hc - h[1] * c[1]; I[2] += hc - h[2] * c[2];
     I[3] -= h[0] * c[1]; I[4] -= h[0] * c[2]; I[5] -= h[1] * c[2];
-#else
-    const float hc = h[0] * c[0] + h[1] * c[1] + h[2] * c[2];
-    I[0] += hc - h[0] * c[0]; I[1] += hc - h[1] * c[1]; I[2] += hc - h[2] * c[2];
-    I[3] -= h[0] * c[1]; I[4] -= h[0] * c[2]; I[5] -= h[1] * c[2];
-    float Pa[3], Pl[3], Fa[3], Fl[3], t0[3], t1[3], t2[3];
-    spatial_inertia_mul(I, h, m, Vw, Vv, Pa, Pl);
-    spatial_inertia_mul(I, h, m, Aa, Al, Fa, Fl);
-    cross3(Vw, Pa, t0);
-    cross3(Vv, Pl, t1);
-    cross3(Vw, Pl, t2);
-#pragma unroll
-    for (int i = 0; i < 3; i++) { f[i] = Fa[i] + t0[i] + t1[i]; f[3 + i] = Fl[i] + t2[i]; }
-#endif
     // force side of the base system: the link's bias force (+ Bullet's base damping on the base body, whose momentum is
     // (Pa, Pl) = (I w, m v): torque k_a I w, force k_l m v; btMultiBody; damp_* are zero in every lane but the base body's, whose COM is O)
 #pragma unroll
@@ -476,11 +418,7 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
   for (int i = 0; i < 6; i++) { I[i] = part_suffix_sum(I[i]); f[i] = part_suffix_sum(f[i]); }
 #pragma unroll
   for (int i = 0; i < 3; i++) h[i] = part_suffix_sum(h[i]);
-#if ORR_LD_V3 && ORR_MSUB
-  m = K.msub;
-#else
-  m = part_suffix_sum(m);
-#endif
+  m = kCarrySubtreeMass ? K.msub : part_suffix_sum(m);
   // own column of F and of the leg's joint-space inertia H (entries H[i][part], i <= part), own bias torque
   float Fo[6], bo;
   {
@@ -501,25 +439,16 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
   WSYNC();
   // ---- every lane of the leg: all three F columns and H ----
   float b[3];
-#if ORR_CHOL_PK >= 2
   pk2 F2[3][3];   // F2[k][p] = (F_k[2p], F_k[2p+1]): the columns of F come out of LDS as aligned pairs
-#else
-  float F[3][6];
-#endif
   float H00, H01, H02, H11, H12, H22;
   {
     const LegExchange& X = S.ph.sub.dyn.legx[leg];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-#if ORR_CHOL_PK >= 2
       static_assert(sizeof(X.F[0]) == 24 && alignof(LegExchange) >= 8, "pairs");
       const pk2* XF = reinterpret_cast<const pk2*>(&X.F[k][0]);
 #pragma unroll
       for (int q = 0; q < 3; q++) F2[k][q] = XF[q];
-#else
-#pragma unroll
-      for (int i = 0; i < 6; i++) F[k][i] = X.F[k][i];
-#endif
       b[k] = X.b[k];
     }
     H00 = X.Hc[0][0]; H01 = X.Hc[1][0]; H11 = X.Hc[1][1]; H02 = X.Hc[2][0]; H12 = X.Hc[2][1]; H22 = X.Hc[2][2];
@@ -536,28 +465,17 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
   const float hq1 = part == 0 ? Hi[3] : (part == 1 ? Hi[1] : (part == 2 ? Hi[5] : 0.0f));
   const float hq2 = part == 0 ? Hi[4] : (part == 1 ? Hi[5] : (part == 2 ? Hi[2] : 0.0f));
   float Tq[6];  // column `part` of T = F H^-1
-#if ORR_CHOL_PK >= 2
   pk2 Tq2[3];
 #pragma unroll
   for (int q = 0; q < 3; q++) { Tq2[q] = F2[0][q] * hq0 + F2[1][q] * hq1 + F2[2][q] * hq2; Tq[2 * q] = Tq2[q].x; Tq[2 * q + 1] = Tq2[q].y; }
-#else
-#pragma unroll
-  for (int i = 0; i < 6; i++) Tq[i] = F[0][i] * hq0 + F[1][i] * hq1 + F[2][i] * hq2;
-#endif
   {  // part-3 lanes: one shared dump slot; H^-1 is the same in all lanes of the leg, every one of them stores it
     LegSolve& Q = S.leg[leg];
     float* const tdst = part < 3 ? &Q.T[part][0] : &S.tdump[0];
-#if ORR_CHOL_PK >= 2
 #pragma unroll
     for (int q = 0; q < 3; q++) reinterpret_cast<pk2*>(tdst)[q] = Tq2[q];
-#else
-#pragma unroll
-    for (int i = 0; i < 6; i++) tdst[i] = Tq[i];
-#endif
 #pragma unroll
     for (int i = 0; i < 6; i++) Q.Hi[i] = Hi[i];
   }
-#if ORR_CHOL_PK >= 2
   // The base matrix is accumulated, summed over the 16 lanes and factorised in ONE layout: the lower triangle by columns with the rows
   // (2,3) and (4,5) paired (Chol6Pk).  Entry (j, i), j >= i, is the (i, j) entry of the old upper-triangle form: own inertia - Tq[i] Fo[j],
   // i.e. column i = (own column) - Tq[i] * (Fo[i..5]) with Fo in pairs -- the same products and sums, 13 instead of 21 instructions.
@@ -579,79 +497,9 @@ __device__ static void leg_dynamics(const KParams& P, Shared& S, const LegConst&
     auto sum2 = [](pk2& v) __attribute__((always_inline)) { v.x = row_sum16(v.x); v.y = row_sum16(v.y); };
     d0 = row_sum16(d0); a10 = row_sum16(a10); d1 = row_sum16(d1); d3 = row_sum16(d3); d5 = row_sum16(d5);
     sum2(a0a); sum2(a0b); sum2(a1a); sum2(a1b); sum2(d2a); sum2(a2b); sum2(a3b); sum2(d4a); sum2(p01); sum2(p23); sum2(p45);
-    static_assert(ORR_ROW_SOLVE, "the packed factor is kept for the rows");
     chol6_pk(d0, d1, d3, d5, a10, d2a, d4a, a0a, a0b, a1a, a1b, a2b, a3b, BF.F);
     chol6_solve_pk(BF.F, -p01.x, -p01.y, -p23, -p45, a0);
   }
-#else
-  // this lane's term of the elimination: -T_k F_k^T on the matrix, +T_k b_k on the force (Fo is zero in the part-3 lanes)
-#define TFT(i, j) (Tq[i] * Fo[j])
-  Iacc[0] -= TFT(0, 0); Iacc[1] -= TFT(1, 1); Iacc[2] -= TFT(2, 2);
-  Iacc[3] -= TFT(0, 1); Iacc[4] -= TFT(0, 2); Iacc[5] -= TFT(1, 2);
-  Macc[0] -= TFT(3, 3); Macc[1] -= TFT(4, 4); Macc[2] -= TFT(5, 5);
-  Macc[3] -= TFT(3, 4); Macc[4] -= TFT(3, 5); Macc[5] -= TFT(4, 5);
-  Hacc[0] -= TFT(0, 3); Hacc[1] -= TFT(0, 4); Hacc[2] -= TFT(0, 5);
-  Hacc[3] -= TFT(1, 3); Hacc[4] -= TFT(1, 4); Hacc[5] -= TFT(1, 5);
-  Hacc[6] -= TFT(2, 3); Hacc[7] -= TFT(2, 4); Hacc[8] -= TFT(2, 5);
-#undef TFT
-#pragma unroll
-  for (int i = 0; i < 6; i++) pacc[i] += Tq[i] * bo;
-  // base system: sum over all bodies / legs / joints = over the robot's 16 lanes (DPP butterfly fused into the adds)
-#pragma unroll
-  for (int i = 0; i < 6; i++) { Iacc[i] = row_sum16(Iacc[i]); Macc[i] = row_sum16(Macc[i]); pacc[i] = row_sum16(pacc[i]); }
-#pragma unroll
-  for (int i = 0; i < 9; i++) Hacc[i] = row_sum16(Hacc[i]);
-  float a0[6];
-#if ORR_CHOL_PK
-  {
-    // A0 = [[I, skew-ish H], [H^T, M]] (rows / columns 0..2 angular, 3..5 linear), lower triangle by columns
-    static_assert(ORR_ROW_SOLVE, "the packed factor is kept for the rows");
-    chol6_pk(Iacc[0], Iacc[1], Macc[0], Macc[2], /*(1,0)*/ Iacc[3], /*(2,2),(3,2)*/ pk2{Iacc[2], Hacc[6]}, /*(4,4),(5,4)*/ pk2{Macc[1], Macc[5]},
-             /*col 0 rows 2,3*/ pk2{Iacc[4], Hacc[0]}, /*rows 4,5*/ pk2{Hacc[1], Hacc[2]},
-             /*col 1 rows 2,3*/ pk2{Iacc[5], Hacc[3]}, /*rows 4,5*/ pk2{Hacc[4], Hacc[5]},
-             /*col 2 rows 4,5*/ pk2{Hacc[7], Hacc[8]}, /*col 3 rows 4,5*/ pk2{Macc[3], Macc[4]}, BF.F);
-    chol6_solve_pk(BF.F, -pacc[0], -pacc[1], pk2{-pacc[2], -pacc[3]}, pk2{-pacc[4], -pacc[5]}, a0);
-  }
-#else
-  {
-    float A6[36];
-    float Im[9], Mm[9];
-    sym_to_m3(Iacc, Im);
-    sym_to_m3(Macc, Mm);
-#pragma unroll
-    for (int a_ = 0; a_ < 3; a_++)
-#pragma unroll
-      for (int b_ = 0; b_ < 3; b_++) {
-        A6[a_ * 6 + b_] = Im[a_ * 3 + b_];
-        A6[a_ * 6 + 3 + b_] = Hacc[a_ * 3 + b_];
-        A6[(3 + a_) * 6 + b_] = Hacc[b_ * 3 + a_];
-        A6[(3 + a_) * 6 + 3 + b_] = Mm[a_ * 3 + b_];
-      }
-    float Lc[21], idg[6], nb[6];
-    chol6(A6, Lc, idg);
-#pragma unroll
-    for (int i = 0; i < 6; i++) nb[i] = -pacc[i];
-    chol6_solve(Lc, idg, nb, a0);
-#if ORR_ROW_SOLVE
-#pragma unroll
-    for (int i = 0; i < 21; i++) BF.L[i] = Lc[i];
-#pragma unroll
-    for (int i = 0; i < 6; i++) BF.idg[i] = idg[i];
-#else
-    // explicit inverse for the impulse responses: lane c (< 6) solves for unit column c
-    // (tried in round 3: ONE solve per lane with its own right-hand side - unit columns in lanes 0..11, -p in lanes 12..15 - and a0
-    // broadcast from lane 12: only 10 instructions fewer per sub-step, and 144 B of LDS per robot for the dump slots of the a0 lanes)
-    float e[6], x[6];
-    const int col = lane % 6;
-#pragma unroll
-    for (int i = 0; i < 6; i++) e[i] = (i == col) ? 1.0f : 0.0f;
-    chol6_solve(Lc, idg, e, x);
-#pragma unroll
-    for (int i = 0; i < 6; i++) S.IA0inv[i * 6 + col] = x[i];   // lanes >= 6 store the same column again (col = lane % 6)
-#endif
-  }
-#endif
-#endif   // ORR_CHOL_PK >= 2
   // joint accelerations qdd = H^-1 (b - F^T a0): row `part` of H^-1 for the lane's own joint; written as the unconstrained
   // velocity u* = u + dt udot by the lane that owns the joint (it has the joint rate)
   const float dt = P.cfg.sim_dt;
@@ -797,9 +645,6 @@ __device__ __forceinline__ void row_setup(const Shared& S, const orr_config& cfg
 // round trip that cannot overlap with anything (the region's own loads: friction coefficient, knee friction, contact softness).  Here
 // every lane loads all of these up front, computes the contact geometry of "its" leg (knee lane l: leg l; the result is discarded) and
 // picks its row's values with selects on lane-constant masks.  Same arithmetic per row, bit for bit.
-#ifndef ORR_BRANCHFREE_ROWS
-#define ORR_BRANCHFREE_ROWS 1
-#endif
 __device__ __forceinline__ void row_setup_bank_a(const Shared& S, const orr_config& cfg, int slot, bool enable, float dt, float inv_dt,
                                                  float erp_dt, Row& R, ContactGeom& G) {
   const bool knee = slot < 4;
@@ -1003,14 +848,10 @@ __device__ __forceinline__ void row_response(Shared& S, const orr_config& cfg, R
   const LegSolve& QL = S.leg[leg];
   float a0[6], mq[12];
   v2f fb2[3], a02[3];
-  // warm-start impulse of the row: loaded HERE, pinned behind the base solve (ORR_EARLY_WARM_LOAD; left to the compiler the load sits
+  // warm-start impulse of the row: loaded HERE, pinned behind the base solve (left to the compiler the load sits
   // right in front of its use at the end of the function, behind the W stores, and a lone wave waits out the LDS round trip there:
   // 4096 robots 0.2256 -> 0.2252 ms, 8192 robots neutral)
-#ifndef ORR_EARLY_WARM_LOAD
-#define ORR_EARLY_WARM_LOAD 1
-#endif
-  float prev = 0.0f;
-  if (ORR_EARLY_WARM_LOAD) prev = S.s[O(LAMBDA) + (R.warm >= 0 ? R.warm : 0)];
+  float prev = S.s[O(LAMBDA) + (R.warm >= 0 ? R.warm : 0)];   // every lane loads (opaque, so that the load is not put behind a branch)
   // the row's Jacobian through opaque copies: otherwise the compiler fuses neighbouring fields of the Row struct into vector loads
   // for the packed operations, which stops it from keeping the struct in registers (the fields went to LDS via promote-alloca)
   float jl0 = R.jl[0], jl1 = R.jl[1], jl2 = R.jl[2];
@@ -1024,39 +865,18 @@ __device__ __forceinline__ void row_response(Shared& S, const orr_config& cfg, R
       const v2f jb = {jb0, jb1};
       fb2[p] = jb - (TL[p] * jl0 + TL[3 + p] * jl1 + TL[6 + p] * jl2);
     }
-#if ORR_ROW_SOLVE
-#if ORR_CHOL_PK
     chol6_solve_pk(BF.F, fb2[0].x, fb2[0].y, fb2[1], fb2[2], a0);
-#else
-    const float fb[6] = {fb2[0].x, fb2[0].y, fb2[1].x, fb2[1].y, fb2[2].x, fb2[2].y};
-    chol6_solve(BF.L, BF.idg, fb, a0);
-#endif
 #pragma unroll
     for (int p = 0; p < 3; p++) a02[p] = v2f{a0[2 * p], a0[2 * p + 1]};
-#else
-    const v2f* IA = reinterpret_cast<const v2f*>(S.IA0inv);       // IA[3 k + p] = (A0^-1[k][2p], A0^-1[k][2p+1])
-#pragma unroll
-    for (int p = 0; p < 3; p++)
-      a02[p] = IA[p] * fb2[0].x + IA[3 + p] * fb2[0].y + IA[6 + p] * fb2[1].x + IA[9 + p] * fb2[1].y + IA[12 + p] * fb2[2].x + IA[15 + p] * fb2[2].y;
-#pragma unroll
-    for (int p = 0; p < 3; p++) { a0[2 * p] = a02[p].x; a0[2 * p + 1] = a02[p].y; }
-#endif
   }
-  if (ORR_EARLY_WARM_LOAD) asm volatile("" : "+v"(prev));
+  asm volatile("" : "+v"(prev));
   const float h0 = QL.Hi[0] * jl0 + QL.Hi[3] * jl1 + QL.Hi[4] * jl2;
   const float h1 = QL.Hi[3] * jl0 + QL.Hi[1] * jl1 + QL.Hi[5] * jl2;
   const float h2 = QL.Hi[4] * jl0 + QL.Hi[5] * jl1 + QL.Hi[2] * jl2;
-#ifndef ORR_ROWRESP_V2     // 1: (a), 2: (a) + (b); the two-wave unit takes (a) only: four more live registers cost it 30 spilled ones
-#ifdef ORR_TU_STEP_W2
-#define ORR_ROWRESP_V2 1
-#else
-#define ORR_ROWRESP_V2 2
-#endif
-#endif
-#if ORR_ROWRESP_V2
   // round 4, v40.  (a) The diagonal J W = Jb . a0 + jl . mq_L without the own-leg selects: with fb = Jb - T_L jl (above) and
   // mq_L = H_L^-1 jl - T_L^T a0 it is jl . (H_L^-1 jl) + fb . a0 -- nine multiply-adds (three of them on pairs) instead of 26 instructions.
-  // (b) "H_L^-1 jl for the own leg, 0 for the others" as a multiply-add with a 0 / 1 factor per leg instead of twelve selects.
+  // (b) "H_L^-1 jl for the own leg, 0 for the others" as a multiply-add with a 0 / 1 factor per leg instead of twelve selects (kOwnLegFactor:
+  // the one-wave unit only).
   const v2f dg = fb2[0] * a02[0] + fb2[1] * a02[1] + fb2[2] * a02[2];    // first: fb dies here
   float dgs = dg.x + dg.y;
   asm volatile("" : "+v"(dgs));
@@ -1069,26 +889,10 @@ __device__ __forceinline__ void row_response(Shared& S, const orr_config& cfg, R
     for (int k = 0; k < 3; k++) {
       const v2f t2 = TK[3 * k] * a02[0] + TK[3 * k + 1] * a02[1] + TK[3 * k + 2] * a02[2];
       const float hk = k == 0 ? h0 : (k == 1 ? h1 : h2);
-      mq[3 * L4 + k] = ORR_ROWRESP_V2 >= 2 ? fmaf(own, hk, -(t2.x + t2.y)) : ((L4 == leg ? hk : 0.0f) - (t2.x + t2.y));   // the same value either way
+      mq[3 * L4 + k] = kOwnLegFactor ? fmaf(own, hk, -(t2.x + t2.y)) : ((L4 == leg ? hk : 0.0f) - (t2.x + t2.y));   // the same value either way
     }
   }
   const float diag = fmaf(jl0, h0, fmaf(jl1, h1, fmaf(jl2, h2, dgs)));
-#else
-  float diag = 0.0f;
-#pragma unroll
-  for (int L4 = 0; L4 < 4; L4++) {
-    const v2f* TK = reinterpret_cast<const v2f*>(&S.leg[L4].T[0][0]);
-    const bool mine = (L4 == leg);
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      const v2f t2 = TK[3 * k] * a02[0] + TK[3 * k + 1] * a02[1] + TK[3 * k + 2] * a02[2];
-      mq[3 * L4 + k] = (mine ? (k == 0 ? h0 : (k == 1 ? h1 : h2)) : 0.0f) - (t2.x + t2.y);
-    }
-    diag += mine ? (jl0 * mq[3 * L4] + jl1 * mq[3 * L4 + 1] + jl2 * mq[3 * L4 + 2]) : 0.0f;
-  }
-#pragma unroll
-  for (int i = 0; i < 6; i++) diag += R.Jb[i] * a0[i];
-#endif
   // an inactive row stores too (zeros: its Jacobian is zero; its impulse stays zero anyway)
 #pragma unroll
   for (int i = 0; i < 6; i++) S.ph.sub.W[slot][i] = a0[i];
@@ -1104,7 +908,6 @@ __device__ __forceinline__ void row_response(Shared& S, const orr_config& cfg, R
   R.jdi = R.active ? __builtin_amdgcn_rcpf(diag + R.cfm) : 0.0f;
   R.rhs *= R.jdi;
   {
-    if (!ORR_EARLY_WARM_LOAD) prev = S.s[O(LAMBDA) + (R.warm >= 0 ? R.warm : 0)];   // every lane loads (opaque, so that the load is not put behind a branch)
     asm volatile("" : "+v"(prev));
     R.lam = (R.active && R.warm >= 0) ? cfg.warmstart_factor * prev : 0.0f;
     R.w = R.cfm * R.lam;
@@ -1368,9 +1171,6 @@ __device__ __forceinline__ void pgs_sweeps(int iters, unsigned int mask, int lan
 // knee rows have J = e_knee (the column is an element of wq), joint-limit rows J = +-e_joint (one multiply), contact rows
 // the full 9 terms (6 base + the 3 joints of their leg, whose index is static per slot).  Knee rows always, joint-limit
 // rows one by one, contact rows per leg.
-#ifndef ORR_DIAG_VCC
-#define ORR_DIAG_VCC 1
-#endif
 // x, but 0 in lane K of the robot's 16 (compare + select through vcc, two instructions, no lane mask kept in SGPRs)
 template <int K>
 __device__ __forceinline__ float zero_in_lane(float x, int lane) {
@@ -1391,22 +1191,14 @@ __device__ __forceinline__ void delassus_columns(const Shared& S, unsigned int m
     const float l0 = bcast_lane<src>(inB ? B.lam : A.lam, sub);
     lam[r] = l0;
     A.w += a * l0;
-#if ORR_DIAG_VCC
     // the diagonal entry of the scaled column is zero (y of the updated row does not move).  `lane == src` as a compare into vcc right
     // here: as a C++ select the compiler keeps one lane mask per row (16 SGPR pairs) alive over the whole sub-step loop, which is what
     // pushed the SGPR file over its limit (46 spilled, every use reloaded with two v_readlane)
     AcA[r] = inB ? -a * A.jdi : zero_in_lane<src>(-a * A.jdi, lane);
-#else
-    AcA[r] = (!inB && lane == src) ? 0.0f : -a * A.jdi;
-#endif
     if (r >= 16 && r < 20 && A.nrm_slot == r) A.lam_n = l0;
     if (HAS_B) {
       B.w += b * l0;
-#if ORR_DIAG_VCC
       AcB[r] = inB ? zero_in_lane<src>(-b * B.jdi, lane) : -b * B.jdi;
-#else
-      AcB[r] = (inB && lane == src) ? 0.0f : -b * B.jdi;
-#endif
     }
     asm("" : "+v"(AcA[r]), "+v"(AcB[r]));  // keep the scaled value (do not re-derive it inside the sweeps)
   };
@@ -1421,15 +1213,11 @@ __device__ __forceinline__ void delassus_columns(const Shared& S, unsigned int m
       finish(rc, sg * A.wq[r - 4], sg * B.wq[r - 4]);
     });
   }
-  // The contact rows leg by leg, each behind a test of the wave's union mask.  Round 4 measured the alternative (ORR_DELASSUS_ALL_LEGS=1:
-  // all four legs unconditionally, no zero-initialisation of the columns a skipped leg leaves - a leg is in contact in 60 % of the
+  // The contact rows leg by leg, each behind a test of the wave's union mask.  Round 4 measured the alternative (all four legs unconditionally, no zero-initialisation of the columns a skipped leg leaves - a leg is in contact in 60 % of the
   // sub-steps, so the union over four robots misses one in < 3 % of them): 120 instructions fewer in the loop, but 4096 robots
   // 0.2262 -> 0.2261 ms (nothing) and 8192 robots 0.3162 -> 0.3254 ms (+2.9 %: twelve columns in one basic block cost the two-wave build
   // 31 more spilled registers, 10 scratch accesses inside the loop).  Kept off.
-#ifndef ORR_DELASSUS_ALL_LEGS
-#define ORR_DELASSUS_ALL_LEGS 0
-#endif
-  const unsigned int cm = ORR_DELASSUS_ALL_LEGS ? 0xFu : (mask >> 16) & 0xFu;
+  const unsigned int cm = (mask >> 16) & 0xFu;
   static_for<0, 4>([&](auto gc) __attribute__((always_inline)) {      // the three contact rows of leg g at once
     constexpr int g = decltype(gc)::value;
     if ((cm >> g) & 1u) {
@@ -1500,11 +1288,7 @@ __device__ static int physics_substep(const KParams& P, Shared& S, const LegCons
   ContactGeom G, Gunused;
   if constexpr (ANCHOR) row_setup_bank_a_anchor(S, cfg, rowlane ? (lane < 4 ? lane : lane + 12) : 0, rowlane, dt, inv_dt, erp_dt, A, G, AS, anchor_robot);
   else {
-#if ORR_BRANCHFREE_ROWS
   row_setup_bank_a(S, cfg, rowlane ? (lane < 4 ? lane : lane + 12) : 0, rowlane, dt, inv_dt, erp_dt, A, G);
-#else
-  row_setup<0>(S, cfg, rowlane ? (lane < 4 ? lane : lane + 12) : 0, rowlane, dt, inv_dt, erp_dt, A, G);
-#endif
   }
   unsigned long long balB = 0ull;
   if (limit_idle > 0) {

@@ -85,17 +85,17 @@ def test_minicheetah_phase_020_fallers_are_ended_by_the_contact_margin_not_by_a_
     The robot lands on ONE leg of the pair, its partner stays 2-6 mm above the ground for four env steps, the trunk sinks ~5 cm and rolls
     0.27 rad - and the episode ends at step 6-10 because a KNEE (a termination-only proxy of radius 0) comes within the 2 cm contact margin
     of the plane: imitation_task.py:536-546 ends an episode on ANY getContactPoints entry of a non-foot link, and this engine lists a
-    proxy as soon as it is inside cfg.contact_margin = 0.02 (Bullet's absolute gContactBreakingThreshold; with its default relative
+    proxy as soon as it is inside cfg.contact_margin (0.02 until round 5: Bullet's absolute gContactBreakingThreshold; with its default relative
     threshold flag the margin of a link-sized shape is a few millimetres - recollection, unverifiable here).  The robot has not fallen:
-    its trunk is still 24-26 cm up, and with a 4 mm margin the very same starts walk on."""
+    its trunk is still 24-26 cm up, and with a 4 mm margin - the default since round 6 - the very same starts walk on."""
     n = 384
-    phase, alive, length, reason, z_end = _minicheetah_run(n, 60)
+    phase, alive, length, reason, z_end = _minicheetah_run(n, 60, margin=0.02)     # the Bullet library's margin: what rounds 1-5 shipped
     win = (phase >= 0.195) & (phase < 0.215)
     assert win.sum() >= 5
     assert not alive[win].any() and length[win].max() <= 14                 # every start in the window ends within 0.5 s ...
     assert np.all((reason[win] & _abi.DONE_CONTACT_FALL) != 0)              # ... by a "contact" of a non-foot link ...
     assert np.all(z_end[win] > 0.22)                                        # ... with the trunk still up (it stands at 0.28)
-    phase2, alive2, length2, _, _ = _minicheetah_run(n, 60, margin=0.004)
+    phase2, alive2, length2, _, _ = _minicheetah_run(n, 60)                         # round 6's default: the 4 mm of config.PYBULLET_REMEMBERED (rule P5)
     np.testing.assert_array_equal(phase, phase2)
     assert alive2[win].all()                                                # the same starts with a 4 mm margin: nobody is stopped
     # the second window (0.93-0.98) is a different story - the robot lands on the wrong pair and really falls - and stays

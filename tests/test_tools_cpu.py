@@ -123,10 +123,76 @@ def test_laikago_identify_runs_end_to_end_on_the_oracle_backend(tmp_path):
     assert a["fit"] == rec["fit"] and "table_with_shipped_config" in a and "greedy" in a
 
 
-def test_pybullet_remembered_constants_are_config_fields_and_not_the_defaults():
+def test_solver_constants_follow_the_recorded_cross_robot_rule():
+    """config.make_config's solver constants are what tools/identify_r6.py's rule P5 decided (profiles/r06_constants_rule.json): the set
+    PyBullet is remembered to run with, adopted because it is preferred on each robot's policies and costs the other robot's nothing."""
     from openroborl_amd import config
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r06_constants_rule.json")))
+    assert rec["sets"]["PYB"] == config.PYBULLET_REMEMBERED and rec["sets"]["LIB"] == config.BULLET_LIBRARY_DEFAULTS
+    a, b = rec["direction_A"], rec["direction_B"]
+    assert rec["adopt_PYB"] == (a["preferred_on_laikago"] and a["validates_on_mini_cheetah"] and b["preferred_on_mini_cheetah"] and b["validates_on_laikago"])
+    # the rule, recomputed from the recorded cells
+    lk = ["laikago_pace", "laikago_spin", "laikago_trot", "laikago_trot0"]
+    cell = rec["cells"]
+    assert a["preferred_on_laikago"] == (np.mean([cell["PYB/" + p]["J"] for p in lk]) >= np.mean([cell["LIB/" + p]["J"] for p in lk]))
+    assert b["validates_on_laikago"] == all(cell["LIB/" + p][k] - cell["PYB/" + p][k] <= 0.02 for p in lk for k in ("F", "J"))
+    assert a["validates_on_mini_cheetah"] == all(cell["LIB/minicheetah_trot"][k] - cell["PYB/minicheetah_trot"][k] <= 0.02 for k in ("F", "J"))
     c = config.make_config(4)
-    for k, v in config.PYBULLET_REMEMBERED.items():
-        assert hasattr(c, k)
-    assert (c.contact_erp, c.warmstart_factor, c.contact_margin) != tuple(config.PYBULLET_REMEMBERED[k] for k in ("contact_erp", "warmstart_factor", "contact_margin"))
-    assert abs(c.contact_erp - 0.2) < 1e-7 and abs(c.warmstart_factor - 0.85) < 1e-7 and abs(c.contact_margin - 0.02) < 1e-7 and abs(c.friction_erp - 0.2) < 1e-7
+    want = config.PYBULLET_REMEMBERED if rec["adopt_PYB"] else config.BULLET_LIBRARY_DEFAULTS
+    for k, v in want.items():
+        assert abs(getattr(c, k) - v) < 1e-7, k
+
+
+def test_identify_r6_box_freezes_what_the_protocol_says_it_freezes():
+    """tools/identify_r6.py P1 / P8: whatever the candidate, the clip-pinned hip height and toe radius, the termination-only proxies, the
+    Laikago's shank sphere and every constant the reference states are those of the reference-point table; the reference point of the box
+    IS round 4's Laikago table / round 2's mini-cheetah table with the clip-calibrated hip height."""
+    import identify_r6 as ir
+    from openroborl_amd import robots
+    rng = np.random.RandomState(3)
+    for robot, ref in (("laikago", robots.laikago(**robots.LAIKAGO_R04)), ("mini_cheetah", robots.mini_cheetah(**dict(robots.MINI_CHEETAH_R02, hip_z=0.011)))):
+        spec = ir.SPECS[robot]
+        m0 = ir.build_model(robot, ir.reference_theta(spec))
+        for key, val in ref.items():
+            if not isinstance(val, str) and key not in ("link_inertia",):          # mini-cheetah shank inertia: the slender-rod rule of round 3
+                np.testing.assert_allclose(np.asarray(m0[key], dtype=float), np.asarray(val, dtype=float), atol=1e-12, err_msg=key)
+        assert ir.distance(spec, ir.reference_theta(spec)) == 0.0
+        for i in range(24):
+            th = ir.random_theta(spec, rng, i % 2)
+            m = ir.build_model(robot, th)
+            for k, (v0, lo, hi) in spec["params"].items():
+                assert lo <= th[k] <= hi and lo <= v0 <= hi
+            frozen = ["kp", "kd", "init_motor_angles", "motor_dir", "motor_offset", "joint_of_motor", "init_pos", "init_quat", "joint_axis", "toe_radius",
+                      "fall_radius", "fall_body", "toe_pos"] + (["shank_radius", "shank_pos"] if robot == "laikago" else [])
+            for key in frozen:
+                np.testing.assert_array_equal(np.asarray(m[key]), np.asarray(ref[key]), err_msg=key)
+            assert np.allclose(m["joint_pos"][0::3, 2], ref["joint_pos"][0::3, 2])                   # hip plane height (clip toe clearance)
+            # chassis corners move only with the COM shift (they are attached to the hips' centre), never in size
+            assert np.allclose(np.ptp(np.asarray(m["fall_pos"])[:8], axis=0), np.ptp(np.asarray(ref["fall_pos"])[:8], axis=0))
+    assert ir.splits()[3] == (["laikago_spin", "laikago_trot"], ["laikago_pace", "laikago_trot0"]) and len(ir.splits()) == 6   # round 5's split is one of the six
+
+
+def test_identify_r6_runs_end_to_end_on_the_oracle_backend(tmp_path):
+    """One run of the round-6 protocol (search on min-J, shortlist re-evaluation, cloud, once-only hold-out) and the smallest-table pass, at
+    toy size on the CPU oracle: the plumbing, not the numbers (2 robots, 12 steps)."""
+    import subprocess
+    tool = os.path.join(ROOT, "tools", "identify_r6.py")
+    out = str(tmp_path / "run.json")
+    r = subprocess.run([sys.executable, tool, "run", "--backend", "oracle", "--robot", "laikago", "--fit", "laikago_trot", "laikago_spin", "--holdout",
+                        "laikago_trot0", "laikago_pace", "--robots", "2", "--steps", "12", "--minutes", "0.1", "--out", out,
+                        "--dump-all", str(tmp_path / "all.jsonl.gz")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.load(open(out))
+    assert rec["fit"] == ["laikago_trot", "laikago_spin"] and rec["holdout"] == ["laikago_trot0", "laikago_pace"] and "P4. CROSS-VALIDATION" in rec["protocol"]
+    ch = rec["chosen"]
+    assert set(ch["fit_final"]["seed_1"]) == set(rec["fit"]) and set(ch["holdout"]["seed_1"]) == set(rec["holdout"])
+    assert all(set(c["fit"]) == set(rec["fit"]) for c in rec["search"]["top_by_J"])                  # no candidate of the search saw a hold-out policy
+    cell = ch["fit_final"]["seed_1"]["laikago_trot"]
+    assert set(cell) >= {"F", "len", "J", "R", "terms", "dvx", "advx"} and set(cell["terms"]) == {"pose", "velocity", "end_effector", "root_pose", "root_velocity"}
+    assert cell["J"] <= cell["R"] + 1e-9                                                                # J forfeits the reward after a failure
+    mn = str(tmp_path / "min.json")
+    r = subprocess.run([sys.executable, tool, "minimal", "--backend", "oracle", "--robots", "2", "--steps", "12", "--record", out, "--out", mn],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    m = json.load(open(mn))
+    assert m["fit"] == rec["fit"] and set(m["minimal"]["still_moved"]) | {p["reverted"] for p in m["minimal"]["path"]} == set(m["single_reverted"])

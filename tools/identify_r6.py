@@ -242,9 +242,10 @@ def _summ(alive, length, ret, first_reason, tsum, tcnt, dvx, advx, k, R, steps):
 
 
 class HipProbe(object):
-    """One env per (policy, group of <= 4 candidates): the candidates of a group live in the four robot-type slots of the device table
-    (robot i is of type i // R), so one launch steps all of them."""
-    SLOTS = 4
+    """One env per (policy, group of <= 32 candidates): the candidates of a group live in the robot-type slots of the device table
+    (ORR_MAX_ROBOT_TYPES = 32; robot i is of type i // R), so one launch steps all of them: 32 x 128 robots = one full 4096-robot launch,
+    which costs the same 0.21 ms as a 512-robot one."""
+    SLOTS = 32
 
     def __init__(self, robot, robots_per_candidate, seed=1, config_over=None, terms_every=4):
         import torch
@@ -449,7 +450,7 @@ def run(args):
 
     nb = 0
     while time.time() - t0 < 0.3 * budget:          # P2 stage 1
-        run_batch([random_theta(spec, rng, (nb + i) % 2) for i in range(4 * probe.SLOTS)], "random")
+        run_batch([random_theta(spec, rng, (nb + i) % 2) for i in range(max(16, probe.SLOTS))], "random")
         nb += 1
         if nb % 16 == 0:
             status("random")
@@ -458,7 +459,7 @@ def run(args):
         frac = min(1.0, (time.time() - t0 - 0.3 * budget) / max(0.7 * budget, 1e-9))
         rel = 0.15 * (1.0 - frac) + 0.03 * frac
         top = sorted(cands, key=lambda c: c["J"], reverse=True)[:16]
-        run_batch([perturb(spec, top[rng.randint(len(top))]["theta"], rng, rel) for _ in range(4 * probe.SLOTS)], "local")
+        run_batch([perturb(spec, top[rng.randint(len(top))]["theta"], rng, rel) for _ in range(max(16, probe.SLOTS))], "local")
         gen += 1
         if gen % 16 == 0:
             status("local (step %.3f)" % rel)
@@ -527,6 +528,10 @@ def cv(args):
             "--constants", args.constants, "--out", out, "--dump-all", os.path.join(args.outdir, "split%d_candidates.jsonl.gz" % i)]
         log = open(os.path.join(args.outdir, "split%d_log.txt" % i), "w")
         procs.append((i, subprocess.Popen(cmd, stdout=log, stderr=subprocess.STDOUT), log))
+        if args.sequential:      # full 4096-robot launches fill the GPU: side by side gains nothing
+            while procs[-1][1].poll() is None:
+                time.sleep(20)
+                print("cv: split %d running, log %d bytes" % (i, os.path.getsize(log.name)), flush=True)
     t0 = time.time()
     while any(p.poll() is None for _, p, _ in procs):
         time.sleep(30)
@@ -707,6 +712,7 @@ def main():
     p.add_argument("--minutes", type=float, default=12.0)
     p.add_argument("--outdir", default=os.path.join(ROOT, "gpurun_out", "r06cv"))
     p.add_argument("--only", type=int, nargs="*", default=None, help="split numbers to run (default: all six)")
+    p.add_argument("--sequential", action="store_true", help="one child after another instead of side by side")
     p = sub.add_parser("collect"); common(p)
     p.add_argument("--outdir", default=os.path.join(ROOT, "gpurun_out", "r06cv"))
     p = sub.add_parser("minimal"); common(p)
