@@ -59,20 +59,27 @@ def push_state(env, st64):
     env.state.copy_(torch.from_numpy(statemod.from_float64(env.layout, st64)).to(env.device))
 
 
-def compare_fields(env, orc, names, atol, rtol=0.0, what="", outlier_robots=0):
-    """outlier_robots: that many robots may miss the tolerance - by at most 10 x - at a multi-sub-step horizon, where a contact row that
-    one side creates a sub-step earlier than the other (float32 distance against the contact margin) is a discrete event, not an error
-    of the arithmetic; 0 (every one-sub-step comparison) = the hard tolerance."""
+def compare_fields(env, orc, names, atol, rtol=0.0, what="", outlier_robots=0, floor=None):
+    """floor: the float32 build of the ORACLE (f32_twin) stepped like `orc` - a robot whose largest error stays within 1.5 x what the same
+    algorithm in float32 does to that robot passes even beyond the hand-set tolerance (ill-conditioned inputs: a robot lying on its shanks
+    with a 0.25 kg toe; measured round 6: float32 oracle 4.0e-4 on one joint rate of 384, HIP 3.0e-4, tolerance 2.2e-4).
+    outlier_robots: that many robots may miss both - by at most 10 x the tolerance - at a multi-sub-step horizon, where a contact row
+    that one side creates a sub-step earlier than the other (float32 distance against the contact margin) is a discrete event, not an
+    error of the arithmetic; 0 (every one-sub-step comparison) = nobody."""
     g = gpu_state64(env)
     for name in names:
         sl = env.layout.sl(name)
         if env.layout.is_int(name):
             np.testing.assert_array_equal(g[:, sl], orc.state[:, sl], err_msg="%s %s" % (what, name))
-        elif outlier_robots:
-            err = np.abs(g[:, sl] - orc.state[:, sl]) - (atol + rtol * np.abs(orc.state[:, sl]))
-            bad = (err > 0).any(axis=1)
-            assert bad.sum() <= outlier_robots, "%s %s: %d robots beyond tolerance" % (what, name, bad.sum())
-            np.testing.assert_allclose(g[:, sl], orc.state[:, sl], atol=10 * atol, rtol=10 * rtol, err_msg="%s %s (outlier bound)" % (what, name))
+        elif outlier_robots or floor is not None:
+            e = np.abs(g[:, sl] - orc.state[:, sl])
+            bad = (e > atol + rtol * np.abs(orc.state[:, sl])).any(axis=1)
+            if floor is not None:
+                e32 = np.abs(floor.state[:, sl].astype(np.float64) - orc.state[:, sl])
+                bad &= e.max(axis=1) > 1.5 * e32.max(axis=1)
+            assert bad.sum() <= outlier_robots, "%s %s: %d robots beyond tolerance and float32 floor (largest error %.3g)" % (what, name, bad.sum(), e[bad].max())
+            if bad.any():
+                np.testing.assert_allclose(g[bad][:, sl], orc.state[bad][:, sl], atol=10 * atol, rtol=10 * rtol, err_msg="%s %s (outlier bound)" % (what, name))
         else:
             np.testing.assert_allclose(g[:, sl], orc.state[:, sl], atol=atol, rtol=rtol, err_msg="%s %s" % (what, name))
 
@@ -585,28 +592,31 @@ def test_shank_contact_parity(robot):
     _, _, _, st, tau = shank_contact_inputs(robot, n)
     push_state(env, st); orc.state[:] = st
     tg = torch.tensor(tau, dtype=torch.float32, device=env.device)
+    o32 = f32_twin(env, orc)
+    tau32 = tau.astype(np.float32)
     for nsub, ptol, vtol in ((1, 2e-6, 2e-4), (8, 1e-4, 2e-3)):
         env.debug_physics(tg, nsub)
         for i in range(n):
             for _ in range(nsub):
                 orc.L.orc_physics_substep(orc.h, ol.P(orc.state[i]), ol.P(np.ascontiguousarray(tau[i])))
+                o32.L.orc_physics_substep(o32.h, o32.P(o32.state[i]), o32.P(np.ascontiguousarray(tau32[i])))
         out = 0 if nsub == 1 else 1     # 8 sub-steps: one robot of 32 may see a contact row switch a sub-step apart (round 6: 4 mm contact margin)
-        compare_fields(env, orc, ["POS", "QUAT", "Q"], atol=ptol, rtol=ptol, what="shank nsub=%d" % nsub, outlier_robots=out)
-        compare_fields(env, orc, ["LINVEL", "ANGVEL", "QD"], atol=vtol, rtol=vtol, what="shank nsub=%d" % nsub, outlier_robots=out)
-        compare_fields(env, orc, ["LAMBDA"], atol=5e-4 if nsub == 1 else 5e-3, what="shank nsub=%d" % nsub, outlier_robots=out)
+        compare_fields(env, orc, ["POS", "QUAT", "Q"], atol=ptol, rtol=ptol, what="shank nsub=%d" % nsub, outlier_robots=out, floor=o32)
+        compare_fields(env, orc, ["LINVEL", "ANGVEL", "QD"], atol=vtol, rtol=vtol, what="shank nsub=%d" % nsub, outlier_robots=out, floor=o32)
+        compare_fields(env, orc, ["LAMBDA"], atol=5e-4 if nsub == 1 else 5e-3, what="shank nsub=%d" % nsub, outlier_robots=out, floor=o32)
         if nsub == 1:   # the robots start with a penetrating shank sphere: its contact is live in (nearly) every robot
             lam = orc.field("LAMBDA").reshape(n, 4, 3)
             assert (lam[:, :, 0].sum(axis=1) > 0).mean() > 0.9
-    env.close(); orc.close()
+    env.close(); orc.close(); o32.close()
 
 
 def test_shipped_minicheetah_policy_probe():
     """IN-SAMPLE anchor (the table was identified against this very policy; there is no second mini-cheetah policy to hold out).
     Behavioural anchor for config 3's robot: the reference's minicheetah_trot policy (trained in PyBullet on the real URDF) walks the
     600-step episode on the mini-cheetah table of robots.py.  Round 2: 0 % of the robots finished (mean survival 158 steps) on the
-    hand-authored table; round 3 identified the uncertain distal masses / COMs / hip height against this very policy
-    (tools/mc_identify.py): 0.90 +- 0.01 of 1024 robots finish (two env seeds), ~10 % still fall.  The test pins
-    that level with the sampling noise of 1024 robots in mind; a failure is counted only for a termination other than the time limit."""
+    hand-authored table; round 3 identified the distal masses / COMs / hip height against this very policy by survival (0.90 finish);
+    round 6 re-identified it on the policy's own reward under the adopted solver constants (tools/identify_r6.py P8 + P7; DESIGN.md
+    section 7.3): 0.98 finish at 0.70 reward per step.  A failure is counted only for a termination other than the time limit."""
     import torch
     W = np.load(os.path.join(ol.GOLDEN, "policy_minicheetah_trot.npz"))
     n = 1024
@@ -631,8 +641,8 @@ def test_shipped_minicheetah_policy_probe():
     mean_len = length.mean().item()
     rps = (ret / length).mean().item()
     print("MINICHEETAH_PROBE finished=%.3f mean_survival_steps=%.1f reward_per_step=%.3f" % (finished, mean_len, rps))
-    assert finished >= 0.85            # measured 0.896 / 0.898 (seeds 1 / 2); the identification's bar was 0.90 on its own 256-robot sample
-    assert mean_len > 500.0 and rps > 0.6
+    assert finished >= 0.95            # measured 0.983 / 0.982 (seeds 1 / 2; rounds 3-5: 0.90)
+    assert mean_len > 570.0 and rps > 0.66                 # 590, 0.697
     env.close()
 
 

@@ -12,21 +12,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
-@pytest.fixture(scope="module")
-def diag():
+@pytest.fixture(scope="module", params=["shipped", "round5"])
+def diag(request):
+    """Both on the table that ships (round 6) and on round 5's, on which the diagnosis was made BEFORE round 6's identification ran."""
     import lag_diagnosis as L
     from openroborl_amd import robots
-    base = robots.laikago()
+    base = robots.laikago() if request.param == "shipped" else robots.laikago(**robots.LAIKAGO_R05)
     kin = L.clip_kinematics("laikago_pace", base, 6.0)
     sim = L.simulate("laikago_pace", "laikago_pace", base, 4, 160, 60)
-    return L, kin, sim
+    return L, kin, sim, base
 
 
 def test_clip_stance_toes_skate_whatever_the_table_or_threshold(diag):
-    L, kin, _ = diag
+    L, kin, _, _ = diag
     from openroborl_amd import robots
     assert abs(kin["v_clip"] - 1.086) < 0.005
-    assert 0.30 <= kin["skate_mean"] <= 0.42                          # 0.344 m/s of 1.086
+    assert 0.30 <= kin["skate_mean"] <= 0.42                          # 0.326 (shipped table) / 0.344 (round 5's) m/s of 1.086
     for table in (robots.laikago(), robots.laikago(**robots.LAIKAGO_R04)):   # not a property of the identified entries
         for mm in (3.0, 10.0, 15.0):
             k = L.clip_kinematics("laikago_pace", table, mm)
@@ -34,22 +35,22 @@ def test_clip_stance_toes_skate_whatever_the_table_or_threshold(diag):
 
 
 def test_simulated_stance_toes_stick_and_the_lag_is_the_clip_skate(diag):
-    _, kin, sim = diag
+    _, kin, sim, _ = diag
     assert sim["finished_window"] == 1.0
     lag = sim["v_ref"] - sim["v_sim"]
-    assert 0.22 <= lag <= 0.40, lag                                   # 0.31 m/s (HIP path, 1024 robots: 0.29-0.32)
-    assert abs(lag - kin["skate_mean"]) < 0.10                        # the lag IS the kinematic skate: 0.310 vs 0.344
-    assert abs(sim["v_sim"] - kin["v_noslip_mean"]) < 0.10            # 0.774 vs 0.757
+    assert 0.15 <= lag <= 0.40, lag                                   # shipped table 0.25, round 5's 0.31 m/s (HIP path, 1024 robots: 0.29 / 0.29-0.32)
+    assert abs(lag - kin["skate_mean"]) < 0.12                        # the lag IS the kinematic skate: 0.254 vs 0.326 / 0.310 vs 0.344
+    assert abs(sim["v_sim"] - kin["v_noslip_mean"]) < 0.12            # 0.830 vs 0.775 / 0.774 vs 0.757
     for leg in sim["legs"]:
-        assert abs(leg["slip_fwd_mm_per_stance"]) < 15.0, leg         # -4 .. +1 mm per stance; the clip's toes skate 16 .. 157 mm per stance
-        assert abs(leg["toe_v_fwd_in_stance"]) < 0.06, leg            # toes at rest on the ground
-        assert leg["friction_at_bound"] < 0.35, leg                   # 0.06 .. 0.15: the cone is not what limits the push
+        # the clip's toes skate FORWARD 8 .. 157 mm per stance; the simulated ones move 2 .. 19 mm, the pushing front toes BACKWARD
+        assert -35.0 < leg["slip_fwd_mm_per_stance"] < 25.0, leg
+        assert abs(leg["toe_v_fwd_in_stance"]) < 0.11, leg            # toes (nearly) at rest on the ground: -0.07 .. +0.04 m/s against the clip's +0.11 .. +0.71
+        assert leg["friction_at_bound"] < 0.45, leg                   # 0.19 .. 0.27 / 0.06 .. 0.15: the cone is not what limits the push
     assert 0.97 <= sim["mean_normal_force_over_weight"] <= 1.03       # the trace's impulses carry the robot
 
 
 def test_more_friction_does_not_buy_the_lag_back(diag):
-    L, kin, sim = diag
-    from openroborl_amd import robots
-    hi = L.simulate("laikago_pace", "laikago_pace", robots.laikago(foot_friction=1.0), 4, 160, 60)
-    assert (hi["v_ref"] - hi["v_sim"]) > 0.2                          # mu 1.0: lag 0.28 (mu 0.5: 0.31)
+    L, kin, sim, base = diag
+    hi = L.simulate("laikago_pace", "laikago_pace", dict(base, foot_friction=1.0), 4, 160, 60)
+    assert (hi["v_ref"] - hi["v_sim"]) > 0.15                         # mu 1.0: lag 0.22 / 0.28 (mu 0.53 / 0.5: 0.25 / 0.31)
     assert abs(hi["v_sim"] - sim["v_sim"]) < 0.08

@@ -10,7 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
-def test_shipped_minicheetah_table_is_the_identified_candidate():
+def test_round3_minicheetah_table_is_its_records_candidate():
+    """ROUND 3's table (robots.MINI_CHEETAH_R03, shipped in rounds 3-5, superseded in round 6) is the candidate of profiles/r03_mc_identify.json."""
     import mc_identify as mi
     from openroborl_amd import robots
     rec = json.load(open(os.path.join(ROOT, "profiles", "r03_mc_identify.json")))
@@ -27,7 +28,7 @@ def test_shipped_minicheetah_table_is_the_identified_candidate():
         tol = 0.1 * abs(best[k]) + 1e-3
         assert abs(shipped[k] - best[k]) <= tol, (k, shipped[k], best[k])
     m_tool = mi.build_model(np.array([shipped[k] for k in mi.NAMES]))
-    m_ship = robots.mini_cheetah()
+    m_ship = robots.mini_cheetah(**robots.MINI_CHEETAH_R03)
     for key, val in m_ship.items():
         if isinstance(val, str):
             continue
@@ -58,10 +59,10 @@ def test_drift_statistics_on_synthetic_errors():
         raise AssertionError("a 4x larger median was accepted")
 
 
-def test_shipped_laikago_table_is_the_identified_candidate_and_the_record_follows_its_protocol():
-    """robots.laikago() IS the chosen candidate of tools/laikago_identify.py's recorded run (profiles/r05_laikago_identify.json), the run
-    followed the protocol stated in the tool's docstring (fit on trot + spin, hold-out run once on the chosen candidate), and what the
-    search did NOT vary is what the reference fixes."""
+def test_round5_laikago_table_is_its_records_candidate_and_the_record_follows_its_protocol():
+    """ROUND 5's table (robots.LAIKAGO_R05, superseded in round 6) IS the chosen candidate of tools/laikago_identify.py's recorded run
+    (profiles/r05_laikago_identify.json), the run followed the protocol stated in the tool's docstring (fit on trot + spin, hold-out run
+    once on the chosen candidate), and what the search did NOT vary is what the reference fixes."""
     import laikago_identify as li
     from openroborl_amd import robots
     rec = json.load(open(os.path.join(ROOT, "profiles", "r05_laikago_identify.json")))
@@ -78,7 +79,7 @@ def test_shipped_laikago_table_is_the_identified_candidate_and_the_record_follow
     # ONE entry differs, on purpose: the hip plane's height is pinned by the clips (stance toes on the ground: tools/diag/clip_toe_clearance.py),
     # not by a policy; the search's winner had put it 2.4 cm lower, the fit-set ablation shows the fit does not care, the calibrated value ships
     assert abs(ch["theta"]["hip_z"] - (-0.068136)) < 1e-5
-    m_tool, m_ship = li.build_model(dict(ch["theta"], hip_z=-0.044)), robots.laikago()
+    m_tool, m_ship = li.build_model(dict(ch["theta"], hip_z=-0.044)), robots.laikago(**robots.LAIKAGO_R05)
     for key, val in m_ship.items():
         if isinstance(val, str):
             continue
@@ -93,7 +94,7 @@ def test_shipped_laikago_table_is_the_identified_candidate_and_the_record_follow
         np.testing.assert_array_equal(np.asarray(m_ship[key]), np.asarray(r4[key]), err_msg=key)          # control constants, conventions
     # link lengths (trans2minicheetah.m:3-5): knee below the hip pitch axis, toe below the knee
     assert np.allclose(m_ship["joint_pos"][2], [0, 0, -0.25223]) and np.allclose(m_ship["toe_pos"][0], [0, 0, -0.251])
-    # the solver constants that ship are the library defaults, not the candidate's: the candidate's table is accepted under them too
+    # the solver constants that shipped in round 5 were the library defaults, not the candidate's: the candidate's table is accepted under them too
     ab = json.load(open(os.path.join(ROOT, "profiles", "r05_laikago_identify_ablation.json")))
     assert all(ab["table_with_shipped_config"]["fit"][p]["F"] >= 0.8 for p in rec["fit"])
     assert ab["single_reverted"]["soft"]["score"][0] < 0.5 and ab["single_reverted"]["foot_friction"]["score"][0] < 0.5    # what it hangs on
@@ -196,3 +197,85 @@ def test_identify_r6_runs_end_to_end_on_the_oracle_backend(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     m = json.load(open(mn))
     assert m["fit"] == rec["fit"] and set(m["minimal"]["still_moved"]) | {p["reverted"] for p in m["minimal"]["path"]} == set(m["single_reverted"])
+
+
+def test_shipped_laikago_table_is_round6s_record_and_the_records_follow_the_protocol():
+    """robots.laikago() IS the end of the smallest-table path (P7) of the all-four run (P6) of tools/identify_r6.py
+    (profiles/r06_laikago_all4.json, r06_laikago_minimal.json); the cross-validation record holds all six splits with their hold-out
+    policies evaluated on the chosen candidate only (P4: profiles/r06_laikago_cv.json); the rules are recomputed from the records."""
+    import identify_r6 as ir
+    from openroborl_amd import robots
+    spec = ir.SPECS["laikago"]
+    all4 = json.load(open(os.path.join(ROOT, "profiles", "r06_laikago_all4.json")))
+    mn = json.load(open(os.path.join(ROOT, "profiles", "r06_laikago_minimal.json")))
+    assert sorted(all4["fit"]) == ir.LAIKAGO_POLICIES and all4["holdout"] == [] and all4["verdict"] == "accepted"
+    assert "P6. WHAT SHIPS" in all4["protocol"] and all4["protocol"].split()[:12] == ir.__doc__.split("==== PROTOCOL")[1].split("usage:")[0].split()[:12]
+    for k, (v0, lo, hi) in all4["params"].items():
+        assert (v0, lo, hi) == tuple(spec["params"][k]) and lo - 1e-12 <= all4["chosen"]["theta"][k] <= hi + 1e-12, k       # the tool's box is the run's box
+    ch = all4["chosen"]
+    assert ch["recheck"]["F"] >= 0.8 and ch["robustness"]["mean_min_F"] >= 0.8                                                # P3
+    assert all(c["F"] >= 0.8 for c in ch["fit_final"]["seed_1"].values())
+    # P7, recomputed: every step of the path kept acceptance and min-J within 0.01 of the chosen candidate's; nothing more could be put back
+    assert mn["of"].endswith("r06_laikago_all4.json") and mn["tolerance_J"] == 0.01
+    assert {k: v for k, v in mn["minimal"]["theta"].items() if k not in mn["minimal"]["still_moved"] and k in spec["params"]} == \
+           {k: spec["params"][k][0] for k in spec["params"] if k not in mn["minimal"]["still_moved"]}
+    for step in mn["path"] if "path" in mn else mn["minimal"]["path"]:
+        assert step["min_F"] >= 0.8 and step["min_J"] >= mn["chosen"]["min_J"] - 0.01
+    for k, e in mn["minimal"]["effect_of_each_moved_entry"].items():
+        assert e["min_F_if_put_back"] < 0.8 or e["min_J_if_put_back"] < mn["chosen"]["min_J"] - 0.01, k                      # each remaining entry costs something
+    # the table = the record (5 significant digits), through the ONE theta -> table mapping
+    moved = dict(robots.LAIKAGO_R06_MOVED)
+    assert set(k for k in moved if k in spec["params"] or k in spec["switches"]) == set(mn["minimal"]["still_moved"])
+    m_tool, m_ship = ir.build_model("laikago", mn["minimal"]["theta"]), robots.laikago()
+    for key, val in m_ship.items():
+        if not isinstance(val, str):
+            b = np.asarray(m_tool[key], dtype=float)
+            np.testing.assert_allclose(np.asarray(val, dtype=float), b, rtol=3e-5, atol=3e-5 * max(1.0, float(np.abs(b).max())), err_msg=key)
+    r4 = robots.laikago(**robots.LAIKAGO_R04)
+    for key in ("kp", "kd", "init_motor_angles", "motor_dir", "motor_offset", "joint_of_motor", "init_pos", "init_quat", "joint_axis", "toe_radius",
+                "fall_radius", "fall_body", "shank_radius", "shank_pos", "joint_lo", "joint_hi"):
+        np.testing.assert_array_equal(np.asarray(m_ship[key]), np.asarray(r4[key]), err_msg=key)          # the reference's constants + what P1 froze
+    assert np.allclose(m_ship["joint_pos"][0::3, 2], -0.044) and np.allclose(m_ship["joint_pos"][2], [0, 0, -0.25223]) and np.allclose(m_ship["toe_pos"][0], [0, 0, -0.251])
+    assert np.allclose(np.abs(m_ship["joint_pos"][0::3, 1]), 0.1157 - 0.032875)                             # hip_y: laikago.py:54-59 minus the coxa
+    # P4: six splits, each hold-out policy evaluated on the chosen candidate and nowhere else
+    cv = json.load(open(os.path.join(ROOT, "profiles", "r06_laikago_cv.json")))
+    assert [(r["fit"], r["holdout"]) for r in cv["splits"]] == [(f, h) for f, h in ir.splits()]
+    for r, row in zip(cv["splits"], cv["table"]):
+        assert set(r["chosen"]["holdout"]["seed_1"]) == set(r["holdout"]) and set(r["chosen"]["fit_final"]["seed_1"]) == set(r["fit"])
+        assert r["transfers"] == (r["verdict"] == "accepted" and all(r["chosen"]["holdout"][s][p]["F"] >= 0.5 for s in r["chosen"]["holdout"] for p in r["holdout"]))
+        assert row["transfers"] == r["transfers"] and len(row["cells"]) == 4
+    held = [(row["split"], p, c["F"]) for row in cv["table"] for p, c in row["cells"].items() if c["role"] == "held out"]
+    assert len(held) == 12
+    # what the matrix says (DESIGN.md section 7.2): pace walks on every table; the two trots carry over to each other when spin or the other
+    # trot is in the fit; spin is never predicted by a table that was not fitted on it
+    assert all(f >= 0.99 for _, p, f in held if p == "laikago_pace") and all(f <= 0.01 for _, p, f in held if p == "laikago_spin")
+    assert sum(r["transfers"] for r in cv["splits"]) == 2 and sum(f >= 0.5 for _, _, f in held) == 7
+
+
+def test_shipped_minicheetah_table_is_round6s_record():
+    """robots.mini_cheetah() IS the end of the smallest-table path of tools/identify_r6.py's mini-cheetah run (P8 + P7;
+    profiles/r06_mc_identify.json, r06_mc_minimal.json).  IN SAMPLE: one policy exists, the record has no hold-out."""
+    import identify_r6 as ir
+    from openroborl_amd import robots
+    spec = ir.SPECS["mini_cheetah"]
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r06_mc_identify.json")))
+    mn = json.load(open(os.path.join(ROOT, "profiles", "r06_mc_minimal.json")))
+    assert rec["fit"] == ["minicheetah_trot"] and rec["holdout"] == [] and rec["verdict"] == "accepted" and rec["accept_F"] == 0.9 and "holdout" not in rec["chosen"]
+    assert rec["chosen"]["recheck"]["F"] >= 0.9 and rec["chosen"]["robustness"]["mean_min_F"] >= 0.8
+    for k, (v0, lo, hi) in rec["params"].items():
+        assert (v0, lo, hi) == tuple(spec["params"][k]) and lo - 1e-12 <= rec["chosen"]["theta"][k] <= hi + 1e-12, k
+    for step in mn["minimal"]["path"]:
+        assert step["min_F"] >= 0.9 and step["min_J"] >= mn["chosen"]["min_J"] - 0.01
+    for k, e in mn["minimal"]["effect_of_each_moved_entry"].items():
+        assert e["min_F_if_put_back"] < 0.9 or e["min_J_if_put_back"] < mn["chosen"]["min_J"] - 0.01, k
+    assert set(robots.MINI_CHEETAH_R06_MOVED) == set(mn["minimal"]["still_moved"])
+    m_tool, m_ship = ir.build_model("mini_cheetah", mn["minimal"]["theta"]), robots.mini_cheetah()
+    for key, val in m_ship.items():
+        if not isinstance(val, str):
+            b = np.asarray(m_tool[key], dtype=float)
+            np.testing.assert_allclose(np.asarray(val, dtype=float), b, rtol=3e-5, atol=3e-5 * max(1.0, float(np.abs(b).max())), err_msg=key)
+    r2 = robots.mini_cheetah(**robots.MINI_CHEETAH_R02)
+    for key in ("kp", "kd", "init_motor_angles", "motor_dir", "motor_offset", "joint_of_motor", "init_pos", "init_quat", "joint_axis", "toe_radius",
+                "fall_radius", "fall_body", "base_mass", "shank_radius", "shank_pos", "joint_lo", "joint_hi"):
+        np.testing.assert_array_equal(np.asarray(m_ship[key]), np.asarray(r2[key]), err_msg=key)
+    assert np.allclose(m_ship["joint_pos"][0::3, 2], 0.011)                      # hip plane: the clip's lowest toe on the ground

@@ -81,7 +81,6 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 TERMS = ("pose", "velocity", "end_effector", "root_pose", "root_velocity")
 LAIKAGO_POLICIES = ["laikago_pace", "laikago_spin", "laikago_trot", "laikago_trot0"]
-MIT_LIMITS = [(-1.05, 1.05), (-3.6, 1.6), (0.05, 2.77)]     # abad, hip pitch, knee (motor convention; approximate published ranges)
 
 
 def clip_of(pol):
@@ -191,33 +190,11 @@ def build_model(robot, th):
     """theta -> robot model table: the reference-point table with the varied entries replaced, everything else frozen (P1 / P8)."""
     from openroborl_amd import robots
     if robot == "laikago":
-        kw = dict(robots.LAIKAGO_R04)
-        for k in ("toe_m", "base_mass", "hip_m", "up_m", "lo_m", "foot_friction"):
-            kw[k] = th[k]
-        kw["hip_xy"] = [th["hip_x"], th["hip_y"]]
-        kw["com_x"] = th["com_x"]
-        kw["base_inertia"] = [th["base_I"] * x for x in robots.LAIKAGO_R04["base_inertia"]]
-        s = th["leg_I"]
-        kw["hip_I"] = [s * x for x in robots.LAIKAGO_R04["hip_I"]]
-        kw["up_I"] = [s * x for x in robots.LAIKAGO_R04["up_I"]]
-        kw["lo_I"] = [s * x for x in robots.LAIKAGO_R04["lo_I"]]
-        kw["hip_com"] = [0.0, th["hip_com_y"], 0.0]
-        kw["up_com"] = [th["up_com_x"], th["up_com_y"], th["up_com_z"]]
-        kw["lo_com"] = [th["lo_com_x"], 0.0, th["lo_com_z"]]
-        if not th["limits"]:
-            kw["limits"] = [(-1e9, 1e9)] * 3
-        kw["friction_anchor"] = int(th["anchor"])
+        kw = dict(robots.LAIKAGO_R04, **robots.laikago_theta_kwargs(th))
         ref = robots.laikago(**robots.LAIKAGO_R04)
     else:
-        kw = dict(robots.MINI_CHEETAH_R02)
-        kw.update(hip_z=0.011, toe_m=th["toe_m"], lo_m=th["lo_m"], lo_com=[0.0, 0.0, th["lo_com_z"]], up_com=[0.0, 0.016, th["up_com_z"]],
-                  shank_r=th["shank_r"], shank_at=th["shank_at"], foot_friction=th["foot_friction"],
-                  # a slender rod of the candidate's mass (round 3's rule; the round-2 table's 0.000245 is that of a 0.064 kg rod)
-                  lo_I=[th["lo_m"] * 0.18 ** 2 / 12.0 + 0.00007, th["lo_m"] * 0.18 ** 2 / 12.0 + 0.00007, 0.000006])
-        if th["limits"]:
-            kw["limits"] = MIT_LIMITS
+        kw = dict(robots.MINI_CHEETAH_R02, **robots.mini_cheetah_theta_kwargs(th))
         ref = robots.mini_cheetah(**robots.MINI_CHEETAH_R02)
-    kw["contact_stiffness"], kw["contact_damping"] = (th["soft_k"], th["soft_d"]) if th["soft"] else (0.0, 0.0)
     m = robots.ROBOTS[robot](**kw)
     frozen = ["kp", "kd", "init_motor_angles", "motor_dir", "motor_offset", "joint_of_motor", "init_pos", "init_quat", "toe_radius", "fall_radius"]
     for key in frozen + (["shank_radius", "shank_pos"] if robot == "laikago" else []):
