@@ -13,14 +13,18 @@ reproduced exactly here:
     (mini-cheetah), FK p = [t*s23 + f*s2, c*side*c1 + (t*c23 + f*c2)*s1, c*side*s1 - (t*c23 + f*c2)*c1]
     (task/motions/trans2minicheetah.m:3-5,28-30; trans_data.py:55-69), and the URDF<->kinematic
     angle maps (trans2minicheetah.m:8-9,32);
-  * hip positions +-0.21 / +-0.1157 (robots/laikago.py:54-59);
+  * hip positions +-0.21 / +-0.1157 (robots/laikago.py:54-59: a tuple the reference never reads; LAIKAGO_R04 carries it, the
+    identification keeps the 0.1157 and moves the 0.21 to 0.192);
   * URDF joint order = motion-frame joint order: FR, FL, RR, RL (Laikago; laikago.py:31-44) and
     fr, fl, hr, hl (mini-cheetah; sign pattern of the abduction columns of minicheetah_trot.txt),
     while the mini-cheetah MOTOR order is fl, hl, fr, hr (mini_cheetah.py:31-44).
 
 Inertial parameters, collision proxies, joint limits and the toe radius are HAND-AUTHORED
-(Unitree / MIT-published figures from memory) and are **parity-unpinned**; they live only in this
-file so they can be swapped without touching a kernel.
+(Unitree / MIT-published figures from memory: LAIKAGO_R04, MINI_CHEETAH_R02) and are **parity-unpinned**;
+a few of them were then IDENTIFIED against the reference's PyBullet-trained policies by a protocol
+committed before its runs (round 6: tools/identify_r6.py; LAIKAGO_R06_MOVED, MINI_CHEETAH_R06_MOVED,
+each entry with its recorded effect).  They live only in this file so they can
+be swapped without touching a kernel.
 
 Frames: "kinematic" body frame x forward, y left, z up; all link frames are parallel to it at zero
 motor angles; the kinematic joint angle equals the motor angle `dir * (q_urdf - offset)`.
