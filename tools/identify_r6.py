@@ -501,7 +501,7 @@ def cv(args):
     for i, (fit, hold) in todo:
         out = os.path.join(args.outdir, "split%d.json" % i)
         cmd = [sys.executable, os.path.abspath(__file__), "run", "--robot", "laikago", "--fit"] + fit + ["--holdout"] + hold + [
-            "--minutes", str(args.minutes), "--robots", str(args.robots), "--steps", str(args.steps), "--seed", str(100 + i), "--backend", args.backend,
+            "--minutes", str(args.minutes), "--robots", str(args.robots), "--steps", str(args.steps), "--seed", str(args.seed_base + i), "--backend", args.backend,
             "--constants", args.constants, "--out", out, "--dump-all", os.path.join(args.outdir, "split%d_candidates.jsonl.gz" % i)]
         log = open(os.path.join(args.outdir, "split%d_log.txt" % i), "w")
         procs.append((i, subprocess.Popen(cmd, stdout=log, stderr=subprocess.STDOUT), log))
@@ -690,6 +690,7 @@ def main():
     p.add_argument("--outdir", default=os.path.join(ROOT, "gpurun_out", "r06cv"))
     p.add_argument("--only", type=int, nargs="*", default=None, help="split numbers to run (default: all six)")
     p.add_argument("--sequential", action="store_true", help="one child after another instead of side by side")
+    p.add_argument("--seed-base", type=int, default=100, help="split i searches with random seed seed_base + i (the recorded cross-validation: 100; its replication: 500)")
     p = sub.add_parser("collect"); common(p)
     p.add_argument("--outdir", default=os.path.join(ROOT, "gpurun_out", "r06cv"))
     p = sub.add_parser("minimal"); common(p)
