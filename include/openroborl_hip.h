@@ -135,10 +135,11 @@ typedef struct orr_config {
   int64_t curriculum_steps;  /* ceil(3e7 / num_procs): wrapper_env.py:45-46 */
   uint64_t seed;
   int32_t flags;
-  /* physics-engine constants (Bullet defaults; parity-unpinned) */
-  float contact_erp;         /* 0.2 */
-  float contact_margin;      /* 0.02 contact breaking threshold */
-  float warmstart_factor;    /* 0.85 */
+  /* physics-engine constants (parity-unpinned).  First value: what the Python host passes since round 6 = what PyBullet's
+     createEmptyDynamicsWorld is remembered to set; in brackets the Bullet library's default (rounds 1-5).  DESIGN.md section 4. */
+  float contact_erp;         /* 0.08 [0.2] */
+  float contact_margin;      /* 0.004 [0.02] contact breaking threshold: a normal row exists / a termination proxy counts inside it */
+  float warmstart_factor;    /* 0.1 [0.85] */
   float max_coord_velocity;  /* 100; orr_create refuses sqrt(3) * max_coord_velocity * sim_dt / 2 >= 0.2 (the base may turn at most 0.4 rad per sub-step) */
   float plane_friction;      /* 1.0 plane_implicit.urdf */
   float limit_activation;    /* 0.1 rad: a joint-limit row exists iff the joint is this close */

@@ -207,7 +207,9 @@ LAIKAGO_R05 = dict(
 # hip_y is back at that tuple's 0.1157 - 0.032875; hip_x is 1.8 cm short of its 0.21 (the tuple is never read by the reference, see the
 # protocol's P1).  Box-limited, i.e. the criterion would go further if the stated plausible intervals allowed: toe_m, up_m, soft_k (and the
 # search's own optimum also had com_x and base_mass near their edges): a compensation for something this engine or table family lacks,
-# not a measurement of the robot.
+# not a measurement of the robot.  In particular com_x and hip_x are NOT the robot's geometry: the turning clip's stance toes stand still for
+# hip_x 0.20-0.21, com_x 0.00, hip_y 0.07-0.08 - round 4's values (tools/diag/clip_hip_x_slip.py, found after the protocol had run) - while
+# putting com_x back costs every policy its walk.  Kept as the protocol produced them; DESIGN.md section 7.2 says what that means.
 LAIKAGO_R06_MOVED = {
     "toe_m": 0.25,           # -0.516   toe link mass [kg]                                   (round 4: 0.06;   box 0.005 .. 0.25)
     "com_x": 0.058198,       # -0.566   base COM in front of the hips' centre [m]            (0;               -0.03 .. 0.06)
