@@ -57,6 +57,18 @@ P8. MINI-CHEETAH: one policy exists, so no hold-out is possible: IN SAMPLE.  P2-
     reference point = the round-2 table (robots.MINI_CHEETAH_R02); frozen: hip_z +0.011 and toe_r (clip toe clearance agrees with round 3's
     policy-based value), the termination-only proxies (knee radius 0 included); then P7.  Record: profiles/r06_mc_identify.json.
 
+P9. REVISION OF THE LAIKAGO BOX, written after P1-P8 had run and their hold-outs had been seen, committed before any P9 GPU call.  The post-hoc
+    diagnostics (tools/diag/spin_hip_x.py, tools/diag/clip_hip_x_slip.py) show that the turning clip `laikago_turn` pins
+    hip_x and hip_y KINEMATICALLY at round 4's values (0.21, 0.0828 = laikago.py:54-59 minus the coxa) - policy-free in-tree data of the same
+    kind as the toe clearance that froze hip_z in P1 - and that P4's splits without spin lose the spin policy because their hip_x ran to the
+    other edge of its interval.  P9 = P2-P4, P6 and P7 again with exactly ONE change: hip_x and hip_y FROZEN at those values (`--freeze-geometry`).
+    com_x stays free although the same clip says 0.00 +- 0.01: with it at 0 no table near P6's keeps trot0 walking
+    (profiles/r06_geometry_pinned_probe.txt) - it is the open compensation of DESIGN.md section 7.2, flagged, not hidden.  Search seeds 700 + i
+    (all-four run: 800), same budgets.  Because P9's design used knowledge of P4's hold-out outcomes, its 6 x 4 matrix is WEAKER evidence than
+    P4's and is reported beside it, never instead of it (profiles/r06_laikago_cv_p9.json).  WHAT SHIPS after P9: the end of P7 on P9's all-four
+    run iff it is accepted on all four policies and its min-J (1024 robots x 2 seeds) is not more than 0.02 below the P6 / P7 table's (0.646);
+    otherwise the P6 / P7 table stays.  Either way both are recorded.
+
 usage:
   python tools/identify_r6.py constants [--robots 1024] [--out gpurun_out/r06_constants_rule.json]
   python tools/identify_r6.py run --robot laikago --fit laikago_trot laikago_spin --holdout laikago_trot0 laikago_pace --minutes 12 --out X.json
@@ -130,6 +142,14 @@ SPECS = {
         "soft_k": (1.0e4, 1.0e5), "soft_d": (1.0e2, 3.0e3), "soft_ref": (30000.0, 1000.0),
     },
 }
+
+
+# P9: the Laikago box with the two entries the turning clip pins frozen at the reference point (build_model leaves missing entries at round 4's)
+SPECS["laikago_g"] = dict(SPECS["laikago"], params={k: v for k, v in SPECS["laikago"]["params"].items() if k not in ("hip_x", "hip_y")})
+
+
+def spec_of(robot, freeze_geometry=False):
+    return SPECS["laikago_g" if (robot == "laikago" and freeze_geometry) else robot]
 
 
 def names(spec):
@@ -396,7 +416,7 @@ def brief(r, policies):
 
 # ---- one run of P2-P3 (+ the once-only hold-out of P4) ---------------------------------------------------------------------------------------
 def run(args):
-    spec = SPECS[args.robot]
+    spec = spec_of(args.robot, args.freeze_geometry)
     probe = make_probe(args, args.robot)
     fit, holdout = list(args.fit), list(args.holdout or [])
     assert not set(fit) & set(holdout)
@@ -406,7 +426,7 @@ def run(args):
     budget = args.minutes * 60.0
     res = {"protocol": __doc__.split("==== PROTOCOL")[1].split("usage:")[0].strip(), "robot": args.robot, "params": spec["params"],
            "switches": spec["switches"], "robots": args.robots, "steps": args.steps, "backend": args.backend, "fit": fit, "holdout": holdout,
-           "seed": args.seed, "constants": args.constants, "accept_F": acc_f}
+           "seed": args.seed, "constants": args.constants, "accept_F": acc_f, "freeze_geometry": bool(args.freeze_geometry)}
     if args.backend == "hip":
         from openroborl_amd import _lib
         res["source_hash"] = _lib.library_hash()
@@ -502,7 +522,8 @@ def cv(args):
         out = os.path.join(args.outdir, "split%d.json" % i)
         cmd = [sys.executable, os.path.abspath(__file__), "run", "--robot", "laikago", "--fit"] + fit + ["--holdout"] + hold + [
             "--minutes", str(args.minutes), "--robots", str(args.robots), "--steps", str(args.steps), "--seed", str(args.seed_base + i), "--backend", args.backend,
-            "--constants", args.constants, "--out", out, "--dump-all", os.path.join(args.outdir, "split%d_candidates.jsonl.gz" % i)]
+            "--constants", args.constants, "--out", out, "--dump-all", os.path.join(args.outdir, "split%d_candidates.jsonl.gz" % i)] + (
+            ["--freeze-geometry"] if args.freeze_geometry else [])
         log = open(os.path.join(args.outdir, "split%d_log.txt" % i), "w")
         procs.append((i, subprocess.Popen(cmd, stdout=log, stderr=subprocess.STDOUT), log))
         if args.sequential:      # full 4096-robot launches fill the GPU: side by side gains nothing
@@ -573,7 +594,7 @@ def fmt_table(rows):
 def minimal(args):
     rec = json.load(open(args.record))
     robot, fit = rec["robot"], rec["fit"]
-    spec = SPECS[robot]
+    spec = spec_of(robot, rec.get("freeze_geometry", False))
     args.constants = rec.get("constants", args.constants)
     probe = make_probe(args, robot)
     acc_f = spec["accept"]
@@ -673,6 +694,7 @@ def main():
     sub = ap.add_subparsers(dest="cmd", required=True)
 
     def common(p):
+        p.add_argument("--freeze-geometry", action="store_true", help="P9: hip_x / hip_y frozen at the values the turning clip pins (Laikago)")
         p.add_argument("--robots", type=int, default=128)
         p.add_argument("--steps", type=int, default=600)
         p.add_argument("--backend", default="hip", choices=["hip", "oracle"])

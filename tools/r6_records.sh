@@ -17,6 +17,9 @@ case $P in
 constants) python3 tools/identify_r6.py constants --out $OUT/r06_constants_rule.json > $OUT/r06_constants_rule.txt 2>&1 ;;
 all4)      python3 tools/identify_r6.py run --robot laikago --fit laikago_pace laikago_spin laikago_trot laikago_trot0 --minutes 8 --seed 200 \
              --out $OUT/r06_laikago_all4.json --dump-all $OUT/r06_laikago_all4_candidates.jsonl.gz > $OUT/r06_laikago_all4_log.txt 2>&1 ;;
+all4p9)    python3 tools/identify_r6.py run --robot laikago --freeze-geometry --fit laikago_pace laikago_spin laikago_trot laikago_trot0 --minutes 8 --seed 800 \
+             --out $OUT/r06_laikago_all4_p9.json --dump-all $OUT/r06_laikago_all4_p9_candidates.jsonl.gz > $OUT/r06_laikago_all4_p9_log.txt 2>&1
+           python3 tools/identify_r6.py minimal --record $OUT/r06_laikago_all4_p9.json --out $OUT/r06_laikago_minimal_p9.json > $OUT/r06_laikago_minimal_p9.txt 2>&1 ;;
 minimal)   python3 tools/identify_r6.py minimal --record $OUT/r06_laikago_all4.json --out $OUT/r06_laikago_minimal.json > $OUT/r06_laikago_minimal.txt 2>&1 ;;
 mc)        python3 tools/identify_r6.py run --robot mini_cheetah --fit minicheetah_trot --minutes 4 --seed 300 \
              --out $OUT/r06_mc_identify.json --dump-all $OUT/r06_mc_candidates.jsonl.gz > $OUT/r06_mc_identify_log.txt 2>&1
