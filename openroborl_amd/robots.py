@@ -197,30 +197,33 @@ LAIKAGO_R05 = dict(
     toe_m=0.13175, toe_r=0.026656, foot_friction=0.5, contact_stiffness=25335.0, contact_damping=2110.9,
     chassis_half=[0.64568 * x for x in (0.27, 0.09, 0.055)], hip_r=0.0066596, knee_r=0.02321, shank_r=0.016522, shank_at=0.073903)
 
-# Round 6: WHAT SHIPS.  The output of tools/identify_r6.py's protocol, fixed before the runs (P6 + P7; profiles/r06_laikago_all4.json,
-# profiles/r06_laikago_minimal.json): all four PyBullet-trained Laikago policies in the fit set (IN SAMPLE - the
-# out-of-sample evidence is the six-split cross-validation, profiles/r06_laikago_cv.json), criterion = the episode return the policies were
-# trained to maximise, then every entry put back to round 4's value unless that costs more than 0.01 of it.  These ten entries are what is
-# left; behind each, what putting it ALONE back costs in min-over-policies J (1024 robots, two seeds; the table's own min-J: 0.646).
-# Frozen by the protocol and therefore round 4's: hip height and toe radius (clip toe clearance), chassis box, hip / knee spheres, shank
-# sphere (termination geometry, imitation_task.py:536-546), joint limits.  NOT moved although laikago.py:54-59 states another value: nothing -
-# hip_y is back at that tuple's 0.1157 - 0.032875; hip_x is 1.8 cm short of its 0.21 (the tuple is never read by the reference, see the
-# protocol's P1).  Box-limited, i.e. the criterion would go further if the stated plausible intervals allowed: toe_m, up_m, soft_k (and the
-# search's own optimum also had com_x and base_mass near their edges): a compensation for something this engine or table family lacks,
-# not a measurement of the robot.  In particular com_x and hip_x are NOT the robot's geometry: the turning clip's stance toes stand still for
-# hip_x 0.20-0.21, com_x 0.00, hip_y 0.07-0.08 - round 4's values (tools/diag/clip_hip_x_slip.py, found after the protocol had run) - while
-# putting com_x back costs every policy its walk.  Kept as the protocol produced them; DESIGN.md section 7.2 says what that means.
+# Round 6, first table (tools/identify_r6.py P6 + P7; profiles/r06_laikago_all4.json, r06_laikago_minimal.json): all four policies in the fit
+# set, hip_x / hip_y still in the box.  Superseded within the round by P9's (below); kept for the record and its tests.
+LAIKAGO_R06_P6_MOVED = {"toe_m": 0.25, "com_x": 0.058198, "soft": 1, "soft_k": 10000.0, "soft_d": 744.99, "up_com_z": -0.081431, "base_mass": 11.364,
+                        "foot_friction": 0.53185, "up_m": 1.1, "hip_m": 0.81071, "base_I": 1.4195, "hip_x": 0.19182}
+
+# Round 6: WHAT SHIPS.  The output of tools/identify_r6.py's protocol in its revision P9 (docstring there; DESIGN.md section 7.2;
+# profiles/r06_laikago_all4_p9.json, r06_laikago_minimal_p9.json): all four PyBullet-trained Laikago policies in the fit set (IN SAMPLE - the
+# out-of-sample evidence is the six-split cross-validation, profiles/r06_laikago_cv.json and r06_laikago_cv_p9.json), criterion = the episode
+# return the policies were trained to maximise, then every entry put back to round 4's value unless that costs more than 0.01 of it.  These
+# nine entries are what is left; behind each, what putting it ALONE back costs in min-over-policies J (1024 robots, two seeds; the table's
+# own min-J: 0.629).  Frozen by the protocol and therefore round 4's: hip height and toe radius (clip toe clearance), hip_x and hip_y (P9: the
+# turning clip's stance toes stand still for exactly laikago.py:54-59's 0.21 / 0.1157 - 0.032875), chassis box, hip / knee spheres, shank
+# sphere (termination geometry, imitation_task.py:536-546), joint limits on, friction anchors off.
+# Box-limited, i.e. the criterion would go further if the stated plausible intervals allowed: com_x, up_m, soft_k at an edge, toe_m and base_mass
+# next to one: a compensation for something this engine or table family lacks, not a measurement of the robot.  In particular com_x is NOT
+# the robot's geometry - the same turning clip says 0.00 +- 0.01 (tools/diag/clip_hip_x_slip.py) - while putting it back costs every
+# policy its walk.  Kept as the protocol produced it; DESIGN.md section 7.2 says what that means.
 LAIKAGO_R06_MOVED = {
-    "toe_m": 0.25,           # -0.516   toe link mass [kg]                                   (round 4: 0.06;   box 0.005 .. 0.25)
-    "com_x": 0.058198,       # -0.566   base COM in front of the hips' centre [m]            (0;               -0.03 .. 0.06)
-    "soft": 1, "soft_k": 10000.0, "soft_d": 744.99,   # -0.470   Bullet's contact stiffness / damping on the toes [N/m, N s/m]  (rigid; k 1e4 .. 1e5, d 300 .. 3000)
-    "up_com_z": -0.081431,   # -0.302   thigh COM below the hip pitch axis [m]               (-0.04;           -0.09 .. -0.01)
-    "base_mass": 11.364,     # -0.169   [kg]                                                 (13.715;          11 .. 16.5)
-    "foot_friction": 0.53185,  # -0.119 toe lateral friction (test mode; training draws U[0.5, 1.25] like the reference)  (1.0;  0.3 .. 3.5)
-    "up_m": 1.1,             # -0.119   thigh mass [kg]                                      (1.527;           1.1 .. 1.9)
-    "hip_m": 0.81071,        # -0.058   hip link mass [kg]                                   (1.095;           0.8 .. 1.4)
-    "base_I": 1.4195,        # -0.033   scale of the base inertia                            (1;               0.6 .. 1.6)
-    "hip_x": 0.19182,        # -0.031   hip joints in front of / behind the hips' centre [m] (0.21;            0.19 .. 0.27)
+    "soft": 1, "soft_k": 10000.0, "soft_d": 924.7,   # -0.490   Bullet's contact stiffness / damping on the toes [N/m, N s/m]  (round 4: rigid;  box k 1e4 .. 1e5, d 300 .. 3000)
+    "com_x": 0.06,           # -0.445   base COM in front of the hips' centre [m]            (0;               -0.03 .. 0.06)
+    "toe_m": 0.2378,         # -0.439   toe link mass [kg]                                   (0.06;            0.005 .. 0.25)
+    "base_mass": 11.033,     # -0.287   [kg]                                                 (13.715;          11 .. 16.5)
+    "up_com_z": -0.074583,   # -0.121   thigh COM below the hip pitch axis [m]               (-0.04;           -0.09 .. -0.01)
+    "up_m": 1.1,             # -0.057   thigh mass [kg]                                      (1.527;           1.1 .. 1.9)
+    "foot_friction": 0.62346,  # -0.033 toe lateral friction (test mode; training draws U[0.5, 1.25] like the reference)  (1.0;  0.3 .. 3.5)
+    "base_I": 1.5833,        # -0.028   scale of the base inertia                            (1;               0.6 .. 1.6)
+    "hip_m": 0.82483,        # -0.028   hip link mass [kg]                                   (1.095;           0.8 .. 1.4)
 }
 
 
@@ -229,10 +232,10 @@ def laikago(**over):
     hand-authored entries: tools/policy_probe.py --sensitivity, tools/identify_r6.py).
 
     The hand-authored entries = round 4's table (LAIKAGO_R04: Unitree / URDF figures from memory, hip height calibrated on the clips) with
-    the ten entries of LAIKAGO_R06_MOVED, see there.  All four shipped Laikago policies on it (1024 robots, seeds 1 / 2, test mode;
-    profiles/r06_policy_probe.txt): pace 1.00, spin 0.95, trot 0.95, trot0 0.98 of the robots finish the 600-step episode at J = 0.69 /
-    0.66 / 0.65 / 0.65 per nominal step (round 5's table under the same solver constants: 1.00 / 0.88 / 0.93 / 0.93 at 0.69 / 0.50 / 0.57 / 0.50).
-    Earlier tables: LAIKAGO_R04, LAIKAGO_R05."""
+    the nine entries of LAIKAGO_R06_MOVED, see there.  All four shipped Laikago policies on it (1024 robots, seeds 1 / 2, test mode;
+    profiles/r06_policy_probe.txt): pace 1.00, spin 0.95, trot 0.97, trot0 1.00 of the robots finish the 600-step episode at J = 0.73 /
+    0.63 / 0.63 / 0.66 per nominal step (round 5's table under the same solver constants: 1.00 / 0.88 / 0.93 / 0.93 at 0.69 / 0.50 / 0.57 / 0.50).
+    Earlier tables: LAIKAGO_R04, LAIKAGO_R05, LAIKAGO_R06_P6_MOVED."""
     return _build(**dict(dict(dict(
         name="laikago",
         init_pos=[0, 0, 0.48], init_quat=[0.5, 0.5, 0.5, 0.5],               # laikago.py:48-49

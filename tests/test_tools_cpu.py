@@ -199,57 +199,82 @@ def test_identify_r6_runs_end_to_end_on_the_oracle_backend(tmp_path):
     assert m["fit"] == rec["fit"] and set(m["minimal"]["still_moved"]) | {p["reverted"] for p in m["minimal"]["path"]} == set(m["single_reverted"])
 
 
-def test_shipped_laikago_table_is_round6s_record_and_the_records_follow_the_protocol():
-    """robots.laikago() IS the end of the smallest-table path (P7) of the all-four run (P6) of tools/identify_r6.py
-    (profiles/r06_laikago_all4.json, r06_laikago_minimal.json); the cross-validation record holds all six splits with their hold-out
-    policies evaluated on the chosen candidate only (P4: profiles/r06_laikago_cv.json); the rules are recomputed from the records."""
-    import identify_r6 as ir
-    from openroborl_amd import robots
-    spec = ir.SPECS["laikago"]
-    all4 = json.load(open(os.path.join(ROOT, "profiles", "r06_laikago_all4.json")))
-    mn = json.load(open(os.path.join(ROOT, "profiles", "r06_laikago_minimal.json")))
-    assert sorted(all4["fit"]) == ir.LAIKAGO_POLICIES and all4["holdout"] == [] and all4["verdict"] == "accepted"
+def _check_all4_and_minimal(ir, robots, all4_name, min_name, freeze, moved):
+    """P3 / P6 / P7 recomputed from one all-four run and its smallest-table pass; -> (model built from the record, the minimal record)."""
+    spec = ir.spec_of("laikago", freeze)
+    all4 = json.load(open(os.path.join(ROOT, "profiles", all4_name)))
+    mn = json.load(open(os.path.join(ROOT, "profiles", min_name)))
+    assert sorted(all4["fit"]) == ir.LAIKAGO_POLICIES and all4["holdout"] == [] and all4["verdict"] == "accepted" and bool(all4.get("freeze_geometry")) == freeze
     assert "P6. WHAT SHIPS" in all4["protocol"] and all4["protocol"].split()[:12] == ir.__doc__.split("==== PROTOCOL")[1].split("usage:")[0].split()[:12]
+    assert ("P9. REVISION" in all4["protocol"]) == freeze                                      # P9 was written down before its runs, and after P6's
+    assert set(all4["params"]) == set(spec["params"])
     for k, (v0, lo, hi) in all4["params"].items():
         assert (v0, lo, hi) == tuple(spec["params"][k]) and lo - 1e-12 <= all4["chosen"]["theta"][k] <= hi + 1e-12, k       # the tool's box is the run's box
     ch = all4["chosen"]
     assert ch["recheck"]["F"] >= 0.8 and ch["robustness"]["mean_min_F"] >= 0.8                                                # P3
     assert all(c["F"] >= 0.8 for c in ch["fit_final"]["seed_1"].values())
     # P7, recomputed: every step of the path kept acceptance and min-J within 0.01 of the chosen candidate's; nothing more could be put back
-    assert mn["of"].endswith("r06_laikago_all4.json") and mn["tolerance_J"] == 0.01
+    assert mn["of"].endswith(all4_name) and mn["tolerance_J"] == 0.01
     assert {k: v for k, v in mn["minimal"]["theta"].items() if k not in mn["minimal"]["still_moved"] and k in spec["params"]} == \
            {k: spec["params"][k][0] for k in spec["params"] if k not in mn["minimal"]["still_moved"]}
-    for step in mn["path"] if "path" in mn else mn["minimal"]["path"]:
+    for step in mn["minimal"]["path"]:
         assert step["min_F"] >= 0.8 and step["min_J"] >= mn["chosen"]["min_J"] - 0.01
     for k, e in mn["minimal"]["effect_of_each_moved_entry"].items():
         assert e["min_F_if_put_back"] < 0.8 or e["min_J_if_put_back"] < mn["chosen"]["min_J"] - 0.01, k                      # each remaining entry costs something
-    # the table = the record (5 significant digits), through the ONE theta -> table mapping
-    moved = dict(robots.LAIKAGO_R06_MOVED)
     assert set(k for k in moved if k in spec["params"] or k in spec["switches"]) == set(mn["minimal"]["still_moved"])
-    m_tool, m_ship = ir.build_model("laikago", mn["minimal"]["theta"]), robots.laikago()
+    m_tool = ir.build_model("laikago", mn["minimal"]["theta"])
+    m_ship = robots.laikago(**dict(robots.LAIKAGO_R04, **robots.laikago_theta_kwargs(moved)))
     for key, val in m_ship.items():
         if not isinstance(val, str):
             b = np.asarray(m_tool[key], dtype=float)
             np.testing.assert_allclose(np.asarray(val, dtype=float), b, rtol=3e-5, atol=3e-5 * max(1.0, float(np.abs(b).max())), err_msg=key)
-    r4 = robots.laikago(**robots.LAIKAGO_R04)
-    for key in ("kp", "kd", "init_motor_angles", "motor_dir", "motor_offset", "joint_of_motor", "init_pos", "init_quat", "joint_axis", "toe_radius",
-                "fall_radius", "fall_body", "shank_radius", "shank_pos", "joint_lo", "joint_hi"):
-        np.testing.assert_array_equal(np.asarray(m_ship[key]), np.asarray(r4[key]), err_msg=key)          # the reference's constants + what P1 froze
-    assert np.allclose(m_ship["joint_pos"][0::3, 2], -0.044) and np.allclose(m_ship["joint_pos"][2], [0, 0, -0.25223]) and np.allclose(m_ship["toe_pos"][0], [0, 0, -0.251])
-    assert np.allclose(np.abs(m_ship["joint_pos"][0::3, 1]), 0.1157 - 0.032875)                             # hip_y: laikago.py:54-59 minus the coxa
-    # P4: six splits, each hold-out policy evaluated on the chosen candidate and nowhere else
-    cv = json.load(open(os.path.join(ROOT, "profiles", "r06_laikago_cv.json")))
-    assert [(r["fit"], r["holdout"]) for r in cv["splits"]] == [(f, h) for f, h in ir.splits()]
+    return m_ship, mn
+
+
+def _check_cv(ir, name, freeze, seeds):
+    cv = json.load(open(os.path.join(ROOT, "profiles", name)))
+    assert [(r["fit"], r["holdout"]) for r in cv["splits"]] == [(f, h) for f, h in ir.splits()] and [r["seed"] for r in cv["splits"]] == seeds
     for r, row in zip(cv["splits"], cv["table"]):
+        assert bool(r.get("freeze_geometry")) == freeze and ("hip_x" in r["chosen"]["theta"]) == (not freeze)
         assert set(r["chosen"]["holdout"]["seed_1"]) == set(r["holdout"]) and set(r["chosen"]["fit_final"]["seed_1"]) == set(r["fit"])
         assert r["transfers"] == (r["verdict"] == "accepted" and all(r["chosen"]["holdout"][s][p]["F"] >= 0.5 for s in r["chosen"]["holdout"] for p in r["holdout"]))
         assert row["transfers"] == r["transfers"] and len(row["cells"]) == 4
     held = [(row["split"], p, c["F"]) for row in cv["table"] for p, c in row["cells"].items() if c["role"] == "held out"]
     assert len(held) == 12
-    # what the matrix says (DESIGN.md section 7.2): pace walks on every table; the two trots carry over to each other when spin or the other
-    # trot is in the fit; spin is never predicted by a table that was not fitted on it
+    return cv, held
+
+
+def test_shipped_laikago_table_is_round6s_record_and_the_records_follow_the_protocol():
+    """robots.laikago() IS the end of the smallest-table path (P7) of the all-four run of tools/identify_r6.py in its revision P9
+    (profiles/r06_laikago_all4_p9.json, r06_laikago_minimal_p9.json), which ships by the rule P9 states; the first table of the round (P6 +
+    P7, hip positions still in the box) is recorded the same way; both cross-validation records hold all six splits with their hold-out
+    policies evaluated on the chosen candidate only; the rules are recomputed from the records."""
+    import identify_r6 as ir
+    from openroborl_amd import robots
+    _, mn6 = _check_all4_and_minimal(ir, robots, "r06_laikago_all4.json", "r06_laikago_minimal.json", False, robots.LAIKAGO_R06_P6_MOVED)
+    m9, mn9 = _check_all4_and_minimal(ir, robots, "r06_laikago_all4_p9.json", "r06_laikago_minimal_p9.json", True, robots.LAIKAGO_R06_MOVED)
+    # P9's shipping rule: accepted on all four and min-J not more than 0.02 below the P6 / P7 table's
+    assert all(c["F"] >= 0.8 for c in mn9["minimal"]["fit"].values()) and mn9["minimal"]["min_J"] >= mn6["minimal"]["min_J"] - 0.02
+    m_ship = robots.laikago()
+    for key, val in m_ship.items():
+        if not isinstance(val, str):
+            np.testing.assert_array_equal(np.asarray(val), np.asarray(m9[key]), err_msg=key)                # what ships = the P9 record
+    r4 = robots.laikago(**robots.LAIKAGO_R04)
+    for key in ("kp", "kd", "init_motor_angles", "motor_dir", "motor_offset", "joint_of_motor", "init_pos", "init_quat", "joint_axis", "toe_radius",
+                "fall_radius", "fall_body", "shank_radius", "shank_pos", "joint_lo", "joint_hi"):
+        np.testing.assert_array_equal(np.asarray(m_ship[key]), np.asarray(r4[key]), err_msg=key)          # the reference's constants + what P1 froze
+    assert np.allclose(m_ship["joint_pos"][0::3, 2], -0.044) and np.allclose(m_ship["joint_pos"][2], [0, 0, -0.25223]) and np.allclose(m_ship["toe_pos"][0], [0, 0, -0.251])
+    # hip_x / hip_y: laikago.py:54-59 (minus the coxa), behind the COM shift
+    assert np.allclose(np.abs(m_ship["joint_pos"][0::3, 1]), 0.1157 - 0.032875) and np.allclose(m_ship["joint_pos"][0::3, 0] + 0.06, [0.21, 0.21, -0.21, -0.21])
+    # P4, as it came out (DESIGN.md section 7.2): pace walks on every table; spin is never predicted by a table that was not fitted on it
+    cv, held = _check_cv(ir, "r06_laikago_cv.json", False, [100 + i for i in range(6)])
     assert all(f >= 0.99 for _, p, f in held if p == "laikago_pace") and all(f <= 0.01 for _, p, f in held if p == "laikago_spin")
     assert sum(r["transfers"] for r in cv["splits"]) == 2 and sum(f >= 0.5 for _, _, f in held) == 7
+    # P9's matrix (weaker evidence: its design knew P4's outcomes): with the wheelbase frozen at the clip-pinned value spin is predicted by two
+    # of the three tables that never saw it
+    cv9, held9 = _check_cv(ir, "r06_laikago_cv_p9.json", True, [700 + i for i in range(6)])
+    assert all(f >= 0.99 for _, p, f in held9 if p == "laikago_pace") and sorted(round(f, 2) for _, p, f in held9 if p == "laikago_spin") == [0.27, 0.80, 0.84]
+    assert sum(r["transfers"] for r in cv9["splits"]) == 4 and sum(f >= 0.5 for _, _, f in held9) == 9
 
 
 def test_shipped_minicheetah_table_is_round6s_record():
