@@ -5,10 +5,11 @@ here.  STATUS OF EACH ANCHOR - read this before taking a g
 
   laikago_pace, laikago_spin, laikago_trot, laikago_trot0
                      ALL FOUR IN SAMPLE since round 6: the shipped Laikago table is the output of tools/identify_r6.py's run with all four
-                     in the fit set (P6 + P7).  The OUT-OF-SAMPLE evidence is not in this file: it is the six-split cross-validation of the
-                     same protocol (profiles/r06_laikago_cv.json; tests/test_tools_cpu.py checks the record): held out, pace walks on every
-                     table (3 of 3), the trots carry over from tables fitted on spin or on the other trot (4 of 6 cells >= 0.5), spin is
-                     never predicted by a table that was not fitted on it (0 of 3).
+                     in the fit set (revision P9 + P7).  The OUT-OF-SAMPLE evidence is not in this file: it is the six-split cross-validation of the
+                     same protocol (profiles/r06_laikago_cv.json as committed, r06_laikago_cv_p9.json in the revision that ships; tests/test_tools_cpu.py
+                     checks the records): held out, pace walks on every table (3 of 3 / 3 of 3), the trots carry over from tables fitted on spin
+                     or on the other trot (4 of 6 / 4 of 6 cells >= 0.5), spin from none (0 of 3) / from two of three once the wheelbase is frozen
+                     at what the turning clip pins.
   minicheetah_trot   IN SAMPLE: the mini-cheetah table is identified against it (round 3, again in round 6: P8); it is the only mini-cheetah
                      policy, so no hold-out can exist.
 
@@ -40,10 +41,10 @@ def test_every_shipped_zip_is_matched_to_exactly_one_clip_pair():
 # policy: (clip, robot, robots, finished lo, finished hi, mean survival lo, hi [steps], J lo)   hi = None: no upper bound.   Measured (1024 robots,
 # seeds 1 / 2, profiles/r06_policy_probe.txt) in the comments; in brackets round 5's table under the same solver constants
 LEVELS = {
-    "laikago_pace": ("laikago_pace", "laikago", 256, 0.97, 1.0, 590, 600, 0.65),       # 1.000 / 1.000, 600, J 0.691 / 0.688  [1.000, 0.691]
-    "laikago_spin": ("laikago_spin", "laikago", 256, 0.85, None, 520, None, 0.60),     # 0.941 / 0.950, 566-571, J 0.661 / 0.667  [0.885, 0.498]
-    "laikago_trot": ("laikago_trot", "laikago", 256, 0.86, None, 530, None, 0.58),     # 0.944 / 0.964, 569-580, J 0.639 / 0.652  [0.934, 0.572]
-    "laikago_trot0": ("laikago_trot", "laikago", 256, 0.90, None, 550, None, 0.59),    # 0.975 / 0.976, 587, J 0.653 / 0.654  [0.933, 0.500]
+    "laikago_pace": ("laikago_pace", "laikago", 256, 0.97, 1.0, 590, 600, 0.68),       # 1.000 / 1.000, 600, J 0.732 / 0.735  [1.000, 0.691]
+    "laikago_spin": ("laikago_spin", "laikago", 256, 0.86, None, 530, None, 0.57),     # 0.950 / 0.958, 571-575, J 0.625 / 0.630  [0.885, 0.498]
+    "laikago_trot": ("laikago_trot", "laikago", 256, 0.90, None, 550, None, 0.58),     # 0.972 / 0.976, 584-587, J 0.628 / 0.631  [0.934, 0.572]
+    "laikago_trot0": ("laikago_trot", "laikago", 256, 0.95, None, 580, None, 0.61),    # 0.998 / 0.999, 599, J 0.655 / 0.656  [0.933, 0.500]
     "minicheetah_trot": ("minicheetah_trot", "mini_cheetah", 1024, 0.95, None, 570, None, 0.65),   # 0.983 / 0.982, 590, J 0.694 / 0.693  [round 3's table: 0.947, 0.648]
 }
 
