@@ -42,7 +42,7 @@ def test_every_shipped_zip_is_matched_to_exactly_one_clip_pair():
 # seeds 1 / 2, profiles/r06_policy_probe.txt) in the comments; in brackets round 5's table under the same solver constants
 LEVELS = {
     "laikago_pace": ("laikago_pace", "laikago", 256, 0.97, 1.0, 590, 600, 0.68),       # 1.000 / 1.000, 600, J 0.732 / 0.735  [1.000, 0.691]
-    "laikago_spin": ("laikago_spin", "laikago", 256, 0.86, None, 530, None, 0.57),     # 0.950 / 0.958, 571-575, J 0.625 / 0.630  [0.885, 0.498]
+    "laikago_spin": ("laikago_spin", "laikago", 256, 0.86, None, 530, None, 0.57),     # 0.950 / 0.958, 571-575, J 0.627 / 0.633  [0.885, 0.498]
     "laikago_trot": ("laikago_trot", "laikago", 256, 0.90, None, 550, None, 0.58),     # 0.972 / 0.976, 584-587, J 0.628 / 0.631  [0.934, 0.572]
     "laikago_trot0": ("laikago_trot", "laikago", 256, 0.95, None, 580, None, 0.61),    # 0.998 / 0.999, 599, J 0.655 / 0.656  [0.933, 0.500]
     "minicheetah_trot": ("minicheetah_trot", "mini_cheetah", 1024, 0.95, None, 570, None, 0.65),   # 0.983 / 0.982, 590, J 0.694 / 0.693  [round 3's table: 0.947, 0.648]

@@ -58,5 +58,7 @@ HY = [0.06, 0.07, 0.08, 0.082825, 0.09, 0.10, 0.11, 0.12]
 row = [slip("laikago_turn", robots.laikago(**dict(robots.LAIKAGO_R04, hip_xy=[0.21, hy])), 6.0) for hy in HY]
 print("hip_y [m]                                      " + "  ".join("%.3f" % x for x in HY) + "   minimum at")
 print("                                               " + "  ".join("%.3f" % v for v in row) + "   %.3f" % HY[int(np.argmin(row))])
-print("shipped table (hip_x 0.192, com_x +0.058): %.3f;  round 4's (0.21, 0): %.3f;  round 5's (0.227, +0.021, hip_y 0.098): %.3f" % (
-    slip("laikago_turn", robots.laikago(), 6.0), slip("laikago_turn", robots.laikago(**robots.LAIKAGO_R04), 6.0), slip("laikago_turn", robots.laikago(**robots.LAIKAGO_R05), 6.0)))
+p6 = dict(robots.LAIKAGO_R04, **robots.laikago_theta_kwargs(robots.LAIKAGO_R06_P6_MOVED))
+print("shipped table (P9: hip_x 0.21, com_x +0.06): %.3f;  round 6's first table (0.192, +0.058): %.3f;  round 4's (0.21, 0): %.3f;  round 5's (0.227, +0.021, hip_y 0.098): %.3f" % (
+    slip("laikago_turn", robots.laikago(), 6.0), slip("laikago_turn", robots.laikago(**p6), 6.0), slip("laikago_turn", robots.laikago(**robots.LAIKAGO_R04), 6.0),
+    slip("laikago_turn", robots.laikago(**robots.LAIKAGO_R05), 6.0)))

@@ -1,6 +1,6 @@
 """EXPLORATION after round 6's protocol had run (in sample on all four policies; a RECORD, nothing ships from it).  The turning clip pins
 the three geometric entries of the identification at round 4's values (hip_x 0.21, hip_y 0.0828, com_x 0: tools/diag/clip_hip_x_slip.py)
-while the shipped table has hip_x 0.192, com_x +0.058, and putting either back ALONE costs the policies their walk (P7:
+while the round's first table (P6 + P7) has hip_x 0.192, com_x +0.058, and putting either back ALONE costs the policies their walk (P7:
 profiles/r06_laikago_minimal.txt).  Put back TOGETHER?  (front hips: shipped 0.134, com_x alone back 0.192, both back 0.21 m ahead of the
 base COM.)  Also recorded, because it costs nothing: the trunk's inertia with its axes as an unpermuted y-up URDF would give them (pitch
 0.0733 instead of 0.2507) - a hypothesis for the missing pitch behaviour that the policies reject.
@@ -13,11 +13,11 @@ import policy_probe
 from openroborl_amd import robots
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-ship = dict(robots.LAIKAGO_R04, **robots.laikago_theta_kwargs(robots.LAIKAGO_R06_MOVED))
+ship = dict(robots.LAIKAGO_R04, **robots.laikago_theta_kwargs(robots.LAIKAGO_R06_P6_MOVED))     # round 6's FIRST table (P6 + P7), on which this probe was made
 geo = dict(hip_xy=[0.21, 0.1157 - 0.032875], com_x=0.0)
 I = (0.073348887, 0.250684593, 0.254469458)
 VARIANTS = [
-    ("shipped table (hip_x 0.192, com_x +0.058)", {}),
+    ("round 6's first table (hip_x 0.192, com_x +0.058)", {}),
     ("com_x alone back to 0", dict(com_x=0.0)),
     ("hip_x alone back to 0.21", dict(hip_xy=[0.21, 0.1157 - 0.032875])),
     ("BOTH back: the geometry the turning clip pins (hip_x 0.21, com_x 0)", geo),
