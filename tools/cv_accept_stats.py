@@ -18,7 +18,7 @@ for path in sys.argv[1:]:
     c = [json.loads(l) for l in gzip.open(path, "rt")]
     fit = list(c[0]["fit"])
     robot = "mini_cheetah" if fit[0].startswith("minicheetah") else "laikago"
-    spec = ir.spec_of(robot, "hip_x" not in c[0]["theta"])
+    spec = ir.spec_of(robot, "hip_x" not in c[0]["theta"], "com_x" not in c[0]["theta"])
     acc = [x for x in c if min(x["fit"][p]["F"] for p in fit) >= spec["accept"]]
     if not acc:
         print("%s: %d candidates, none accepted" % (os.path.basename(path), len(c)))

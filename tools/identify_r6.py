@@ -148,7 +148,13 @@ SPECS = {
 SPECS["laikago_g"] = dict(SPECS["laikago"], params={k: v for k, v in SPECS["laikago"]["params"].items() if k not in ("hip_x", "hip_y")})
 
 
-def spec_of(robot, freeze_geometry=False):
+# exploration only (never part of what ships): com_x frozen at the clip-pinned 0.00 as well
+SPECS["laikago_gc"] = dict(SPECS["laikago"], params={k: v for k, v in SPECS["laikago"]["params"].items() if k not in ("hip_x", "hip_y", "com_x")})
+
+
+def spec_of(robot, freeze_geometry=False, freeze_com=False):
+    if robot == "laikago" and freeze_com:
+        return SPECS["laikago_gc"]
     return SPECS["laikago_g" if (robot == "laikago" and freeze_geometry) else robot]
 
 
@@ -416,7 +422,7 @@ def brief(r, policies):
 
 # ---- one run of P2-P3 (+ the once-only hold-out of P4) ---------------------------------------------------------------------------------------
 def run(args):
-    spec = spec_of(args.robot, args.freeze_geometry)
+    spec = spec_of(args.robot, args.freeze_geometry, args.freeze_com)
     probe = make_probe(args, args.robot)
     fit, holdout = list(args.fit), list(args.holdout or [])
     assert not set(fit) & set(holdout)
@@ -426,7 +432,7 @@ def run(args):
     budget = args.minutes * 60.0
     res = {"protocol": __doc__.split("==== PROTOCOL")[1].split("usage:")[0].strip(), "robot": args.robot, "params": spec["params"],
            "switches": spec["switches"], "robots": args.robots, "steps": args.steps, "backend": args.backend, "fit": fit, "holdout": holdout,
-           "seed": args.seed, "constants": args.constants, "accept_F": acc_f, "freeze_geometry": bool(args.freeze_geometry)}
+           "seed": args.seed, "constants": args.constants, "accept_F": acc_f, "freeze_geometry": bool(args.freeze_geometry), "freeze_com": bool(args.freeze_com)}
     if args.backend == "hip":
         from openroborl_amd import _lib
         res["source_hash"] = _lib.library_hash()
@@ -594,7 +600,7 @@ def fmt_table(rows):
 def minimal(args):
     rec = json.load(open(args.record))
     robot, fit = rec["robot"], rec["fit"]
-    spec = spec_of(robot, rec.get("freeze_geometry", False))
+    spec = spec_of(robot, rec.get("freeze_geometry", False), rec.get("freeze_com", False))
     args.constants = rec.get("constants", args.constants)
     probe = make_probe(args, robot)
     acc_f = spec["accept"]
@@ -695,6 +701,7 @@ def main():
 
     def common(p):
         p.add_argument("--freeze-geometry", action="store_true", help="P9: hip_x / hip_y frozen at the values the turning clip pins (Laikago)")
+        p.add_argument("--freeze-com", action="store_true", help="EXPLORATION, ships nothing: com_x frozen at the clip-pinned 0.00 too (with hip_x / hip_y)")
         p.add_argument("--robots", type=int, default=128)
         p.add_argument("--steps", type=int, default=600)
         p.add_argument("--backend", default="hip", choices=["hip", "oracle"])
