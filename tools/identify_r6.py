@@ -452,7 +452,7 @@ def run(args):
             tag, len(cands), best["J"], best["F"], sum(c["F"] >= acc_f for c in cands), time.time() - t0), flush=True)
 
     nb = 0
-    while time.time() - t0 < 0.3 * budget:          # P2 stage 1
+    while time.time() - t0 < 0.3 * budget or not cands:          # P2 stage 1 (at least one batch, whatever the budget)
         run_batch([random_theta(spec, rng, (nb + i) % 2) for i in range(max(16, probe.SLOTS))], "random")
         nb += 1
         if nb % 16 == 0:
