@@ -210,14 +210,17 @@ def main():
     ap.add_argument("--skip", type=int, default=100)
     ap.add_argument("--stance-mm", type=float, default=6.0)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--table", default="shipped", choices=["shipped", "r05", "r04"], help="r05: round 5's table, on which the diagnosis was first made")
     args = ap.parse_args()
     clip = args.clip or args.policy.rstrip("0")
-    base = robots.laikago()
+    tab = {"shipped": {}, "r05": robots.LAIKAGO_R05, "r04": robots.LAIKAGO_R04}[args.table]
+    base = robots.laikago(**tab)
     kin = clip_kinematics(clip, base, args.stance_mm)
+    print("table: %s" % args.table)
     print(fmt_kin(kin), flush=True)
     res = {"kinematics": kin, "variants": []}
     for name, mo, co in VARIANTS:
-        o = simulate(args.policy, clip, robots.laikago(**mo), args.robots, args.steps, args.skip, co)
+        o = simulate(args.policy, clip, robots.laikago(**dict(tab, **mo)), args.robots, args.steps, args.skip, co)
         o["variant"] = name
         res["variants"].append(o)
         print(fmt_sim(name, o, kin), flush=True)
