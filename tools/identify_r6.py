@@ -529,7 +529,7 @@ def cv(args):
         cmd = [sys.executable, os.path.abspath(__file__), "run", "--robot", "laikago", "--fit"] + fit + ["--holdout"] + hold + [
             "--minutes", str(args.minutes), "--robots", str(args.robots), "--steps", str(args.steps), "--seed", str(args.seed_base + i), "--backend", args.backend,
             "--constants", args.constants, "--out", out, "--dump-all", os.path.join(args.outdir, "split%d_candidates.jsonl.gz" % i)] + (
-            ["--freeze-geometry"] if args.freeze_geometry else [])
+            ["--freeze-geometry"] if args.freeze_geometry else []) + (["--freeze-com"] if args.freeze_com else [])
         log = open(os.path.join(args.outdir, "split%d_log.txt" % i), "w")
         procs.append((i, subprocess.Popen(cmd, stdout=log, stderr=subprocess.STDOUT), log))
         if args.sequential:      # full 4096-robot launches fill the GPU: side by side gains nothing
